@@ -1,0 +1,89 @@
+"""ctypes binding of libfsr_hip.so (the C ABI declared in include/fsr_hip.h).
+
+The product path has exactly one backend: the hipcc-built gfx950 library next to this file.
+If it is missing, `lib()` raises -- there is no CPU or PyTorch fallback.  The only other
+library that can ever be installed here is the thread-per-lane emulation build used by the CPU
+test-suite (tests/emu), and only through the explicit `_install_for_testing` hook.
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libfsr_hip.so")
+
+FSR_F32, FSR_BF16 = 0, 1
+ACT_NONE, ACT_RELU, ACT_LEAKY, ACT_PRELU, ACT_TANH = 0, 1, 2, 3, 4
+CONV_FWD, CONV_DGRAD = 0, 1
+PACK_FWD, PACK_FWD_PS, PACK_DGRAD, PACK_DGRAD_PS = 0, 1, 2, 3
+C3_IN_PLAIN, C3_IN_VGG_NORM, C3_IN_TANH_BWD = 0, 1, 2
+
+c_int, c_float, c_void_p, c_size_t = ctypes.c_int, ctypes.c_float, ctypes.c_void_p, ctypes.c_size_t
+
+
+class ConvDesc(ctypes.Structure):
+    """struct fsr_conv_desc (include/fsr_hip.h)."""
+    _fields_ = [
+        ("dtype", c_int), ("mode", c_int),
+        ("n", c_int), ("ih", c_int), ("iw", c_int), ("cin", c_int),
+        ("oh", c_int), ("ow", c_int), ("cout", c_int),
+        ("stride", c_int), ("act", c_int), ("slope", c_float),
+        ("pixel_shuffle", c_int), ("in_pixel_shuffled", c_int), ("out_f32", c_int),
+    ]
+
+
+# name -> (restype, argtypes); every symbol include/fsr_hip.h declares must appear here
+SIGNATURES = {
+    "fsr_version": (c_int, []),
+    "fsr_last_error": (ctypes.c_char_p, []),
+    "fsr_device_info": (c_int, [ctypes.c_char_p, c_size_t]),
+    "fsr_pack_conv3x3": (c_int, [c_int, c_int, c_void_p, c_int, c_int, c_void_p, c_void_p]),
+    "fsr_conv3x3": (c_int, [ctypes.POINTER(ConvDesc), c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                            c_void_p, c_void_p]),
+}
+
+_lib = None
+_is_emulation = False
+
+
+class FsrError(RuntimeError):
+    pass
+
+
+def _bind(path):
+    handle = ctypes.CDLL(path)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(handle, name)  # AttributeError if the library does not export it
+        fn.restype = res
+        fn.argtypes = args
+    return handle
+
+
+def lib():
+    """The loaded kernel library.  Raises if the HIP extension has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise FsrError(
+                "libfsr_hip.so is missing (%s). Build it with `python fast-srgan_amd/build.py` "
+                "(hipcc, gfx950). There is no fallback path." % LIB_PATH)
+        _lib = _bind(LIB_PATH)
+    return _lib
+
+
+def is_emulation():
+    return _is_emulation
+
+
+def _install_for_testing(path):
+    """TEST HOOK: route calls to the host-emulation build of the same sources (tests/emu)."""
+    global _lib, _is_emulation
+    if path is None:
+        _lib, _is_emulation = None, False
+    else:
+        _lib, _is_emulation = _bind(path), True
+
+
+def check(rc, what=""):
+    if rc != 0:
+        msg = lib().fsr_last_error()
+        raise FsrError("%s failed (%d): %s" % (what or "fsr call", rc, msg.decode() if msg else "?"))

@@ -1,0 +1,357 @@
+// 3x3 convolution as an implicit GEMM on the gfx950 matrix cores (NHWC activations).
+//
+// Replaces the torch.nn.Conv2d(k=3, p=1) calls of the reference on the hot path:
+//   /root/reference/model.py:47-64  (ResidualBlock conv1/conv2, 64->64, no bias)
+//   /root/reference/model.py:86-93  (bottleneck conv)
+//   /root/reference/model.py:30-40  (UpSamplingBlock conv 64->256 + PixelShuffle(2) [+PReLU])
+//   /root/reference/model.py:102-109 (head conv 64->3 + tanh; Cout padded to one 16-wide tile)
+//   /root/reference/model.py:124-131,148-183 (Discriminator SimpleBlock convs, stride 1 and 2)
+//   torchvision vgg19.features[2:34] convs used by /root/reference/model.py:8
+// and, with other tap tables, the data-gradients (dgrad) of all of the above.
+//
+// Work decomposition
+//   workgroup (256 threads = 4 waves) -> TH x 16 output pixels of one image x BN output channels
+//   wave                              -> MT pixel rows (16 px each) x NT 16-wide channel tiles
+//   K loop                            -> input-channel chunks of KC; inside a chunk one step per tap
+// LDS images
+//   halo : [(TH-1)*S+3][15*S+3][KC] input pixels of the current chunk, loaded ONCE per chunk and
+//          re-read by every tap (9x reuse out of LDS instead of L2), pixel pitch KC+16B so that the
+//          16 pixel rows of a fragment spread over the bank row;
+//   wl   : [2][BN][KC] filter slice of the current / next tap (double buffered: the global loads of
+//          tap t+1 are issued before the MFMAs of tap t and written after them - one barrier/tap).
+// MFMA mapping: D[row = output channel][col = pixel] = W[cout][k] * X[k][pixel], so each lane ends
+// up with 4 consecutive output channels of one pixel and the NHWC store is a 8/16-byte vector.
+// K index permutation inside a chunk is free as long as both operands agree; both operands are
+// read as one 16-byte vector per lane: lane group g = lane>>4 owns channels [8g,8g+8) (bf16, one
+// v_mfma_f32_16x16x32_bf16 per 32 channels) or [4g,4g+4) (f32, four v_mfma_f32_16x16x4_f32, MFMA j
+// consuming channel 4g+j).
+#include "fsr_common.h"
+#include "fsr_conv_args.h"
+#include "fsr_host.h"
+
+#include <utility>
+
+template <typename T> struct Frag;
+template <> struct Frag<bf16_t> { typedef s16x8 type; };
+template <> struct Frag<float> { typedef f32x4 type; };
+
+// tap t of the launch: bits 0-1 halo row offset, bits 2-3 halo column offset, bits 4-7 filter slice
+__device__ __forceinline__ unsigned tap_code(const ConvKArgs& a, int t) {
+  return (t < 8) ? (unsigned)((a.taps_lo >> (8 * t)) & 0xffull) : a.taps_hi;
+}
+
+// acc_row[n] with a compile-time-resolvable select chain (n comes from an unrolled loop)
+template <int NT>
+__device__ __forceinline__ f32x4 pick_col(const f32x4 (&row)[NT], int n) {
+  f32x4 r = row[0];
+#pragma unroll
+  for (int j = 1; j < NT; ++j)
+    if (n == j) r = row[j];
+  return r;
+}
+
+// Epilogue for one (pixel, 4 consecutive output channels): optional addend, statistics of the
+// pre-activation, activation, NHWC (or depth-to-space) vector store.
+template <typename T>
+__device__ __forceinline__ void conv_store(const ConvKArgs& a, int img, int gy, int gx, int co, f32x4 v, float slope,
+                                           f32x4& s1, f32x4& s2) {
+  if (gy >= a.GH || gx >= a.GW || co >= a.Cout) return;
+  const int oy = gy * a.osy + a.ooy, ox = gx * a.osx + a.oox;
+  size_t off;
+  if (!a.ps) {
+    off = (((size_t)img * a.FOH + oy) * a.FOW + ox) * a.Cout + co;
+  } else {
+    const int cps = a.Cout >> 2;
+    const int q = co / cps, cc = co - q * cps;
+    off = (((size_t)img * 2 * a.FOH + 2 * oy + (q >> 1)) * (size_t)(2 * a.FOW) + 2 * ox + (q & 1)) * cps + cc;
+  }
+  const bool f32_out = a.out_f32 || sizeof(T) == 4;
+  const bool full = (co + 4 <= a.Cout);
+  if (a.addend) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+      if (co + r < a.Cout)
+        v[r] += f32_out ? ((const float*)a.addend)[off + r] : bf2f(((const bf16_t*)a.addend)[off + r]);
+  }
+  s1 += v;
+  s2 += v * v;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) v[r] = act_apply(v[r], a.act, slope);
+  if (f32_out) {
+    float* o = (float*)a.out + off;
+    if (full && (a.Cout & 3) == 0) {
+      *(f32x4*)o = v;
+    } else {
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        if (co + r < a.Cout) o[r] = v[r];
+    }
+  } else {
+    bf16_t* o = (bf16_t*)a.out + off;
+    if (full && (a.Cout & 3) == 0) {
+      u32x2 pk;
+      pk.x = (unsigned)f2bf(v[0]) | ((unsigned)f2bf(v[1]) << 16);
+      pk.y = (unsigned)f2bf(v[2]) | ((unsigned)f2bf(v[3]) << 16);
+      *(u32x2*)o = pk;
+    } else {
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        if (co + r < a.Cout) o[r] = f2bf(v[r]);
+    }
+  }
+}
+
+template <typename T, int MT, int NT, int... Ms>
+__device__ __forceinline__ void epilogue_rows(const ConvKArgs& a, int img, int gy_base, int gx, int co,
+                                              f32x4 (&acc)[MT][NT], int n, f32x4 bv, float slope, f32x4& s1,
+                                              f32x4& s2, std::integer_sequence<int, Ms...>) {
+  (conv_store<T>(a, img, gy_base + Ms, gx, co, pick_col<NT>(acc[Ms], n) + bv, slope, s1, s2), ...);
+}
+
+template <typename T, int TH, int BN, int WM, int WN, int KC, int S>
+__global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvKArgs a) {
+  static_assert(WM * WN == 4, "4 waves per workgroup");
+  constexpr int MT = TH / WM;
+  constexpr int NT = BN / 16 / WN;
+  constexpr int EPB = 16 / (int)sizeof(T);  // elements per 16-byte unit
+  constexpr int PITCH = KC + EPB;
+  constexpr int UNITS = KC / EPB;
+  constexpr int KSTEP = (sizeof(T) == 2) ? 32 : 16;  // channels consumed per operand vector pair
+  constexpr int WPT = (BN * UNITS + 255) / 256;
+  typedef typename Frag<T>::type frag_t;
+
+  HIP_DYNAMIC_SHARED(char, smem)
+  T* halo = (T*)smem;
+  T* wl = halo + a.HH * a.HW * PITCH;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave / WN, wn = wave % WN;
+  const int l15 = lane & 15, lg = lane >> 4;
+
+  int bid = xcd_remap((int)blockIdx.x, (int)gridDim.x);
+  const int nb = bid % a.nblk_n;
+  bid /= a.nblk_n;
+  const int tx = bid % a.tiles_x;
+  bid /= a.tiles_x;
+  const int ty = bid % a.tiles_y;
+  const int img = bid / a.tiles_y;
+
+  const int gy0 = ty * TH, gx0 = tx * 16;
+  const int iy0 = gy0 * S + a.org_y, ix0 = gx0 * S + a.org_x;
+  const T* in = (const T*)a.in;
+  const T* wpk = (const T*)a.wpk;
+  const int nchunks = a.Cin / KC;
+
+  auto load_halo = [&](int c) {
+    const int total = a.HH * a.HW * UNITS;
+    for (int u = tid; u < total; u += 256) {
+      const int unit = u % UNITS;
+      const int p = u / UNITS;
+      const int hx = p % a.HW, hy = p / a.HW;
+      const int iy = iy0 + hy, ix = ix0 + hx;
+      u32x4 v = (u32x4){0u, 0u, 0u, 0u};
+      if (iy >= 0 && iy < a.IH && ix >= 0 && ix < a.IW) {
+        const int ch = c * KC + unit * EPB;
+        unsigned eoff;  // 32-bit element offset (host guarantees the tensor has < 2^31 elements)
+        if (!a.in_ps) {
+          eoff = (unsigned)((img * a.IH + iy) * a.IW + ix) * (unsigned)a.Cin + (unsigned)ch;
+        } else {
+          const int cps = a.Cin >> 2;
+          const int q = ch / cps, cc = ch - q * cps;
+          eoff = (unsigned)((img * 2 * a.IH + 2 * iy + (q >> 1)) * (2 * a.IW) + 2 * ix + (q & 1)) * (unsigned)cps + (unsigned)cc;
+        }
+        v = *(const u32x4*)(in + eoff);
+      }
+      *(u32x4*)(halo + (size_t)p * PITCH + unit * EPB) = v;
+    }
+  };
+
+  // filter-slice staging registers: global loads for tap t+1 are issued before the MFMAs of tap
+  // t and written to the other LDS buffer after them.
+  u32x4 wreg[WPT];
+#define FSR_WLOAD(tapi, c)                                                                              \
+  {                                                                                                     \
+    const T* base_ = wpk + ((size_t)(tap_code(a, (tapi)) >> 4) * a.CoutPad + (size_t)nb * BN) * a.Cin + (c) * KC; \
+    _Pragma("unroll") for (int i_ = 0; i_ < WPT; ++i_) {                                                \
+      const int u_ = tid + i_ * 256;                                                                    \
+      if ((BN * UNITS) % 256 == 0 || u_ < BN * UNITS)                                                   \
+        wreg[i_] = *(const u32x4*)(base_ + (unsigned)((u_ / UNITS) * a.Cin + (u_ % UNITS) * EPB));      \
+    }                                                                                                   \
+  }
+#define FSR_WSTORE(buf)                                                                                 \
+  {                                                                                                     \
+    _Pragma("unroll") for (int i_ = 0; i_ < WPT; ++i_) {                                                \
+      const int u_ = tid + i_ * 256;                                                                    \
+      if ((BN * UNITS) % 256 == 0 || u_ < BN * UNITS)                                                   \
+        *(u32x4*)(wl + ((size_t)(buf) * BN + (u_ / UNITS)) * PITCH + (u_ % UNITS) * EPB) = wreg[i_];    \
+    }                                                                                                   \
+  }
+
+  f32x4 acc[MT][NT];
+#pragma unroll
+  for (int m = 0; m < MT; ++m)
+#pragma unroll
+    for (int n = 0; n < NT; ++n) acc[m][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  int pixbase[MT], wbase[NT];
+#pragma unroll
+  for (int m = 0; m < MT; ++m) pixbase[m] = (((wm * MT + m) * S) * a.HW + l15 * S) * PITCH + lg * EPB;
+#pragma unroll
+  for (int n = 0; n < NT; ++n) wbase[n] = ((wn * NT + n) * 16 + l15) * PITCH + lg * EPB;
+
+  load_halo(0);
+  FSR_WLOAD(0, 0)
+  FSR_WSTORE(0)
+  __syncthreads();
+
+  int cur = 0;
+  for (int c = 0; c < nchunks; ++c) {
+    for (int t = 0; t < a.ntaps; ++t) {
+      const bool last_tap = (t + 1 == a.ntaps);
+      const bool has_next = !(last_tap && c + 1 == nchunks);
+      if (has_next) FSR_WLOAD(last_tap ? 0 : t + 1, last_tap ? c + 1 : c)
+
+      const T* wcur = wl + (size_t)cur * BN * PITCH;
+      const unsigned tc = tap_code(a, t);
+      const int toff = ((int)(tc & 3u) * a.HW + (int)((tc >> 2) & 3u)) * PITCH;
+#pragma unroll
+      for (int ks = 0; ks < KC / KSTEP; ++ks) {
+        frag_t wf[NT], xf[MT];
+#pragma unroll
+        for (int n = 0; n < NT; ++n) wf[n] = *(const frag_t*)(wcur + wbase[n] + ks * KSTEP);
+#pragma unroll
+        for (int m = 0; m < MT; ++m) xf[m] = *(const frag_t*)(halo + pixbase[m] + toff + ks * KSTEP);
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+#pragma unroll
+          for (int n = 0; n < NT; ++n) {
+            if constexpr (sizeof(T) == 2) {
+              acc[m][n] = mfma_bf16_16x16x32(wf[n], xf[m], acc[m][n]);
+            } else {
+#pragma unroll
+              for (int j = 0; j < 4; ++j) acc[m][n] = mfma_f32_16x16x4(wf[n][j], xf[m][j], acc[m][n]);
+            }
+          }
+      }
+      if (has_next) FSR_WSTORE(cur ^ 1)
+      __syncthreads();
+      cur ^= 1;
+    }
+    if (c + 1 < nchunks) {
+      load_halo(c + 1);
+      __syncthreads();
+    }
+  }
+
+  // ---------------------------------------------------------------- epilogue
+  const float slope = (a.act == FSR_ACT_PRELU) ? a.prelu[0] : a.slope;
+#pragma unroll
+  for (int n = 0; n < NT; ++n) {
+    const int co = nb * BN + (wn * NT + n) * 16 + lg * 4;  // this lane's 4 consecutive channels
+    f32x4 bv = (f32x4){0.f, 0.f, 0.f, 0.f};
+    if (a.bias) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        if (co + r < a.Cout) {
+          // pixel-shuffle launches use filter rows permuted to [q][c]; the bias stays in torch order
+          const int cps = a.Cout >> 2;
+          bv[r] = a.bias[a.ps ? 4 * ((co + r) % cps) + (co + r) / cps : co + r];
+        }
+    }
+    f32x4 s1 = (f32x4){0.f, 0.f, 0.f, 0.f}, s2 = (f32x4){0.f, 0.f, 0.f, 0.f};
+    // static row indices (fold expression): keeps the accumulator array in registers even when
+    // the unrolled epilogue exceeds the compiler's pragma-unroll size threshold
+    epilogue_rows<T, MT, NT>(a, img, gy0 + wm * MT, gx0 + l15, co, acc, n, bv, slope, s1, s2,
+                             std::make_integer_sequence<int, MT>());
+    if (a.stats) {
+      // per-(image, channel) partial sums over this wave's pixels: xor-reduce the 16 pixel lanes
+      // of each lane group, then one atomic per (wave, channel).
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        float x1 = s1[r], x2 = s2[r];
+#pragma unroll
+        for (int o = 8; o >= 1; o >>= 1) {
+          x1 += __shfl_xor(x1, o, 64);
+          x2 += __shfl_xor(x2, o, 64);
+        }
+        if (l15 == 0 && co + r < a.Cout) {
+          float* st = a.stats + ((size_t)img * a.Cout + co + r) * 2;
+          atomicAdd(st, x1);
+          atomicAdd(st + 1, x2);
+        }
+      }
+    }
+  }
+}
+
+#undef FSR_WLOAD
+#undef FSR_WSTORE
+
+// ---------------------------------------------------------------------------- host side
+template <typename T, int TH, int BN, int WM, int WN, int KC, int S>
+static int launch_cfg(ConvKArgs& a, hipStream_t stream) {
+  constexpr int EPB = 16 / (int)sizeof(T);
+  constexpr int PITCH = KC + EPB;
+  if (a.Cin % KC != 0) return fsr_fail(-2, "conv3x3: Cin=%d is not a multiple of the chunk %d", a.Cin, KC);
+  if (a.CoutPad % BN != 0) return fsr_fail(-2, "conv3x3: padded Cout=%d is not a multiple of %d", a.CoutPad, BN);
+  a.tiles_x = (a.GW + 15) / 16;
+  a.tiles_y = (a.GH + TH - 1) / TH;
+  a.nblk_n = a.CoutPad / BN;
+  int maxdy = 0, maxdx = 0;
+  for (int t = 0; t < a.ntaps; ++t) {
+    if (a.tdy[t] > maxdy) maxdy = a.tdy[t];
+    if (a.tdx[t] > maxdx) maxdx = a.tdx[t];
+  }
+  a.taps_lo = 0;
+  a.taps_hi = 0;
+  for (int t = 0; t < a.ntaps; ++t) {
+    const unsigned code = (unsigned)a.tdy[t] | ((unsigned)a.tdx[t] << 2) | ((unsigned)a.tw[t] << 4);
+    if (t < 8) a.taps_lo |= (unsigned long long)code << (8 * t);
+    else a.taps_hi = code;
+  }
+  a.HH = (TH - 1) * S + maxdy + 1;
+  a.HW = 15 * S + maxdx + 1;
+  const size_t lds = ((size_t)a.HH * a.HW * PITCH + 2 * (size_t)BN * PITCH) * sizeof(T);
+  auto kern = conv_igemm_kernel<T, TH, BN, WM, WN, KC, S>;
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+    attr_set = true;
+  }
+  if ((long long)a.N * a.IH * a.IW * a.Cin >= (1LL << 31) || (long long)a.N * a.FOH * a.FOW * a.Cout >= (1LL << 31))
+    return fsr_fail(-2, "conv3x3: tensors with 2^31 or more elements are not supported");
+  const long long nwg = (long long)a.tiles_x * a.tiles_y * a.N * a.nblk_n;
+  if (nwg <= 0 || nwg > 0x7fffffffLL) return fsr_fail(-2, "conv3x3: bad grid");
+  hipLaunchKernelGGL(kern, dim3((unsigned)nwg), dim3(256), lds, stream, a);
+  return fsr_check_launch("conv_igemm_kernel");
+}
+
+template <typename T, int KCW, int KCN>
+static int dispatch_T(ConvKArgs& a, int S, hipStream_t stream) {
+  // KCW: chunk used by the 64-channel "whole filter row in one chunk" config; KCN: normal chunk
+  const int w16 = ((a.GH + 15) / 16) * 16 - a.GH, w8 = ((a.GH + 7) / 8) * 8 - a.GH;
+  const bool th8 = (S == 2) || (w16 - w8 >= 8);
+  if (a.CoutPad == 16) {
+    if (S != 1) return fsr_fail(-2, "conv3x3: thin-Cout config supports stride 1 only");
+    if (a.Cin % KCW == 0) return launch_cfg<T, 16, 16, 4, 1, KCW, 1>(a, stream);
+    return launch_cfg<T, 16, 16, 4, 1, KCN, 1>(a, stream);
+  }
+  if (a.CoutPad % 128 == 0) {
+    if (S == 2) return launch_cfg<T, 8, 128, 2, 2, KCN, 2>(a, stream);
+    if (th8) return launch_cfg<T, 8, 128, 2, 2, KCN, 1>(a, stream);
+    return launch_cfg<T, 16, 128, 2, 2, KCN, 1>(a, stream);
+  }
+  if (a.CoutPad % 64 == 0) {
+    if (S == 2) return launch_cfg<T, 8, 64, 2, 2, KCN, 2>(a, stream);
+    if (th8) return launch_cfg<T, 8, 64, 2, 2, KCN, 1>(a, stream);
+    if (a.Cin % KCW == 0) return launch_cfg<T, 16, 64, 4, 1, KCW, 1>(a, stream);
+    return launch_cfg<T, 16, 64, 4, 1, KCN, 1>(a, stream);
+  }
+  return fsr_fail(-2, "conv3x3: unsupported padded Cout=%d (need 16 or a multiple of 64)", a.CoutPad);
+}
+
+int fsr_conv_igemm_dispatch(int dtype, ConvKArgs& a, int S, hipStream_t stream) {
+  if (dtype == FSR_BF16) return dispatch_T<bf16_t, 64, 32>(a, S, stream);
+  if (dtype == FSR_F32) return dispatch_T<float, 16, 16>(a, S, stream);
+  return fsr_fail(-2, "conv3x3: unknown dtype %d", dtype);
+}

@@ -1,0 +1,139 @@
+// C-ABI entry points: library info, error reporting and the 3x3 convolution front-end that turns
+// an fsr_conv_desc into tap tables for the implicit-GEMM kernel (conv_igemm.hip).
+#include <string.h>
+
+#include "fsr_common.h"
+#include "fsr_conv_args.h"
+#include "fsr_host.h"
+
+static thread_local char g_err[512] = "";
+
+int fsr_fail(int code, const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+  return code;
+}
+
+int fsr_check_launch(const char* what) {
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return fsr_fail(-3, "%s: launch failed: %s", what, hipGetErrorString(e));
+  return 0;
+}
+
+extern "C" int fsr_version(void) { return FSR_ABI_VERSION; }
+extern "C" const char* fsr_last_error(void) { return g_err; }
+
+extern "C" int fsr_device_info(char* buf, size_t buflen) {
+  if (!buf || buflen == 0) return fsr_fail(-1, "fsr_device_info: null buffer");
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return fsr_fail(-3, "fsr_device_info: no HIP device");
+  hipDeviceProp_t p;
+  if (hipGetDeviceProperties(&p, dev) != hipSuccess) return fsr_fail(-3, "fsr_device_info: query failed");
+  snprintf(buf, buflen, "name=%s;arch=%s;cus=%d;hbm_bytes=%zu", p.name, p.gcnArchName, p.multiProcessorCount,
+           (size_t)p.totalGlobalMem);
+  return 0;
+}
+
+extern "C" int fsr_conv3x3(const fsr_conv_desc* d, const void* in, const void* packed_w, const float* bias,
+                           const float* prelu_weight, const void* addend, void* out, float* stats,
+                           fsr_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  if (!d || !in || !packed_w || !out) return fsr_fail(-1, "fsr_conv3x3: null argument");
+  if (d->stride != 1 && d->stride != 2) return fsr_fail(-2, "fsr_conv3x3: stride must be 1 or 2");
+  if (d->act == FSR_ACT_PRELU && !prelu_weight) return fsr_fail(-1, "fsr_conv3x3: PReLU needs its weight");
+  if (d->n <= 0 || d->ih <= 0 || d->iw <= 0 || d->oh <= 0 || d->ow <= 0) return fsr_fail(-2, "fsr_conv3x3: bad dims");
+
+  ConvKArgs a;
+  memset(&a, 0, sizeof(a));
+  a.in = in;
+  a.wpk = packed_w;
+  a.out = out;
+  a.bias = bias;
+  a.prelu = prelu_weight;
+  a.addend = addend;
+  a.stats = stats;
+  a.N = d->n;
+  a.IH = d->ih;
+  a.IW = d->iw;
+  a.Cin = d->cin;
+  a.Cout = d->cout;
+  a.CoutPad = d->cout < 16 ? 16 : d->cout;
+  a.FOH = d->oh;
+  a.FOW = d->ow;
+  a.act = d->act;
+  a.slope = d->slope;
+  a.ps = d->pixel_shuffle;
+  a.in_ps = d->in_pixel_shuffled;
+  a.out_f32 = d->out_f32;
+  if (a.ps && (d->cout % 16 != 0)) return fsr_fail(-2, "fsr_conv3x3: pixel shuffle needs cout %% 16 == 0");
+  if (a.in_ps && (d->cin % 4 != 0)) return fsr_fail(-2, "fsr_conv3x3: in_pixel_shuffled needs cin %% 4 == 0");
+
+  if (d->mode == FSR_CONV_FWD) {
+    if (d->oh != (d->ih - 1) / d->stride + 1 || d->ow != (d->iw - 1) / d->stride + 1)
+      return fsr_fail(-2, "fsr_conv3x3: output dims do not match k=3,p=1,stride=%d", d->stride);
+    a.GH = d->oh;
+    a.GW = d->ow;
+    a.org_y = a.org_x = -1;
+    a.ntaps = 9;
+    for (int ky = 0; ky < 3; ++ky)
+      for (int kx = 0; kx < 3; ++kx) {
+        const int t = ky * 3 + kx;
+        a.tdy[t] = ky;
+        a.tdx[t] = kx;
+        a.tw[t] = t;
+      }
+    a.osy = a.osx = 1;
+    a.ooy = a.oox = 0;
+    return fsr_conv_igemm_dispatch(d->dtype, a, d->stride, stream);
+  }
+  if (d->mode != FSR_CONV_DGRAD) return fsr_fail(-2, "fsr_conv3x3: unknown mode %d", d->mode);
+  if (d->ih != (d->oh - 1) / d->stride + 1 || d->iw != (d->ow - 1) / d->stride + 1)
+    return fsr_fail(-2, "fsr_conv3x3: dgrad dims do not match k=3,p=1,stride=%d", d->stride);
+
+  if (d->stride == 1) {
+    // dx[y,x] = sum_{ky,kx} dy[y+1-ky, x+1-kx] * w[:, :, ky, kx]
+    a.GH = d->oh;
+    a.GW = d->ow;
+    a.org_y = a.org_x = -1;
+    a.ntaps = 9;
+    for (int ky = 0; ky < 3; ++ky)
+      for (int kx = 0; kx < 3; ++kx) {
+        const int t = ky * 3 + kx;
+        a.tdy[t] = 2 - ky;
+        a.tdx[t] = 2 - kx;
+        a.tw[t] = t;
+      }
+    a.osy = a.osx = 1;
+    a.ooy = a.oox = 0;
+    return fsr_conv_igemm_dispatch(d->dtype, a, 1, stream);
+  }
+  // stride 2: split dx into its four parity classes.  For dx row y = 2i+py the contributing
+  // filter rows are ky = 1 (py = 0; dy row i) or ky in {0, 2} (py = 1; dy rows i+1, i).
+  for (int py = 0; py < 2; ++py)
+    for (int px = 0; px < 2; ++px) {
+      ConvKArgs b = a;
+      b.GH = (d->oh - py + 1) / 2;
+      b.GW = (d->ow - px + 1) / 2;
+      if (b.GH <= 0 || b.GW <= 0) continue;
+      b.org_y = b.org_x = 0;
+      b.ntaps = 0;
+      for (int ky = 0; ky < 3; ++ky) {
+        if (((py + 1 - ky) & 1) != 0) continue;
+        for (int kx = 0; kx < 3; ++kx) {
+          if (((px + 1 - kx) & 1) != 0) continue;
+          const int t = b.ntaps++;
+          b.tdy[t] = (py + 1 - ky) / 2;
+          b.tdx[t] = (px + 1 - kx) / 2;
+          b.tw[t] = ky * 3 + kx;
+        }
+      }
+      b.osy = b.osx = 2;
+      b.ooy = py;
+      b.oox = px;
+      int rc = fsr_conv_igemm_dispatch(d->dtype, b, 1, stream);
+      if (rc != 0) return rc;
+    }
+  return 0;
+}

@@ -1,0 +1,84 @@
+// Shared device-side helpers for the gfx950 (CDNA4) Fast-SRGAN kernels.
+//
+// Conventions used by every kernel in this directory:
+//   * activations are NHWC ("pixel-major, channels contiguous"), element type
+//     T = float (exact-f32 parity mode) or bf16 stored as unsigned short;
+//   * a wavefront is 64 lanes; workgroups are 256 threads (4 waves, one per SIMD);
+//   * MFMA shapes: v_mfma_f32_16x16x32_bf16 (bf16 mode) and v_mfma_f32_16x16x4_f32
+//     (f32 mode, exact fmaf-chain numerics at the f32 vector rate);
+//   * accumulator layout (both shapes): lane l, reg r -> row (l>>4)*4+r, col l&15.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef unsigned short bf16_t;  // raw bf16 bits
+
+typedef short s16x8 __attribute__((ext_vector_type(8)));
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));  // one 16-byte staging unit
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x8_hw __attribute__((ext_vector_type(8)));
+
+#ifndef FSR_LDS_PTR
+#define FSR_LDS_PTR(T, p) ((__attribute__((address_space(3))) T*)(p))
+#endif
+
+// dtype / activation / mode enums come from the public ABI header
+#include "fsr_hip.h"
+
+__device__ __forceinline__ float bf2f(bf16_t h) {
+  return __uint_as_float(((unsigned)h) << 16);
+}
+// round-to-nearest-even, NaN kept quiet
+__device__ __forceinline__ bf16_t f2bf(float f) {
+  unsigned u = __float_as_uint(f);
+  if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)((u >> 16) | 0x40);
+  u += 0x7fffu + ((u >> 16) & 1u);
+  return (bf16_t)(u >> 16);
+}
+
+template <typename T> struct ElemIO;
+template <> struct ElemIO<float> {
+  static __device__ __forceinline__ float ld(const float* p) { return *p; }
+  static __device__ __forceinline__ void st(float* p, float v) { *p = v; }
+};
+template <> struct ElemIO<bf16_t> {
+  static __device__ __forceinline__ float ld(const bf16_t* p) { return bf2f(*p); }
+  static __device__ __forceinline__ void st(bf16_t* p, float v) { *p = f2bf(v); }
+};
+
+__device__ __forceinline__ f32x4 mfma_bf16_16x16x32(s16x8 a, s16x8 b, f32x4 c) {
+  return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_hw, a),
+                                                 __builtin_bit_cast(bf16x8_hw, b), c, 0, 0, 0);
+}
+__device__ __forceinline__ f32x4 mfma_f32_16x16x4(float a, float b, f32x4 c) {
+  return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+}
+
+__device__ __forceinline__ float act_apply(float v, int act, float slope) {
+  switch (act) {
+    case FSR_ACT_RELU: return v > 0.f ? v : 0.f;
+    case FSR_ACT_LEAKY:
+    case FSR_ACT_PRELU: return v > 0.f ? v : v * slope;
+    case FSR_ACT_TANH: return tanhf(v);
+    default: return v;
+  }
+}
+
+// sum over the 64 lanes of a wave; every lane gets the total
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+// XCD-aware bijective remap of a linear workgroup id: consecutive logical ids land on
+// the same XCD (dispatcher places hardware block b on XCD b % 8), so neighbouring tiles
+// that share halo rows / filter slices hit the same 4 MiB L2. Speed only, never correctness.
+__device__ __forceinline__ int xcd_remap(int bid, int nwg) {
+  const int q = nwg >> 3, r = nwg & 7;
+  const int xcd = bid & 7, idx = bid >> 3;
+  const int base = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+  return base + idx;
+}

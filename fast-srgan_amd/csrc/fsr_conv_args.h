@@ -1,0 +1,37 @@
+// Kernel-argument blocks for the 3x3 convolution family (host + device view).
+#pragma once
+#include <stddef.h>
+
+// One launch of the generic implicit-GEMM kernel.  A launch produces an output *grid* of
+// GH x GW pixels per image; grid pixel (gy, gx) reads input pixels
+//     (gy*S + org_y + tdy[t], gx*S + org_x + tdx[t])  for t in [0, ntaps)
+// multiplies them with weight slice tw[t] ([CoutPad][Cin], Cin contiguous) and is written to
+// output pixel (gy*osy + ooy, gx*osx + oox).  Forward 3x3 (stride S), data-gradient of a
+// stride-1 conv (flipped taps) and the four parity classes of a stride-2 data-gradient are
+// all instances of this one form.
+struct ConvKArgs {
+  const void* in;
+  const void* wpk;
+  void* out;
+  const float* bias;    // [Cout] or null
+  const float* prelu;   // device scalar, used when act == FSR_ACT_PRELU
+  const void* addend;   // optional tensor with the layout/dtype of `out`, added before the act
+  float* stats;         // optional [N][Cout][2] (sum, sum of squares of the pre-activation)
+  int N, IH, IW, Cin;
+  int GH, GW;
+  int Cout, CoutPad;
+  int org_y, org_x;
+  int ntaps;
+  int tdy[9], tdx[9], tw[9];   // host-side tap table; the kernel reads the packed form below
+  unsigned long long taps_lo;  // taps 0..7, one byte each: tdy | tdx<<2 | tw<<4
+  unsigned taps_hi;            // tap 8
+  int HH, HW;           // halo extent (rows, cols) this launch needs
+  int FOH, FOW;         // spatial dims of the output tensor (before pixel shuffle)
+  int osy, osx, ooy, oox;
+  int act;
+  float slope;
+  int ps;               // epilogue stores depth-to-space(2); weight rows packed [q][c]
+  int in_ps;            // `in` is stored depth-to-space(2) (gradient of a pixel-shuffle conv)
+  int out_f32;          // store float regardless of T
+  int tiles_x, tiles_y, nblk_n;
+};

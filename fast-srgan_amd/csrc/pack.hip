@@ -1,0 +1,61 @@
+// Filter repacking: torch OIHW float parameters -> [tap][rows_pad][K] in the compute dtype.
+// See include/fsr_hip.h (fsr_pack_conv3x3) for the four layouts.
+#include "fsr_common.h"
+#include "fsr_host.h"
+
+template <typename T>
+__global__ void pack_conv3x3_kernel(const float* __restrict__ w, T* __restrict__ out, int cout, int cin, int mode,
+                                    int rows, int rows_pad, int K) {
+  const long long total = 9LL * rows_pad * K;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+       i += (long long)gridDim.x * blockDim.x) {
+    const int k = (int)(i % K);
+    const int row = (int)((i / K) % rows_pad);
+    const int t = (int)(i / ((long long)K * rows_pad));
+    float v = 0.f;
+    if (row < rows) {
+      int co, ci;
+      if (mode == FSR_PACK_FWD || mode == FSR_PACK_FWD_PS) {
+        co = row;
+        ci = k;
+        if (mode == FSR_PACK_FWD_PS) {
+          const int cps = cout >> 2;
+          co = 4 * (row % cps) + row / cps;
+        }
+      } else {
+        ci = row;
+        co = k;
+        if (mode == FSR_PACK_DGRAD_PS) {
+          const int cps = cout >> 2;
+          co = 4 * (k % cps) + k / cps;
+        }
+      }
+      v = w[((size_t)co * cin + ci) * 9 + t];
+    }
+    ElemIO<T>::st(out + i, v);
+  }
+}
+
+extern "C" int fsr_pack_conv3x3(int dtype, int mode, const float* w_oihw, int cout, int cin, void* packed,
+                                fsr_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  if (!w_oihw || !packed) return fsr_fail(-1, "fsr_pack_conv3x3: null argument");
+  if (mode < FSR_PACK_FWD || mode > FSR_PACK_DGRAD_PS) return fsr_fail(-2, "fsr_pack_conv3x3: bad mode %d", mode);
+  if ((mode == FSR_PACK_FWD_PS || mode == FSR_PACK_DGRAD_PS) && cout % 4 != 0)
+    return fsr_fail(-2, "fsr_pack_conv3x3: pixel-shuffle packing needs cout %% 4 == 0");
+  const bool fwd = (mode == FSR_PACK_FWD || mode == FSR_PACK_FWD_PS);
+  const int rows = fwd ? cout : cin, K = fwd ? cin : cout;
+  const int rows_pad = rows < 16 ? 16 : rows;
+  const long long total = 9LL * rows_pad * K;
+  int blocks = (int)((total + 255) / 256);
+  if (blocks > 4096) blocks = 4096;
+  if (dtype == FSR_BF16)
+    hipLaunchKernelGGL(pack_conv3x3_kernel<bf16_t>, dim3(blocks), dim3(256), 0, stream, w_oihw, (bf16_t*)packed, cout,
+                       cin, mode, rows, rows_pad, K);
+  else if (dtype == FSR_F32)
+    hipLaunchKernelGGL(pack_conv3x3_kernel<float>, dim3(blocks), dim3(256), 0, stream, w_oihw, (float*)packed, cout,
+                       cin, mode, rows, rows_pad, K);
+  else
+    return fsr_fail(-2, "fsr_pack_conv3x3: unknown dtype %d", dtype);
+  return fsr_check_launch("pack_conv3x3_kernel");
+}
