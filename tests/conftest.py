@@ -1,0 +1,30 @@
+import importlib
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run by the driver with -m gpu)")
+
+
+@pytest.fixture(scope="session")
+def pkg():
+    """The product package (directory name has a hyphen, so it is imported by string)."""
+    return importlib.import_module("fast-srgan_amd")
+
+
+def load_npz(name):
+    import numpy as np
+    return np.load(os.path.join(GOLDEN, name))
+
+
+def sd_from(npz, prefix):
+    import torch
+    return {k[len(prefix):]: torch.from_numpy(npz[k].copy()) for k in npz.files if k.startswith(prefix)}

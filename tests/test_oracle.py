@@ -1,0 +1,107 @@
+"""Pins oracle/srgan_cpu.py (the CPU restatement) to the outputs of the reference's own modules,
+recorded by tests/golden/make_golden.py.  CPU only."""
+import random
+
+import numpy as np
+import torch
+
+from conftest import load_npz, sd_from
+from oracle import srgan_cpu as O
+
+
+def rel(a, b):
+    return float((a - b).abs().max() / b.abs().max().clamp_min(1e-30))
+
+
+def test_generator_shipped_weights_kat():
+    z = load_npz("g_model_pt.npz")
+    sd = sd_from(z, "sd.")
+    assert len(sd) == 36 and sum(v.numel() for v in sd.values()) == 925646
+    y = O.generator_forward(sd, torch.from_numpy(z["x_small"]))
+    assert rel(y, torch.from_numpy(z["y_small"])) < 1e-5
+    # the SURVEY.md 8c known answer: seed-0 input, full 96x96 batch of 4
+    torch.manual_seed(0)
+    x = torch.rand(4, 3, 96, 96) * 2 - 1
+    y = O.generator_forward(sd, x)
+    assert abs(y.double().sum().item() - float(z["y_sum"])) < 1e-3 * abs(float(z["y_sum"]))
+    assert abs(float(z["y_sum"]) - 86830.994529) < 0.5
+    assert np.allclose(y[0, 0, 0, :4].numpy(), [-0.37453923, -0.60736173, -0.31874713, 0.24013290], atol=2e-5)
+    assert rel(y[:, :, ::16, ::16], torch.from_numpy(z["y_strided"])) < 1e-4
+
+
+def _grads(fwd, sd, x, r):
+    p = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    x = x.clone().requires_grad_(True)
+    y = fwd(p, x)
+    g = torch.autograd.grad((y * r).sum(), [x] + list(p.values()))
+    return y.detach(), g[0], dict(zip(p.keys(), g[1:]))
+
+
+def test_generator_small_forward_backward():
+    z = load_npz("g_small.npz")
+    sd = sd_from(z, "sd.")
+    y, dx, gr = _grads(O.generator_forward, sd, torch.from_numpy(z["x"]), torch.from_numpy(z["r"]))
+    assert rel(y, torch.from_numpy(z["y"])) < 1e-5
+    assert rel(dx, torch.from_numpy(z["dx"])) < 1e-4
+    for k, g in gr.items():
+        assert rel(g, torch.from_numpy(z["grad." + k])) < 2e-4, k
+
+
+def test_discriminator_small_forward_backward():
+    z = load_npz("d_small.npz")
+    sd = sd_from(z, "sd.")
+    y, dx, gr = _grads(O.discriminator_forward, sd, torch.from_numpy(z["x"]), torch.from_numpy(z["r"]))
+    assert y.shape == (2, 1, 4, 3)
+    assert rel(y, torch.from_numpy(z["y"])) < 1e-5
+    assert rel(dx, torch.from_numpy(z["dx"])) < 1e-4
+    for k, g in gr.items():
+        assert rel(g, torch.from_numpy(z["grad." + k])) < 2e-4, k
+
+
+def test_vgg_wrapper_forward_backward():
+    z = load_npz("vgg_small.npz")
+    sd = O.vgg_standin_state_dict(int(z["seed"]), int(z["width_div"]))
+    assert abs(sd["vgg.0.weight"].double().sum().item() - float(z["w0_sum"])) < 1e-9
+    x = torch.from_numpy(z["x"]).requires_grad_(True)
+    y = O.vgg_forward(sd, x)
+    assert y.shape == (2, 512 // int(z["width_div"]), 2, 3)
+    assert rel(y.detach(), torch.from_numpy(z["y"])) < 1e-5
+    (dx,) = torch.autograd.grad((y * torch.from_numpy(z["r"])).sum(), [x])
+    assert rel(dx, torch.from_numpy(z["dx"])) < 1e-4
+
+
+def test_train_steps_match_reference_trainer():
+    """Two iterations of the reference's own Trainer.train (trainer.py:165-196) vs the restatement."""
+    z = load_npz("train_steps.npz")
+    g, d = sd_from(z, "g0."), sd_from(z, "d0.")
+    v = O.vgg_standin_state_dict(int(z["vgg_seed"]), int(z["vgg_width_div"]))
+    gs, ds = {}, {}
+    for it in range(2):
+        noise = [torch.from_numpy(z[f"noise{3 * it + j}"]) for j in range(3)]
+        out = O.train_step(g, d, v, torch.from_numpy(z[f"lr{it}"]), torch.from_numpy(z[f"hr{it}"]), noise, gs, ds)
+        got = np.array([out["loss_real"], out["loss_fake"], out["adv_loss"], out["content_loss"]], dtype=np.float64)
+        assert np.allclose(got, z["losses"][it], rtol=2e-5), (it, got, z["losses"][it])
+    # Parameters after two AdamW steps.  Adam normalises every element's update to ~lr whatever the
+    # gradient's size, so elements whose gradient is tiny inherit its (large) relative fp32 noise:
+    # compare in the mean, relative to the mean update the two steps made.
+    for pre, cur in (("g", g), ("d", d)):
+        for k, p in cur.items():
+            p0, p2 = torch.from_numpy(z[f"{pre}0.{k}"]), torch.from_numpy(z[f"{pre}2.{k}"])
+            upd = (p2 - p0).abs().mean()
+            assert upd > 0 and (p - p2).abs().mean() <= 0.08 * upd, (pre, k)
+
+
+def test_dataset_item_matches_reference_dataset():
+    z = load_npz("dataset.npz")
+    random.seed(int(z["seed"]))
+    for i in range(3):
+        lr, hr, _ = O.dataset_item(z["image"], 12, 4)
+        assert torch.equal(hr, torch.from_numpy(z[f"hr{i}"]))
+        assert (lr - torch.from_numpy(z[f"lr{i}"])).abs().max() < 5e-6  # LR overshoots [-1,1]: no clamp
+    assert max(float(np.abs(z[f"lr{i}"]).max()) for i in range(3)) > 1.0
+
+
+def test_postprocess_truncates():
+    y = torch.tensor([[[[-1.0, 0.0, 0.999, 0.5019]]] * 3])
+    u = O.postprocess_u8(y)
+    assert u.dtype == np.uint8 and u[0, 0] == 0 and u[1, 0] == 127 and u[2, 0] == 254 and u[3, 0] == 191
