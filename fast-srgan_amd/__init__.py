@@ -1,0 +1,9 @@
+"""fast-srgan_amd: MI355X-native (gfx950) hot path of Fast-SRGAN behind the reference's Python surface.
+
+The directory name carries a hyphen (it mirrors the upstream repository name), so import it with
+`importlib.import_module("fast-srgan_amd")` or through the `fast_srgan_amd` alias module at the repo root.
+"""
+from . import _lib  # noqa: F401
+from .model import VGG19, Discriminator, Generator  # noqa: F401
+
+__all__ = ["Generator", "Discriminator", "VGG19"]

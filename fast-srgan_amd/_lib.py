@@ -15,9 +15,9 @@ FSR_F32, FSR_BF16 = 0, 1
 ACT_NONE, ACT_RELU, ACT_LEAKY, ACT_PRELU, ACT_TANH = 0, 1, 2, 3, 4
 CONV_FWD, CONV_DGRAD = 0, 1
 PACK_FWD, PACK_FWD_PS, PACK_DGRAD, PACK_DGRAD_PS = 0, 1, 2, 3
-C3_IN_PLAIN, C3_IN_VGG_NORM, C3_IN_TANH_BWD = 0, 1, 2
+ABI_VERSION = 2
 
-c_int, c_float, c_void_p, c_size_t = ctypes.c_int, ctypes.c_float, ctypes.c_void_p, ctypes.c_size_t
+c_int, c_float, c_void_p, c_size_t, c_ll = ctypes.c_int, ctypes.c_float, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_longlong
 
 
 class ConvDesc(ctypes.Structure):
@@ -31,14 +31,43 @@ class ConvDesc(ctypes.Structure):
     ]
 
 
+class WgradDesc(ctypes.Structure):
+    """struct fsr_wgrad_desc (include/fsr_hip.h)."""
+    _fields_ = [
+        ("dtype", c_int),
+        ("n", c_int), ("ih", c_int), ("iw", c_int), ("cin_pad", c_int), ("cin", c_int),
+        ("oh", c_int), ("ow", c_int), ("cout_pad", c_int), ("cout", c_int),
+        ("stride", c_int), ("dy_pixel_shuffled", c_int),
+    ]
+
+
+P = c_void_p
 # name -> (restype, argtypes); every symbol include/fsr_hip.h declares must appear here
 SIGNATURES = {
     "fsr_version": (c_int, []),
     "fsr_last_error": (ctypes.c_char_p, []),
     "fsr_device_info": (c_int, [ctypes.c_char_p, c_size_t]),
-    "fsr_pack_conv3x3": (c_int, [c_int, c_int, c_void_p, c_int, c_int, c_void_p, c_void_p]),
-    "fsr_conv3x3": (c_int, [ctypes.POINTER(ConvDesc), c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
-                            c_void_p, c_void_p]),
+    "fsr_pack_conv3x3": (c_int, [c_int, c_int, P, c_int, c_int, c_int, P, P]),
+    "fsr_conv3x3": (c_int, [ctypes.POINTER(ConvDesc), P, P, P, P, P, P, P, P, P]),
+    "fsr_conv3x3_wgrad_workspace": (c_size_t, [ctypes.POINTER(WgradDesc)]),
+    "fsr_conv3x3_wgrad": (c_int, [ctypes.POINTER(WgradDesc), P, P, P, P, P]),
+    "fsr_instnorm_act_fwd": (c_int, [c_int, P, P, P, c_int, c_float, P, P, c_int, c_int, c_int, P]),
+    "fsr_instnorm_act_bwd_reduce": (c_int, [c_int, P, P, P, c_int, c_float, P, P, P, c_int, c_int, c_int, P]),
+    "fsr_instnorm_act_bwd_apply": (c_int, [c_int, P, P, P, P, c_int, c_float, P, P, c_int, c_int, c_int, P]),
+    "fsr_act_bwd": (c_int, [c_int, P, P, c_int, c_float, P, P, P, P, c_int, c_int, c_int, c_int, c_int, P]),
+    "fsr_image_to_nhwc": (c_int, [c_int, P, c_ll, c_ll, c_ll, c_ll, c_int, c_int, c_int, c_float, c_float, c_float,
+                                  c_float, c_float, c_float, P, c_int, P]),
+    "fsr_tanh_bwd_to_nhwc": (c_int, [c_int, P, c_ll, c_ll, c_ll, c_ll, P, c_int, c_int, c_int, P, c_int, P, P]),
+    "fsr_maxpool2_fwd": (c_int, [c_int, P, P, c_int, c_int, c_int, c_int, P]),
+    "fsr_maxpool2_bwd": (c_int, [c_int, P, P, P, P, c_int, c_int, c_int, c_int, P]),
+    "fsr_conv1x1_c1_fwd": (c_int, [c_int, P, P, P, P, c_int, c_int, P]),
+    "fsr_conv1x1_c1_bwd": (c_int, [c_int, P, P, P, P, P, P, c_int, c_int, P]),
+    "fsr_bce_logits_fwd": (c_int, [P, P, P, c_ll, P]),
+    "fsr_bce_logits_bwd": (c_int, [P, P, P, P, c_ll, P]),
+    "fsr_smooth_l1_fwd": (c_int, [c_int, P, P, P, c_ll, P]),
+    "fsr_smooth_l1_bwd": (c_int, [c_int, P, P, P, P, c_ll, P]),
+    "fsr_adamw_step": (c_int, [P, P, P, P, c_ll, c_float, c_float, c_float, c_float, c_float, c_int, P]),
+    "fsr_crop_resize": (c_int, [P, P, P, P, P, c_int, c_int, c_int, P, P, P, c_int, P, P, P, P]),
 }
 
 _lib = None

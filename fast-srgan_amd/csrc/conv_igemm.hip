@@ -50,8 +50,36 @@ __device__ __forceinline__ f32x4 pick_col(const f32x4 (&row)[NT], int n) {
   return r;
 }
 
-// Epilogue for one (pixel, 4 consecutive output channels): optional addend, statistics of the
-// pre-activation, activation, NHWC (or depth-to-space) vector store.
+// 4 consecutive channels of one pixel -> memory (16/8-byte vector when the channel count allows)
+template <typename T>
+__device__ __forceinline__ void store4(void* base, size_t off, f32x4 v, int co, int Cout, bool f32_out) {
+  const bool full = (co + 4 <= Cout) && ((Cout & 3) == 0);
+  if (f32_out) {
+    float* o = (float*)base + off;
+    if (full) {
+      *(f32x4*)o = v;
+    } else {
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        if (co + r < Cout) o[r] = v[r];
+    }
+  } else {
+    bf16_t* o = (bf16_t*)base + off;
+    if (full) {
+      u32x2 pk;
+      pk.x = (unsigned)f2bf(v[0]) | ((unsigned)f2bf(v[1]) << 16);
+      pk.y = (unsigned)f2bf(v[2]) | ((unsigned)f2bf(v[3]) << 16);
+      *(u32x2*)o = pk;
+    } else {
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        if (co + r < Cout) o[r] = f2bf(v[r]);
+    }
+  }
+}
+
+// Epilogue for one (pixel, 4 consecutive output channels): statistics of the pre-activation,
+// optional pre-activation store, activation, NHWC (or depth-to-space) vector store.
 template <typename T>
 __device__ __forceinline__ void conv_store(const ConvKArgs& a, int img, int gy, int gx, int co, f32x4 v, float slope,
                                            f32x4& s1, f32x4& s2) {
@@ -66,46 +94,21 @@ __device__ __forceinline__ void conv_store(const ConvKArgs& a, int img, int gy, 
     off = (((size_t)img * 2 * a.FOH + 2 * oy + (q >> 1)) * (size_t)(2 * a.FOW) + 2 * ox + (q & 1)) * cps + cc;
   }
   const bool f32_out = a.out_f32 || sizeof(T) == 4;
-  const bool full = (co + 4 <= a.Cout);
-  if (a.addend) {
-#pragma unroll
-    for (int r = 0; r < 4; ++r)
-      if (co + r < a.Cout)
-        v[r] += f32_out ? ((const float*)a.addend)[off + r] : bf2f(((const bf16_t*)a.addend)[off + r]);
-  }
+  // a pixel-shuffled store keeps 4-channel groups intact only inside one quadrant slice
+  const int climit = a.ps ? (co / (a.Cout >> 2) + 1) * (a.Cout >> 2) : a.Cout;
   s1 += v;
   s2 += v * v;
+  if (a.preact) store4<T>(a.preact, off, v, co, climit, f32_out);
 #pragma unroll
   for (int r = 0; r < 4; ++r) v[r] = act_apply(v[r], a.act, slope);
-  if (f32_out) {
-    float* o = (float*)a.out + off;
-    if (full && (a.Cout & 3) == 0) {
-      *(f32x4*)o = v;
-    } else {
-#pragma unroll
-      for (int r = 0; r < 4; ++r)
-        if (co + r < a.Cout) o[r] = v[r];
-    }
-  } else {
-    bf16_t* o = (bf16_t*)a.out + off;
-    if (full && (a.Cout & 3) == 0) {
-      u32x2 pk;
-      pk.x = (unsigned)f2bf(v[0]) | ((unsigned)f2bf(v[1]) << 16);
-      pk.y = (unsigned)f2bf(v[2]) | ((unsigned)f2bf(v[3]) << 16);
-      *(u32x2*)o = pk;
-    } else {
-#pragma unroll
-      for (int r = 0; r < 4; ++r)
-        if (co + r < a.Cout) o[r] = f2bf(v[r]);
-    }
-  }
+  store4<T>(a.out, off, v, co, climit, f32_out);
 }
 
 template <typename T, int MT, int NT, int... Ms>
 __device__ __forceinline__ void epilogue_rows(const ConvKArgs& a, int img, int gy_base, int gx, int co,
-                                              f32x4 (&acc)[MT][NT], int n, f32x4 bv, float slope, f32x4& s1,
+                                              f32x4 (&acc)[MT][NT], int n, f32x4 sv, f32x4 bv, float slope, f32x4& s1,
                                               f32x4& s2, std::integer_sequence<int, Ms...>) {
-  (conv_store<T>(a, img, gy_base + Ms, gx, co, pick_col<NT>(acc[Ms], n) + bv, slope, s1, s2), ...);
+  (conv_store<T>(a, img, gy_base + Ms, gx, co, pick_col<NT>(acc[Ms], n) * sv + bv, slope, s1, s2), ...);
 }
 
 template <typename T, int TH, int BN, int WM, int WN, int KC, int S>
@@ -258,10 +261,16 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvKArgs a) {
           bv[r] = a.bias[a.ps ? 4 * ((co + r) % cps) + (co + r) / cps : co + r];
         }
     }
+    f32x4 sv = (f32x4){1.f, 1.f, 1.f, 1.f};
+    if (a.oscale) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        if (co + r < a.Cout) sv[r] = a.oscale[co + r];
+    }
     f32x4 s1 = (f32x4){0.f, 0.f, 0.f, 0.f}, s2 = (f32x4){0.f, 0.f, 0.f, 0.f};
     // static row indices (fold expression): keeps the accumulator array in registers even when
     // the unrolled epilogue exceeds the compiler's pragma-unroll size threshold
-    epilogue_rows<T, MT, NT>(a, img, gy0 + wm * MT, gx0 + l15, co, acc, n, bv, slope, s1, s2,
+    epilogue_rows<T, MT, NT>(a, img, gy0 + wm * MT, gx0 + l15, co, acc, n, sv, bv, slope, s1, s2,
                              std::make_integer_sequence<int, MT>());
     if (a.stats) {
       // per-(image, channel) partial sums over this wave's pixels: xor-reduce the 16 pixel lanes
@@ -331,11 +340,6 @@ static int dispatch_T(ConvKArgs& a, int S, hipStream_t stream) {
   // KCW: chunk used by the 64-channel "whole filter row in one chunk" config; KCN: normal chunk
   const int w16 = ((a.GH + 15) / 16) * 16 - a.GH, w8 = ((a.GH + 7) / 8) * 8 - a.GH;
   const bool th8 = (S == 2) || (w16 - w8 >= 8);
-  if (a.CoutPad == 16) {
-    if (S != 1) return fsr_fail(-2, "conv3x3: thin-Cout config supports stride 1 only");
-    if (a.Cin % KCW == 0) return launch_cfg<T, 16, 16, 4, 1, KCW, 1>(a, stream);
-    return launch_cfg<T, 16, 16, 4, 1, KCN, 1>(a, stream);
-  }
   if (a.CoutPad % 128 == 0) {
     if (S == 2) return launch_cfg<T, 8, 128, 2, 2, KCN, 2>(a, stream);
     if (th8) return launch_cfg<T, 8, 128, 2, 2, KCN, 1>(a, stream);
@@ -347,7 +351,12 @@ static int dispatch_T(ConvKArgs& a, int S, hipStream_t stream) {
     if (a.Cin % KCW == 0) return launch_cfg<T, 16, 64, 4, 1, KCW, 1>(a, stream);
     return launch_cfg<T, 16, 64, 4, 1, KCN, 1>(a, stream);
   }
-  return fsr_fail(-2, "conv3x3: unsupported padded Cout=%d (need 16 or a multiple of 64)", a.CoutPad);
+  if (a.CoutPad % 16 == 0) {  // thin outputs (head conv, image gradients) and small test networks
+    if (S == 2) return launch_cfg<T, 8, 16, 4, 1, KCN, 2>(a, stream);
+    if (a.Cin % KCW == 0) return launch_cfg<T, 16, 16, 4, 1, KCW, 1>(a, stream);
+    return launch_cfg<T, 16, 16, 4, 1, KCN, 1>(a, stream);
+  }
+  return fsr_fail(-2, "conv3x3: unsupported padded Cout=%d (need a multiple of 16)", a.CoutPad);
 }
 
 int fsr_conv_igemm_dispatch(int dtype, ConvKArgs& a, int S, hipStream_t stream) {

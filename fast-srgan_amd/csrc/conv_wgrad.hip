@@ -1,0 +1,302 @@
+// Weight gradient of the 3x3 convolutions as a split-K implicit GEMM on the matrix cores.
+//
+//   dW[tap][co][ci] = sum over (image, output pixel) of dy[pixel][co] * x[pixel*S + tap - 1][ci]
+//
+// i.e. autograd's weight gradient of every Conv2d(k=3,p=1) the reference trains:
+//   /root/reference/model.py:30-35, 47-64, 75-76, 86-93, 103-108 (Generator)
+//   /root/reference/model.py:124-131, 143-183 (Discriminator)
+//
+// GEMM view: M = Cout, N = Cin (x 9 taps), K = N*OH*OW output pixels.  The contraction index is
+// the PIXEL, which is the strided dimension of NHWC tensors, so both MFMA operands have to be
+// transposed on the way from LDS to registers:
+//   bf16 : ds_read_b64_tr_b16 -- each 16-lane group reads a [4 pixels][16 channels] block and every
+//          lane receives one channel's 4 pixels; two reads feed one v_mfma_f32_16x16x32_bf16;
+//   f32  : v_mfma_f32_16x16x4_f32 takes ONE element per lane, lane (l&15, l>>4) = (channel, pixel):
+//          a plain ds_read_b32 with the 16 channel lanes on consecutive banks.
+// Work decomposition
+//   workgroup -> BM output channels x BN input channels x all 9 taps, for a slab of pixel tiles
+//                (TPH x 16 output pixels each); the dy tile and the x halo of a pixel tile are
+//                staged in LDS once and reused by all 9 taps (x) / all taps and channel tiles (dy);
+//   wave      -> one 16-row co tile x TPW 16-wide ci tiles x 9 taps of accumulators in registers;
+//   split-K   -> slabs write f32 partials [slab][9][cout_pad][cin_pad] to the workspace; a second
+//                kernel sums the slabs and adds the result into the OIHW float gradient.
+#include "fsr_common.h"
+#include "fsr_host.h"
+
+struct WgradKArgs {
+  const void* x;
+  const void* dy;
+  float* ws;
+  int N, IH, IW, CinPad;
+  int OH, OW, CoutPad;
+  int dy_ps;
+  int tiles_x, tiles_y, tiles_total, tiles_per_slab, nslab;
+  int nbm, nbn;
+};
+
+template <typename T, int BM, int BN, int S, int TPH>
+__global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradKArgs a) {
+  constexpr int EPB = 16 / (int)sizeof(T);
+  constexpr int PAD = 16;
+  constexpr int PA = BM + PAD, PB = BN + PAD;  // LDS pixel pitches (elements)
+  constexpr int HH = (TPH - 1) * S + 3, HW = 15 * S + 3;
+  constexpr int NPAIR = (BM / 16) * (BN / 16);
+  constexpr int TPW = (NPAIR + 3) / 4;  // (co tile, ci tile) pairs per wave; all share one co tile
+  constexpr int NBT = BN / 16;
+  static_assert(TPW <= NBT, "a wave's pairs must share its co tile");
+  constexpr int TPIX = TPH * 16;
+
+  HIP_DYNAMIC_SHARED(char, smem)
+  T* dyt = (T*)smem;              // [TPIX][PA]
+  T* halo = dyt + TPIX * PA;      // [HH*HW][PB]
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int l15 = lane & 15, lg = lane >> 4;
+  int bid = (int)blockIdx.x;
+  const int bn = bid % a.nbn;
+  bid /= a.nbn;
+  const int bm = bid % a.nbm;
+  const int slab = bid / a.nbm;
+
+  const bool active = wave * TPW < NPAIR;
+  const int co_t = (wave * TPW) / NBT, ci_t0 = (wave * TPW) % NBT;
+
+  f32x4 acc[9][TPW];
+#pragma unroll
+  for (int t = 0; t < 9; ++t)
+#pragma unroll
+    for (int j = 0; j < TPW; ++j) acc[t][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  const T* xg = (const T*)a.x;
+  const T* dyg = (const T*)a.dy;
+  const int tile0 = slab * a.tiles_per_slab;
+  const int tile1 = (tile0 + a.tiles_per_slab < a.tiles_total) ? tile0 + a.tiles_per_slab : a.tiles_total;
+
+  for (int tile = tile0; tile < tile1; ++tile) {
+    const int tx = tile % a.tiles_x;
+    const int ty = (tile / a.tiles_x) % a.tiles_y;
+    const int img = tile / (a.tiles_x * a.tiles_y);
+    const int oy0 = ty * TPH, ox0 = tx * 16;
+    __syncthreads();  // the previous tile's LDS images are dead
+    // ---- stage dy tile: [TPIX][BM]
+    for (int u = tid; u < TPIX * (BM / EPB); u += 256) {
+      const int unit = u % (BM / EPB), p = u / (BM / EPB);
+      const int oy = oy0 + p / 16, ox = ox0 + (p & 15);
+      u32x4 v = (u32x4){0u, 0u, 0u, 0u};
+      if (oy < a.OH && ox < a.OW) {
+        const int ch = bm * BM + unit * EPB;
+        unsigned eoff;
+        if (!a.dy_ps) {
+          eoff = (unsigned)((img * a.OH + oy) * a.OW + ox) * (unsigned)a.CoutPad + (unsigned)ch;
+        } else {
+          const int cps = a.CoutPad >> 2;
+          const int q = ch / cps, cc = ch - q * cps;
+          eoff = (unsigned)((img * 2 * a.OH + 2 * oy + (q >> 1)) * (2 * a.OW) + 2 * ox + (q & 1)) * (unsigned)cps + (unsigned)cc;
+        }
+        v = *(const u32x4*)(dyg + eoff);
+      }
+      *(u32x4*)(dyt + p * PA + unit * EPB) = v;
+    }
+    // ---- stage x halo: [HH][HW][BN]
+    const int iy0 = oy0 * S - 1, ix0 = ox0 * S - 1;
+    for (int u = tid; u < HH * HW * (BN / EPB); u += 256) {
+      const int unit = u % (BN / EPB), p = u / (BN / EPB);
+      const int iy = iy0 + p / HW, ix = ix0 + p % HW;
+      u32x4 v = (u32x4){0u, 0u, 0u, 0u};
+      if (iy >= 0 && iy < a.IH && ix >= 0 && ix < a.IW)
+        v = *(const u32x4*)(xg + (unsigned)((img * a.IH + iy) * a.IW + ix) * (unsigned)a.CinPad + (unsigned)(bn * BN + unit * EPB));
+      *(u32x4*)(halo + p * PB + unit * EPB) = v;
+    }
+    __syncthreads();
+    if (!active) continue;
+
+    if constexpr (sizeof(T) == 2) {
+      // K step = 32 pixels = tile rows 2s, 2s+1; lane group g owns pixels k = 8g..8g+7:
+      // row 2s + (g>>1), columns 8(g&1) .. +7.  A transposing read h (0/1) fetches pixels 4h..4h+3:
+      // group-lane q supplies pixel 4h + (q>>2), channel chunk q&3.
+      const int qrow = l15 >> 2, qch = (l15 & 3) * 4;
+#pragma unroll 1
+      for (int s = 0; s < TPH / 2; ++s) {
+        const int r = 2 * s + (lg >> 1);
+        const int c0 = 8 * (lg & 1);
+        s16x8 af;
+        {
+          const T* pa = dyt + (r * 16 + c0 + qrow) * PA + co_t * 16 + qch;
+          const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(FSR_LDS_PTR(s16x4, pa));
+          const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(FSR_LDS_PTR(s16x4, pa + 4 * PA));
+          af = (s16x8){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+        }
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+          const int ky = t / 3, kx = t % 3;
+          const T* pb0 = halo + ((r * S + ky) * HW + (c0 + qrow) * S + kx) * PB + ci_t0 * 16 + qch;
+#pragma unroll
+          for (int j = 0; j < TPW; ++j) {
+            const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(FSR_LDS_PTR(s16x4, pb0 + j * 16));
+            const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(FSR_LDS_PTR(s16x4, pb0 + j * 16 + 4 * S * PB));
+            const s16x8 bf = (s16x8){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+            acc[t][j] = mfma_bf16_16x16x32(af, bf, acc[t][j]);
+          }
+        }
+      }
+    } else {
+      // K step = 4 pixels of one row: pixel k = lg -> (row s>>2, column 4(s&3) + lg)
+#pragma unroll 1
+      for (int s = 0; s < TPH * 4; ++s) {
+        const int r = s >> 2, c = 4 * (s & 3) + lg;
+        const float av = dyt[(r * 16 + c) * PA + co_t * 16 + l15];
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+          const int ky = t / 3, kx = t % 3;
+          const T* pb = halo + ((r * S + ky) * HW + c * S + kx) * PB + ci_t0 * 16 + l15;
+#pragma unroll
+          for (int j = 0; j < TPW; ++j) acc[t][j] = mfma_f32_16x16x4(av, pb[j * 16], acc[t][j]);
+        }
+      }
+    }
+  }
+
+  if (!active) return;
+  // partial tile -> workspace [slab][tap][cout_pad][cin_pad]; D layout: lane column = ci, rows 4*lg+r = co
+#pragma unroll
+  for (int t = 0; t < 9; ++t)
+#pragma unroll
+    for (int j = 0; j < TPW; ++j) {
+      float* o = a.ws + (((size_t)slab * 9 + t) * a.CoutPad + bm * BM + co_t * 16 + lg * 4) * a.CinPad + bn * BN + (ci_t0 + j) * 16 + l15;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) o[(size_t)r * a.CinPad] = acc[t][j][r];
+    }
+}
+
+// dw[co][ci][tap] += sum_slab ws[slab][tap][row(co)][ci]; row(co) undoes the pixel-shuffle row order.
+__global__ __launch_bounds__(256) void conv_wgrad_reduce_kernel(const float* __restrict__ ws, float* __restrict__ dw, int nslab,
+                                                                int cout, int cin, int cout_pad, int cin_pad, int ps) {
+  const int total = 9 * cout * cin;
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < total; i += gridDim.x * 256) {
+    const int ci = i % cin;
+    const int co = (i / cin) % cout;
+    const int t = i / (cin * cout);
+    const int row = ps ? (co & 3) * (cout_pad >> 2) + (co >> 2) : co;
+    const float* p = ws + ((size_t)t * cout_pad + row) * cin_pad + ci;
+    const size_t stride = (size_t)9 * cout_pad * cin_pad;
+    float s = 0.f;
+    for (int k = 0; k < nslab; ++k) s += p[k * stride];
+    dw[((size_t)co * cin + ci) * 9 + t] += s;
+  }
+}
+
+namespace {
+
+struct WgradPlan {
+  int BM, BN, TPH, S;
+  int tiles_x, tiles_y, tiles_total, tiles_per_slab, nslab, nbm, nbn;
+  size_t lds;
+};
+
+int make_plan(const fsr_wgrad_desc* d, WgradPlan& p) {
+  if (!d) return fsr_fail(-1, "conv3x3_wgrad: null descriptor");
+  if (d->dtype != FSR_F32 && d->dtype != FSR_BF16) return fsr_fail(-2, "conv3x3_wgrad: unknown dtype %d", d->dtype);
+  const int cpad = d->dtype == FSR_BF16 ? 32 : 16;
+  if (d->stride != 1 && d->stride != 2) return fsr_fail(-2, "conv3x3_wgrad: stride must be 1 or 2");
+  if (d->cin_pad % cpad || d->cin_pad <= 0) return fsr_fail(-2, "conv3x3_wgrad: cin_pad %d is not a multiple of %d", d->cin_pad, cpad);
+  if (d->cout_pad % 16 || d->cout_pad <= 0) return fsr_fail(-2, "conv3x3_wgrad: cout_pad %d is not a multiple of 16", d->cout_pad);
+  if (d->dtype == FSR_BF16 && d->cout_pad % 8) return fsr_fail(-2, "conv3x3_wgrad: bad cout_pad");
+  if (d->cin > d->cin_pad || d->cout > d->cout_pad || d->cin <= 0 || d->cout <= 0) return fsr_fail(-2, "conv3x3_wgrad: bad channel counts");
+  if (d->oh != (d->ih - 1) / d->stride + 1 || d->ow != (d->iw - 1) / d->stride + 1)
+    return fsr_fail(-2, "conv3x3_wgrad: output dims do not match k=3,p=1,stride=%d", d->stride);
+  if (d->dy_pixel_shuffled && (d->cout_pad % 64 || d->cout != d->cout_pad))
+    return fsr_fail(-2, "conv3x3_wgrad: pixel-shuffled dy needs cout %% 64 == 0");
+  if ((long long)d->n * d->ih * d->iw * d->cin_pad >= (1LL << 31) || (long long)d->n * d->oh * d->ow * d->cout_pad >= (1LL << 31))
+    return fsr_fail(-2, "conv3x3_wgrad: tensors with 2^31 or more elements are not supported");
+  p.S = d->stride;
+  p.BM = (d->cout_pad % 64 == 0) ? 64 : 16;
+  p.BN = (d->cin_pad % 64 == 0) ? 64 : (d->cin_pad % 32 == 0 ? 32 : 16);
+  if (d->dy_pixel_shuffled && (d->cout_pad / 4) % p.BM) p.BM = 16;  // a BM block must stay inside one quadrant slice
+  p.TPH = d->dtype == FSR_BF16 ? 8 : 4;
+  p.tiles_x = (d->ow + 15) / 16;
+  p.tiles_y = (d->oh + p.TPH - 1) / p.TPH;
+  p.tiles_total = p.tiles_x * p.tiles_y * d->n;
+  p.nbm = d->cout_pad / p.BM;
+  p.nbn = d->cin_pad / p.BN;
+  int want = (768 + p.nbm * p.nbn - 1) / (p.nbm * p.nbn);  // ~3 workgroups per CU in total
+  if (want > p.tiles_total) want = p.tiles_total;
+  if (want < 1) want = 1;
+  p.tiles_per_slab = (p.tiles_total + want - 1) / want;
+  p.nslab = (p.tiles_total + p.tiles_per_slab - 1) / p.tiles_per_slab;
+  const int es = d->dtype == FSR_BF16 ? 2 : 4;
+  const int HH = (p.TPH - 1) * p.S + 3, HW = 15 * p.S + 3;
+  p.lds = ((size_t)p.TPH * 16 * (p.BM + 16) + (size_t)HH * HW * (p.BN + 16)) * es;
+  return 0;
+}
+
+template <typename T, int BM, int BN, int S, int TPH>
+int launch_wgrad(const WgradKArgs& a, size_t lds, hipStream_t stream) {
+  auto kern = conv_wgrad_kernel<T, BM, BN, S, TPH>;
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(kern, dim3((unsigned)(a.nslab * a.nbm * a.nbn)), dim3(256), lds, stream, a);
+  return fsr_check_launch("conv_wgrad_kernel");
+}
+
+template <typename T, int TPH>
+int dispatch_wgrad(const WgradPlan& p, const WgradKArgs& a, hipStream_t stream) {
+#define FSR_WG_CASE(bm, bn)                                                           \
+  if (p.BM == bm && p.BN == bn)                                                       \
+    return p.S == 1 ? launch_wgrad<T, bm, bn, 1, TPH>(a, p.lds, stream) : launch_wgrad<T, bm, bn, 2, TPH>(a, p.lds, stream);
+  FSR_WG_CASE(64, 64)
+  FSR_WG_CASE(64, 32)
+  FSR_WG_CASE(16, 64)
+  FSR_WG_CASE(16, 32)
+  if constexpr (sizeof(T) == 4) {
+    FSR_WG_CASE(64, 16)
+    FSR_WG_CASE(16, 16)
+  }
+#undef FSR_WG_CASE
+  return fsr_fail(-2, "conv3x3_wgrad: no kernel for block %dx%d", p.BM, p.BN);
+}
+
+}  // namespace
+
+extern "C" size_t fsr_conv3x3_wgrad_workspace(const fsr_wgrad_desc* d) {
+  WgradPlan p;
+  if (make_plan(d, p) != 0) return 0;
+  return (size_t)p.nslab * 9 * d->cout_pad * d->cin_pad * sizeof(float);
+}
+
+extern "C" int fsr_conv3x3_wgrad(const fsr_wgrad_desc* d, const void* x, const void* dy, float* dw_oihw, void* workspace,
+                                 fsr_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  WgradPlan p;
+  if (int rc = make_plan(d, p)) return rc;
+  if (!x || !dy || !dw_oihw || !workspace) return fsr_fail(-1, "fsr_conv3x3_wgrad: null argument");
+  WgradKArgs a;
+  a.x = x;
+  a.dy = dy;
+  a.ws = (float*)workspace;
+  a.N = d->n;
+  a.IH = d->ih;
+  a.IW = d->iw;
+  a.CinPad = d->cin_pad;
+  a.OH = d->oh;
+  a.OW = d->ow;
+  a.CoutPad = d->cout_pad;
+  a.dy_ps = d->dy_pixel_shuffled;
+  a.tiles_x = p.tiles_x;
+  a.tiles_y = p.tiles_y;
+  a.tiles_total = p.tiles_total;
+  a.tiles_per_slab = p.tiles_per_slab;
+  a.nslab = p.nslab;
+  a.nbm = p.nbm;
+  a.nbn = p.nbn;
+  int rc = d->dtype == FSR_BF16 ? dispatch_wgrad<bf16_t, 8>(p, a, stream) : dispatch_wgrad<float, 4>(p, a, stream);
+  if (rc) return rc;
+  const int total = 9 * d->cout * d->cin;
+  int blocks = (total + 255) / 256;
+  if (blocks > 1024) blocks = 1024;
+  hipLaunchKernelGGL(conv_wgrad_reduce_kernel, dim3(blocks), dim3(256), 0, stream, (const float*)workspace, dw_oihw, p.nslab,
+                     d->cout, d->cin, d->cout_pad, d->cin_pad, d->dy_pixel_shuffled);
+  return fsr_check_launch("conv_wgrad_reduce_kernel");
+}

@@ -1,0 +1,543 @@
+// HBM-bound elementwise / reduction kernels of the Fast-SRGAN hot path (NHWC activations).
+//
+//   InstanceNorm2d apply (+PReLU / LeakyReLU, + residual)   /root/reference/model.py:55-56,65,69,94,115,132-133
+//   backward of the same (two per-(n,c) reductions + apply)  autograd of the above
+//   activation backward of fused conv epilogues + bias grad  model.py:37,77,145 ; vgg ReLU model.py:8
+//   3-channel image <-> zero-padded NHWC, tanh backward      model.py:20-22 (VGG normalise), :109
+//   MaxPool2d(2,2) forward / backward                        vgg19.features pools (model.py:8)
+//
+// Every kernel moves 16 bytes per lane per access (8 bf16 / 4 f32), grid-strides over a capped grid
+// and keeps all arithmetic in f32.  They are bandwidth-bound: bytes moved per element are listed
+// in DESIGN.md.
+#include "fsr_common.h"
+#include "fsr_host.h"
+
+namespace {
+
+constexpr float kEps = 1e-5f;  // torch.nn.InstanceNorm2d default eps
+
+template <typename T> struct V16;  // one 16-byte unit of T viewed as floats
+template <> struct V16<float> {
+  static constexpr int N = 4;
+  static __device__ __forceinline__ void ld(const float* p, float (&v)[4]) {
+    const f32x4 t = *(const f32x4*)p;
+    v[0] = t[0]; v[1] = t[1]; v[2] = t[2]; v[3] = t[3];
+  }
+  static __device__ __forceinline__ void st(float* p, const float (&v)[4]) {
+    *(f32x4*)p = (f32x4){v[0], v[1], v[2], v[3]};
+  }
+};
+template <> struct V16<bf16_t> {
+  static constexpr int N = 8;
+  static __device__ __forceinline__ void ld(const bf16_t* p, float (&v)[8]) {
+    const u32x4 t = *(const u32x4*)p;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      v[2 * i] = __uint_as_float(t[i] << 16);
+      v[2 * i + 1] = __uint_as_float(t[i] & 0xffff0000u);
+    }
+  }
+  static __device__ __forceinline__ void st(bf16_t* p, const float (&v)[8]) {
+    u32x4 t;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) t[i] = (unsigned)f2bf(v[2 * i]) | ((unsigned)f2bf(v[2 * i + 1]) << 16);
+    *(u32x4*)p = t;
+  }
+};
+
+__device__ __forceinline__ float act_fwd(float z, int act, float slope) {
+  if (act == FSR_ACT_NONE) return z;
+  if (act == FSR_ACT_RELU) return z > 0.f ? z : 0.f;
+  return z > 0.f ? z : z * slope;
+}
+// derivative with respect to the pre-activation, evaluated from the pre-activation
+__device__ __forceinline__ float act_dz(float z, int act, float slope) {
+  if (act == FSR_ACT_NONE) return 1.f;
+  if (act == FSR_ACT_RELU) return z > 0.f ? 1.f : 0.f;
+  return z > 0.f ? 1.f : slope;
+}
+
+inline int capped_blocks(long long work_items, int per_block) {
+  long long b = (work_items + per_block - 1) / per_block;
+  if (b > 256 * 8) b = 256 * 8;  // 8 workgroups of 256 threads per CU, grid-stride the rest
+  if (b < 1) b = 1;
+  return (int)b;
+}
+
+// ------------------------------------------------------------------ InstanceNorm apply
+template <typename T>
+__global__ __launch_bounds__(256) void instnorm_act_fwd_kernel(const T* __restrict__ x, const float* __restrict__ stats,
+                                                               const T* __restrict__ res, int act, float slope_in,
+                                                               const float* __restrict__ prelu, T* __restrict__ out,
+                                                               long long units, int hw, int c) {
+  constexpr int E = V16<T>::N;
+  const int cu = c / E;
+  const float slope = (act == FSR_ACT_PRELU) ? prelu[0] : slope_in;
+  const float inv = 1.f / (float)hw;
+  for (long long u = (long long)blockIdx.x * 256 + threadIdx.x; u < units; u += (long long)gridDim.x * 256) {
+    const int c0 = (int)(u % cu) * E;
+    const int n = (int)(u / ((long long)cu * hw));
+    const float* st = stats + ((size_t)n * c + c0) * 2;
+    float v[E], r[E];
+    V16<T>::ld(x + u * E, v);
+    if (res) V16<T>::ld(res + u * E, r);
+#pragma unroll
+    for (int i = 0; i < E; ++i) {
+      const float mean = st[2 * i] * inv;
+      const float var = fmaxf(st[2 * i + 1] * inv - mean * mean, 0.f);
+      const float z = (v[i] - mean) * rsqrtf(var + kEps);
+      v[i] = act_fwd(z, act, slope) + (res ? r[i] : 0.f);
+    }
+    V16<T>::st(out + u * E, v);
+  }
+}
+
+// Backward phase 1.  Workgroup = one image x a slab of pixels x all channels: thread t owns channel
+// unit t % cu and walks pixels t / cu, t / cu + 256 / cu, ...; partial sums meet in LDS, then one
+// atomic per (workgroup, channel, quantity).
+template <typename T>
+__global__ __launch_bounds__(256) void instnorm_act_bwd_reduce_kernel(const T* __restrict__ g, const T* __restrict__ x,
+                                                                      const float* __restrict__ stats, int act,
+                                                                      float slope_in, const float* __restrict__ prelu,
+                                                                      float* __restrict__ sums, float* __restrict__ dprelu,
+                                                                      int hw, int c, int slabs) {
+  constexpr int E = V16<T>::N;
+  __shared__ float red[256 * 2 * E];
+  __shared__ float red_p[4];
+  const int cu = c / E;            // <= 256 (host checked)
+  const int rows = 256 / cu;       // pixel rows walked in parallel
+  const int tid = threadIdx.x;
+  const int n = blockIdx.x / slabs, slab = blockIdx.x % slabs;
+  const int per = (hw + slabs - 1) / slabs;
+  const int p0 = slab * per, p1 = (p0 + per < hw) ? p0 + per : hw;
+  const float slope = (act == FSR_ACT_PRELU) ? prelu[0] : slope_in;
+  const float inv = 1.f / (float)hw;
+  const int unit = tid % cu, row = tid / cu;
+  float s1[E], s2[E], mean[E], rstd[E];
+  float dp = 0.f;
+#pragma unroll
+  for (int i = 0; i < E; ++i) s1[i] = s2[i] = 0.f;
+  if (row < rows) {
+    const float* st = stats + ((size_t)n * c + unit * E) * 2;
+#pragma unroll
+    for (int i = 0; i < E; ++i) {
+      mean[i] = st[2 * i] * inv;
+      rstd[i] = rsqrtf(fmaxf(st[2 * i + 1] * inv - mean[i] * mean[i], 0.f) + kEps);
+    }
+    for (int p = p0 + row; p < p1; p += rows) {
+      const size_t off = ((size_t)n * hw + p) * c + unit * E;
+      float gv[E], xv[E];
+      V16<T>::ld(g + off, gv);
+      V16<T>::ld(x + off, xv);
+#pragma unroll
+      for (int i = 0; i < E; ++i) {
+        const float xh = (xv[i] - mean[i]) * rstd[i];
+        const float gz = gv[i] * act_dz(xh, act, slope);
+        s1[i] += gz;
+        s2[i] += gz * xh;
+        dp += gv[i] * fminf(xh, 0.f);
+      }
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < E; ++i) {
+    red[(2 * i) * 256 + tid] = s1[i];
+    red[(2 * i + 1) * 256 + tid] = s2[i];
+  }
+  if (dprelu) {
+    dp = wave_sum(dp);
+    if ((tid & 63) == 0) red_p[tid >> 6] = dp;
+  }
+  __syncthreads();
+  // thread t < cu*2*E : quantity q = t / cu (0..2E-1), channel unit t % cu
+  for (int t = tid; t < cu * 2 * E; t += 256) {
+    const int q = t / cu, un = t % cu;
+    float s = 0.f;
+    for (int r = 0; r < rows; ++r) s += red[q * 256 + r * cu + un];
+    atomicAdd(sums + ((size_t)n * c + un * E + (q >> 1)) * 2 + (q & 1), s);
+  }
+  if (dprelu && tid == 0) atomicAdd(dprelu, red_p[0] + red_p[1] + red_p[2] + red_p[3]);
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void instnorm_act_bwd_apply_kernel(const T* __restrict__ g, const T* __restrict__ x,
+                                                                     const float* __restrict__ stats,
+                                                                     const float* __restrict__ sums, int act,
+                                                                     float slope_in, const float* __restrict__ prelu,
+                                                                     T* __restrict__ dx, long long units, int hw, int c) {
+  constexpr int E = V16<T>::N;
+  const int cu = c / E;
+  const float slope = (act == FSR_ACT_PRELU) ? prelu[0] : slope_in;
+  const float inv = 1.f / (float)hw;
+  for (long long u = (long long)blockIdx.x * 256 + threadIdx.x; u < units; u += (long long)gridDim.x * 256) {
+    const int c0 = (int)(u % cu) * E;
+    const int n = (int)(u / ((long long)cu * hw));
+    const float* st = stats + ((size_t)n * c + c0) * 2;
+    const float* sm = sums + ((size_t)n * c + c0) * 2;
+    float gv[E], xv[E];
+    V16<T>::ld(g + u * E, gv);
+    V16<T>::ld(x + u * E, xv);
+#pragma unroll
+    for (int i = 0; i < E; ++i) {
+      const float mean = st[2 * i] * inv;
+      const float rstd = rsqrtf(fmaxf(st[2 * i + 1] * inv - mean * mean, 0.f) + kEps);
+      const float xh = (xv[i] - mean) * rstd;
+      const float gz = gv[i] * act_dz(xh, act, slope);
+      xv[i] = rstd * (gz - sm[2 * i] * inv - xh * sm[2 * i + 1] * inv);
+    }
+    V16<T>::st(dx + u * E, xv);
+  }
+}
+
+// ------------------------------------------------------------------ activation backward of a fused conv epilogue
+// Workgroup layout as in the reduce kernel above (channel unit x pixel rows) so that the bias
+// gradient is a column sum.  Pixel-shuffled tensors: the bias index depends on the pixel parity.
+template <typename T>
+__global__ __launch_bounds__(256) void act_bwd_kernel(const T* __restrict__ g, const T* __restrict__ saved, int act,
+                                                      float slope_in, const float* __restrict__ prelu, T* __restrict__ dz,
+                                                      float* __restrict__ dbias, float* __restrict__ dprelu, int h, int w,
+                                                      int c, int ps, int slabs) {
+  constexpr int E = V16<T>::N;
+  __shared__ float red[256 * E];
+  __shared__ float red_p[4];
+  const int cu = c / E;
+  const int rows = 256 / cu;
+  const int tid = threadIdx.x;
+  const int hw = h * w;
+  // ps: a slab is one (row parity, column parity) class of pixels so that a thread's column sums
+  // belong to one bias entry per channel
+  const int nclass = ps ? 4 : 1;
+  int b = blockIdx.x;
+  const int cls = b % nclass;
+  b /= nclass;
+  const int slab = b % slabs, n = b / slabs;
+  const int ch = ps ? h / 2 : h, cw = ps ? w / 2 : w;  // class grid
+  const int cnt = ch * cw;
+  const int per = (cnt + slabs - 1) / slabs;
+  const int p0 = slab * per, p1 = (p0 + per < cnt) ? p0 + per : cnt;
+  const float slope = (act == FSR_ACT_PRELU) ? prelu[0] : slope_in;
+  const int unit = tid % cu, row = tid / cu;
+  float s1[E];
+  float dp = 0.f;
+#pragma unroll
+  for (int i = 0; i < E; ++i) s1[i] = 0.f;
+  if (row < rows) {
+    for (int p = p0 + row; p < p1; p += rows) {
+      int py = p / cw, px = p % cw;
+      if (ps) {
+        py = 2 * py + (cls >> 1);
+        px = 2 * px + (cls & 1);
+      }
+      const size_t off = ((size_t)n * hw + (size_t)py * w + px) * c + unit * E;
+      float gv[E], sv[E];
+      V16<T>::ld(g + off, gv);
+      V16<T>::ld(saved + off, sv);
+#pragma unroll
+      for (int i = 0; i < E; ++i) {
+        const float d = gv[i] * act_dz(sv[i], act, slope);
+        dp += gv[i] * fminf(sv[i], 0.f);
+        s1[i] += d;
+        gv[i] = d;
+      }
+      V16<T>::st(dz + off, gv);
+    }
+  }
+  if (dprelu) {
+    dp = wave_sum(dp);
+    if ((tid & 63) == 0) red_p[tid >> 6] = dp;
+  }
+  if (dbias) {
+#pragma unroll
+    for (int i = 0; i < E; ++i) red[i * 256 + tid] = s1[i];
+  }
+  __syncthreads();
+  if (dbias) {
+    for (int t = tid; t < cu * E; t += 256) {
+      const int q = t / cu, un = t % cu;
+      float s = 0.f;
+      for (int r = 0; r < rows; ++r) s += red[q * 256 + r * cu + un];
+      const int chn = un * E + q;
+      atomicAdd(dbias + (ps ? 4 * chn + cls : chn), s);
+    }
+  }
+  if (dprelu && tid == 0) atomicAdd(dprelu, red_p[0] + red_p[1] + red_p[2] + red_p[3]);
+}
+
+// ------------------------------------------------------------------ 3-channel images <-> padded NHWC
+template <typename T>
+__global__ __launch_bounds__(256) void image_to_nhwc_kernel(const float* __restrict__ img, long long sn, long long sc,
+                                                            long long sh, long long sw, int h, int w, float a0, float a1,
+                                                            float a2, float b0, float b1, float b2, T* __restrict__ out,
+                                                            int cpad, long long npix) {
+  constexpr int E = V16<T>::N;
+  const int upp = cpad / E;  // 16-byte units per pixel
+  for (long long u = (long long)blockIdx.x * 256 + threadIdx.x; u < npix * upp; u += (long long)gridDim.x * 256) {
+    const long long p = u / upp;
+    const int un = (int)(u % upp);
+    float v[E];
+#pragma unroll
+    for (int i = 0; i < E; ++i) v[i] = 0.f;
+    if (un == 0) {
+      const int x = (int)(p % w);
+      const int y = (int)((p / w) % h);
+      const long long n = p / ((long long)w * h);
+      const float* s = img + n * sn + y * sh + x * sw;
+      v[0] = s[0] * a0 + b0;
+      v[1] = s[sc] * a1 + b1;
+      v[2] = s[2 * sc] * a2 + b2;
+    }
+    V16<T>::st(out + u * E, v);
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void tanh_bwd_to_nhwc_kernel(const float* __restrict__ g, long long sn, long long sc,
+                                                               long long sh, long long sw, const float* __restrict__ y,
+                                                               int h, int w, T* __restrict__ dz, int cpad, long long npix,
+                                                               float* __restrict__ dbias) {
+  constexpr int E = V16<T>::N;
+  __shared__ float red[3][4];
+  const int upp = cpad / E;
+  float b0 = 0.f, b1 = 0.f, b2 = 0.f;
+  for (long long u = (long long)blockIdx.x * 256 + threadIdx.x; u < npix * upp; u += (long long)gridDim.x * 256) {
+    const long long p = u / upp;
+    const int un = (int)(u % upp);
+    float v[E];
+#pragma unroll
+    for (int i = 0; i < E; ++i) v[i] = 0.f;
+    if (un == 0) {
+      const int x = (int)(p % w);
+      const int yy = (int)((p / w) % h);
+      const long long n = p / ((long long)w * h);
+      const float* s = g + n * sn + yy * sh + x * sw;
+      const float* t = y + p * 3;
+      v[0] = s[0] * (1.f - t[0] * t[0]);
+      v[1] = s[sc] * (1.f - t[1] * t[1]);
+      v[2] = s[2 * sc] * (1.f - t[2] * t[2]);
+      b0 += v[0];
+      b1 += v[1];
+      b2 += v[2];
+    }
+    V16<T>::st(dz + u * E, v);
+  }
+  if (dbias) {
+    b0 = wave_sum(b0);
+    b1 = wave_sum(b1);
+    b2 = wave_sum(b2);
+    if ((threadIdx.x & 63) == 0) {
+      red[0][threadIdx.x >> 6] = b0;
+      red[1][threadIdx.x >> 6] = b1;
+      red[2][threadIdx.x >> 6] = b2;
+    }
+    __syncthreads();
+    if (threadIdx.x < 3) atomicAdd(dbias + threadIdx.x, red[threadIdx.x][0] + red[threadIdx.x][1] + red[threadIdx.x][2] + red[threadIdx.x][3]);
+  }
+}
+
+// ------------------------------------------------------------------ MaxPool2d(2,2)
+template <typename T>
+__global__ __launch_bounds__(256) void maxpool2_fwd_kernel(const T* __restrict__ x, T* __restrict__ y, int h, int w, int c,
+                                                           long long units) {
+  constexpr int E = V16<T>::N;
+  const int cu = c / E, oh = h / 2, ow = w / 2;
+  for (long long u = (long long)blockIdx.x * 256 + threadIdx.x; u < units; u += (long long)gridDim.x * 256) {
+    const int un = (int)(u % cu);
+    long long p = u / cu;
+    const int ox = (int)(p % ow);
+    p /= ow;
+    const int oy = (int)(p % oh);
+    const long long n = p / oh;
+    const T* s = x + ((n * h + 2 * oy) * w + 2 * ox) * (long long)c + un * E;
+    float a[E], b[E];
+    V16<T>::ld(s, a);
+    V16<T>::ld(s + c, b);
+#pragma unroll
+    for (int i = 0; i < E; ++i) a[i] = fmaxf(a[i], b[i]);
+    V16<T>::ld(s + (long long)w * c, b);
+#pragma unroll
+    for (int i = 0; i < E; ++i) a[i] = fmaxf(a[i], b[i]);
+    V16<T>::ld(s + (long long)w * c + c, b);
+#pragma unroll
+    for (int i = 0; i < E; ++i) a[i] = fmaxf(a[i], b[i]);
+    V16<T>::st(y + u * E, a);
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void maxpool2_bwd_kernel(const T* __restrict__ g, const T* __restrict__ x,
+                                                           const T* __restrict__ y, T* __restrict__ dx, int h, int w, int c,
+                                                           long long units) {
+  constexpr int E = V16<T>::N;
+  const int cu = c / E, oh = h / 2, ow = w / 2;
+  for (long long u = (long long)blockIdx.x * 256 + threadIdx.x; u < units; u += (long long)gridDim.x * 256) {
+    const int un = (int)(u % cu);
+    long long p = u / cu;
+    const int ox = (int)(p % ow);
+    p /= ow;
+    const int oy = (int)(p % oh);
+    const long long n = p / oh;
+    const long long base = ((n * h + 2 * oy) * w + 2 * ox) * (long long)c + un * E;
+    float gv[E], yv[E], xv[E], o[E];
+    bool taken[E];
+    V16<T>::ld(g + u * E, gv);
+    V16<T>::ld(y + u * E, yv);
+#pragma unroll
+    for (int i = 0; i < E; ++i) taken[i] = false;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const long long off = base + (long long)(k >> 1) * w * c + (k & 1) * c;
+      V16<T>::ld(x + off, xv);
+#pragma unroll
+      for (int i = 0; i < E; ++i) {
+        const bool hit = !taken[i] && xv[i] == yv[i];
+        o[i] = hit ? gv[i] : 0.f;
+        taken[i] = taken[i] || hit;
+      }
+      V16<T>::st(dx + off, o);
+    }
+  }
+}
+
+template <typename T> T* P(void* p) { return (T*)p; }
+template <typename T> const T* P(const void* p) { return (const T*)p; }
+
+int check_c(const char* what, int dtype, int c) {
+  const int e = dtype == FSR_BF16 ? 8 : 4;
+  if (dtype != FSR_F32 && dtype != FSR_BF16) return fsr_fail(-2, "%s: unknown dtype %d", what, dtype);
+  if (c <= 0 || c % e != 0) return fsr_fail(-2, "%s: channel count %d is not a multiple of %d", what, c, e);
+  return 0;
+}
+int check_reduce_c(const char* what, int dtype, int c) {
+  int rc = check_c(what, dtype, c);
+  if (rc) return rc;
+  const int cu = c / (dtype == FSR_BF16 ? 8 : 4);
+  if (cu > 256 || 256 % cu != 0) return fsr_fail(-2, "%s: %d channels do not tile a 256-thread workgroup", what, c);
+  return 0;
+}
+int slabs_for(int n, int hw) {
+  // enough workgroups to fill 256 CUs a few times over, at least ~64 pixels of work per row walk
+  int s = (256 * 4 + n - 1) / n;
+  const int maxs = (hw + 63) / 64;
+  if (s > maxs) s = maxs;
+  return s < 1 ? 1 : s;
+}
+
+}  // namespace
+
+#define FSR_DISPATCH_T(dtype, ...)                    \
+  if ((dtype) == FSR_BF16) {                          \
+    typedef bf16_t T;                                 \
+    __VA_ARGS__                                       \
+  } else {                                            \
+    typedef float T;                                  \
+    __VA_ARGS__                                       \
+  }
+
+extern "C" int fsr_instnorm_act_fwd(int dtype, const void* x, const float* stats, const void* res, int act, float slope,
+                                    const float* prelu_weight, void* out, int n, int hw, int c, fsr_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  if (!x || !stats || !out) return fsr_fail(-1, "fsr_instnorm_act_fwd: null argument");
+  if (act == FSR_ACT_PRELU && !prelu_weight) return fsr_fail(-1, "fsr_instnorm_act_fwd: PReLU needs its weight");
+  if (int rc = check_c("fsr_instnorm_act_fwd", dtype, c)) return rc;
+  const long long units = (long long)n * hw * (c / (dtype == FSR_BF16 ? 8 : 4));
+  FSR_DISPATCH_T(dtype, hipLaunchKernelGGL(instnorm_act_fwd_kernel<T>, dim3(capped_blocks(units, 256)), dim3(256), 0,
+                                           stream, P<T>(x), stats, P<T>(res), act, slope, prelu_weight, P<T>(out), units,
+                                           hw, c);)
+  return fsr_check_launch("instnorm_act_fwd_kernel");
+}
+
+extern "C" int fsr_instnorm_act_bwd_reduce(int dtype, const void* g, const void* x, const float* stats, int act,
+                                           float slope, const float* prelu_weight, float* sums, float* dprelu, int n,
+                                           int hw, int c, fsr_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  if (!g || !x || !stats || !sums) return fsr_fail(-1, "fsr_instnorm_act_bwd_reduce: null argument");
+  if (act == FSR_ACT_PRELU && !prelu_weight) return fsr_fail(-1, "fsr_instnorm_act_bwd_reduce: PReLU needs its weight");
+  if (int rc = check_reduce_c("fsr_instnorm_act_bwd_reduce", dtype, c)) return rc;
+  const int slabs = slabs_for(n, hw);
+  FSR_DISPATCH_T(dtype, hipLaunchKernelGGL(instnorm_act_bwd_reduce_kernel<T>, dim3(n * slabs), dim3(256), 0, stream,
+                                           P<T>(g), P<T>(x), stats, act, slope, prelu_weight, sums, dprelu, hw, c, slabs);)
+  return fsr_check_launch("instnorm_act_bwd_reduce_kernel");
+}
+
+extern "C" int fsr_instnorm_act_bwd_apply(int dtype, const void* g, const void* x, const float* stats, const float* sums,
+                                          int act, float slope, const float* prelu_weight, void* dx, int n, int hw, int c,
+                                          fsr_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  if (!g || !x || !stats || !sums || !dx) return fsr_fail(-1, "fsr_instnorm_act_bwd_apply: null argument");
+  if (act == FSR_ACT_PRELU && !prelu_weight) return fsr_fail(-1, "fsr_instnorm_act_bwd_apply: PReLU needs its weight");
+  if (int rc = check_c("fsr_instnorm_act_bwd_apply", dtype, c)) return rc;
+  const long long units = (long long)n * hw * (c / (dtype == FSR_BF16 ? 8 : 4));
+  FSR_DISPATCH_T(dtype, hipLaunchKernelGGL(instnorm_act_bwd_apply_kernel<T>, dim3(capped_blocks(units, 256)), dim3(256), 0,
+                                           stream, P<T>(g), P<T>(x), stats, sums, act, slope, prelu_weight, P<T>(dx), units,
+                                           hw, c);)
+  return fsr_check_launch("instnorm_act_bwd_apply_kernel");
+}
+
+extern "C" int fsr_act_bwd(int dtype, const void* g, const void* saved, int act, float slope, const float* prelu_weight,
+                           void* dz, float* dbias, float* dprelu, int n, int h, int w, int c, int pixel_shuffled,
+                           fsr_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  if (!g || !dz) return fsr_fail(-1, "fsr_act_bwd: null argument");
+  if (act != FSR_ACT_NONE && !saved) return fsr_fail(-1, "fsr_act_bwd: the activation needs the saved tensor");
+  if (act == FSR_ACT_PRELU && !prelu_weight) return fsr_fail(-1, "fsr_act_bwd: PReLU needs its weight");
+  if (act == FSR_ACT_TANH) return fsr_fail(-2, "fsr_act_bwd: tanh is handled by fsr_tanh_bwd_to_nhwc");
+  if (int rc = check_reduce_c("fsr_act_bwd", dtype, c)) return rc;
+  if (pixel_shuffled && ((h | w) & 1)) return fsr_fail(-2, "fsr_act_bwd: pixel-shuffled tensors have even extents");
+  if (!saved) saved = g;  // FSR_ACT_NONE: only the bias gradient is wanted; act_dz ignores the value
+  const int nclass = pixel_shuffled ? 4 : 1;
+  const int slabs = slabs_for(n * nclass, h * w / nclass);
+  FSR_DISPATCH_T(dtype, hipLaunchKernelGGL(act_bwd_kernel<T>, dim3(n * slabs * nclass), dim3(256), 0, stream, P<T>(g),
+                                           P<T>(saved), act, slope, prelu_weight, P<T>(dz), dbias, dprelu, h, w, c,
+                                           pixel_shuffled, slabs);)
+  return fsr_check_launch("act_bwd_kernel");
+}
+
+extern "C" int fsr_image_to_nhwc(int dtype, const float* img, long long sn, long long sc, long long sh, long long sw,
+                                 int n, int h, int w, float scale0, float scale1, float scale2, float shift0, float shift1,
+                                 float shift2, void* out, int cpad, fsr_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  if (!img || !out) return fsr_fail(-1, "fsr_image_to_nhwc: null argument");
+  if (int rc = check_c("fsr_image_to_nhwc", dtype, cpad)) return rc;
+  const long long npix = (long long)n * h * w;
+  const long long units = npix * (cpad / (dtype == FSR_BF16 ? 8 : 4));
+  FSR_DISPATCH_T(dtype, hipLaunchKernelGGL(image_to_nhwc_kernel<T>, dim3(capped_blocks(units, 256)), dim3(256), 0, stream,
+                                           img, sn, sc, sh, sw, h, w, scale0, scale1, scale2, shift0, shift1, shift2,
+                                           P<T>(out), cpad, npix);)
+  return fsr_check_launch("image_to_nhwc_kernel");
+}
+
+extern "C" int fsr_tanh_bwd_to_nhwc(int dtype, const float* g, long long sn, long long sc, long long sh, long long sw,
+                                    const float* y_nhwc3, int n, int h, int w, void* dz, int cpad, float* dbias,
+                                    fsr_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  if (!g || !y_nhwc3 || !dz) return fsr_fail(-1, "fsr_tanh_bwd_to_nhwc: null argument");
+  if (int rc = check_c("fsr_tanh_bwd_to_nhwc", dtype, cpad)) return rc;
+  const long long npix = (long long)n * h * w;
+  const long long units = npix * (cpad / (dtype == FSR_BF16 ? 8 : 4));
+  FSR_DISPATCH_T(dtype, hipLaunchKernelGGL(tanh_bwd_to_nhwc_kernel<T>, dim3(capped_blocks(units, 256)), dim3(256), 0,
+                                           stream, g, sn, sc, sh, sw, y_nhwc3, h, w, P<T>(dz), cpad, npix, dbias);)
+  return fsr_check_launch("tanh_bwd_to_nhwc_kernel");
+}
+
+extern "C" int fsr_maxpool2_fwd(int dtype, const void* x, void* y, int n, int h, int w, int c, fsr_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  if (!x || !y) return fsr_fail(-1, "fsr_maxpool2_fwd: null argument");
+  if (int rc = check_c("fsr_maxpool2_fwd", dtype, c)) return rc;
+  if ((h | w) & 1) return fsr_fail(-2, "fsr_maxpool2_fwd: odd extent %dx%d", h, w);
+  const long long units = (long long)n * (h / 2) * (w / 2) * (c / (dtype == FSR_BF16 ? 8 : 4));
+  FSR_DISPATCH_T(dtype, hipLaunchKernelGGL(maxpool2_fwd_kernel<T>, dim3(capped_blocks(units, 256)), dim3(256), 0, stream,
+                                           P<T>(x), P<T>(y), h, w, c, units);)
+  return fsr_check_launch("maxpool2_fwd_kernel");
+}
+
+extern "C" int fsr_maxpool2_bwd(int dtype, const void* g, const void* x, const void* y, void* dx, int n, int h, int w,
+                                int c, fsr_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  if (!g || !x || !y || !dx) return fsr_fail(-1, "fsr_maxpool2_bwd: null argument");
+  if (int rc = check_c("fsr_maxpool2_bwd", dtype, c)) return rc;
+  if ((h | w) & 1) return fsr_fail(-2, "fsr_maxpool2_bwd: odd extent %dx%d", h, w);
+  const long long units = (long long)n * (h / 2) * (w / 2) * (c / (dtype == FSR_BF16 ? 8 : 4));
+  FSR_DISPATCH_T(dtype, hipLaunchKernelGGL(maxpool2_bwd_kernel<T>, dim3(capped_blocks(units, 256)), dim3(256), 0, stream,
+                                           P<T>(g), P<T>(x), P<T>(y), P<T>(dx), h, w, c, units);)
+  return fsr_check_launch("maxpool2_bwd_kernel");
+}

@@ -37,7 +37,7 @@ extern "C" int fsr_device_info(char* buf, size_t buflen) {
 }
 
 extern "C" int fsr_conv3x3(const fsr_conv_desc* d, const void* in, const void* packed_w, const float* bias,
-                           const float* prelu_weight, const void* addend, void* out, float* stats,
+                           const float* prelu_weight, const float* oscale, void* out, void* preact, float* stats,
                            fsr_stream_t stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   if (!d || !in || !packed_w || !out) return fsr_fail(-1, "fsr_conv3x3: null argument");
@@ -52,14 +52,15 @@ extern "C" int fsr_conv3x3(const fsr_conv_desc* d, const void* in, const void* p
   a.out = out;
   a.bias = bias;
   a.prelu = prelu_weight;
-  a.addend = addend;
+  a.preact = preact;
+  a.oscale = oscale;
   a.stats = stats;
   a.N = d->n;
   a.IH = d->ih;
   a.IW = d->iw;
   a.Cin = d->cin;
   a.Cout = d->cout;
-  a.CoutPad = d->cout < 16 ? 16 : d->cout;
+  a.CoutPad = (d->cout + 15) / 16 * 16;
   a.FOH = d->oh;
   a.FOW = d->ow;
   a.act = d->act;
@@ -67,6 +68,7 @@ extern "C" int fsr_conv3x3(const fsr_conv_desc* d, const void* in, const void* p
   a.ps = d->pixel_shuffle;
   a.in_ps = d->in_pixel_shuffled;
   a.out_f32 = d->out_f32;
+  if (a.ps && stats) return fsr_fail(-2, "fsr_conv3x3: statistics are not available together with pixel shuffle");
   if (a.ps && (d->cout % 16 != 0)) return fsr_fail(-2, "fsr_conv3x3: pixel shuffle needs cout %% 16 == 0");
   if (a.in_ps && (d->cin % 4 != 0)) return fsr_fail(-2, "fsr_conv3x3: in_pixel_shuffled needs cin %% 4 == 0");
 

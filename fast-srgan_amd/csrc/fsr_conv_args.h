@@ -15,7 +15,8 @@ struct ConvKArgs {
   void* out;
   const float* bias;    // [Cout] or null
   const float* prelu;   // device scalar, used when act == FSR_ACT_PRELU
-  const void* addend;   // optional tensor with the layout/dtype of `out`, added before the act
+  void* preact;         // optional tensor like `out`: receives the pre-activation
+  const float* oscale;  // optional [Cout] scale applied to the accumulator before the bias
   float* stats;         // optional [N][Cout][2] (sum, sum of squares of the pre-activation)
   int N, IH, IW, Cin;
   int GH, GW;

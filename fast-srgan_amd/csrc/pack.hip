@@ -5,7 +5,7 @@
 
 template <typename T>
 __global__ void pack_conv3x3_kernel(const float* __restrict__ w, T* __restrict__ out, int cout, int cin, int mode,
-                                    int rows, int rows_pad, int K) {
+                                    int rows, int rows_pad, int K, int Kreal) {
   const long long total = 9LL * rows_pad * K;
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
        i += (long long)gridDim.x * blockDim.x) {
@@ -13,7 +13,7 @@ __global__ void pack_conv3x3_kernel(const float* __restrict__ w, T* __restrict__
     const int row = (int)((i / K) % rows_pad);
     const int t = (int)(i / ((long long)K * rows_pad));
     float v = 0.f;
-    if (row < rows) {
+    if (row < rows && k < Kreal) {
       int co, ci;
       if (mode == FSR_PACK_FWD || mode == FSR_PACK_FWD_PS) {
         co = row;
@@ -36,7 +36,7 @@ __global__ void pack_conv3x3_kernel(const float* __restrict__ w, T* __restrict__
   }
 }
 
-extern "C" int fsr_pack_conv3x3(int dtype, int mode, const float* w_oihw, int cout, int cin, void* packed,
+extern "C" int fsr_pack_conv3x3(int dtype, int mode, const float* w_oihw, int cout, int cin, int k_pad, void* packed,
                                 fsr_stream_t stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   if (!w_oihw || !packed) return fsr_fail(-1, "fsr_pack_conv3x3: null argument");
@@ -44,17 +44,19 @@ extern "C" int fsr_pack_conv3x3(int dtype, int mode, const float* w_oihw, int co
   if ((mode == FSR_PACK_FWD_PS || mode == FSR_PACK_DGRAD_PS) && cout % 4 != 0)
     return fsr_fail(-2, "fsr_pack_conv3x3: pixel-shuffle packing needs cout %% 4 == 0");
   const bool fwd = (mode == FSR_PACK_FWD || mode == FSR_PACK_FWD_PS);
-  const int rows = fwd ? cout : cin, K = fwd ? cin : cout;
-  const int rows_pad = rows < 16 ? 16 : rows;
+  const int rows = fwd ? cout : cin, Kreal = fwd ? cin : cout;
+  if (k_pad < Kreal) return fsr_fail(-2, "fsr_pack_conv3x3: k_pad %d < K %d", k_pad, Kreal);
+  const int K = k_pad;
+  const int rows_pad = (rows + 15) / 16 * 16;
   const long long total = 9LL * rows_pad * K;
   int blocks = (int)((total + 255) / 256);
   if (blocks > 4096) blocks = 4096;
   if (dtype == FSR_BF16)
     hipLaunchKernelGGL(pack_conv3x3_kernel<bf16_t>, dim3(blocks), dim3(256), 0, stream, w_oihw, (bf16_t*)packed, cout,
-                       cin, mode, rows, rows_pad, K);
+                       cin, mode, rows, rows_pad, K, Kreal);
   else if (dtype == FSR_F32)
     hipLaunchKernelGGL(pack_conv3x3_kernel<float>, dim3(blocks), dim3(256), 0, stream, w_oihw, (float*)packed, cout,
-                       cin, mode, rows, rows_pad, K);
+                       cin, mode, rows, rows_pad, K, Kreal);
   else
     return fsr_fail(-2, "fsr_pack_conv3x3: unknown dtype %d", dtype);
   return fsr_check_launch("pack_conv3x3_kernel");

@@ -1,0 +1,186 @@
+"""Generator / Discriminator / VGG19 with the reference's nn.Module surface on MI355X kernels.
+
+Drop-in for /root/reference/model.py: same class names, constructor arguments, submodule names and
+therefore the same state_dict keys and shapes (the shipped models/model.pt loads unchanged), same
+forward signatures ((N,3,H,W) float32 in; (N,3,4H,4W) / (N,1,H/16,W/16) float32 out).  The torch.nn
+submodules are kept purely as PARAMETER CONTAINERS (and so that default initialisation draws the
+same random numbers in the same order as the reference); their forward methods are never called.
+All math runs through fast-srgan_amd.ops on NHWC activations in the module's compute dtype.
+
+Extra constructor keyword (not in the reference): compute_dtype = "bf16" (default; bf16 MFMA with
+f32 accumulation, f32 parameters/statistics) or "f32" (exact-f32 MFMA; the parity mode).
+"""
+import os
+import warnings
+
+import torch
+
+from . import _lib as L
+from . import ops
+
+_DEFAULT_DTYPE = os.environ.get("FSR_COMPUTE_DTYPE", "bf16")
+
+
+class UpSamplingBlock(torch.nn.Module):
+    """model.py:26-40: conv 3x3 C->4C (bias) -> PixelShuffle(2) -> PReLU, one fused kernel here."""
+
+    def __init__(self, config):
+        super().__init__()
+        self.conv = torch.nn.Conv2d(config.n_filters, config.n_filters * 4, kernel_size=3, padding=1)
+        self.phase_shift = torch.nn.PixelShuffle(upscale_factor=2)
+        self.relu = torch.nn.PReLU()
+
+
+class ResidualBlock(torch.nn.Module):
+    """model.py:43-69."""
+
+    def __init__(self, in_channels, out_channels):
+        super().__init__()
+        self.conv1 = torch.nn.Conv2d(in_channels, out_channels, kernel_size=3, stride=1, padding=1, bias=False)
+        self.bn1 = torch.nn.InstanceNorm2d(out_channels)
+        self.relu1 = torch.nn.PReLU()
+        self.conv2 = torch.nn.Conv2d(in_channels, out_channels, kernel_size=3, stride=1, padding=1, bias=False)
+        self.bn2 = torch.nn.InstanceNorm2d(out_channels)
+
+
+class Generator(torch.nn.Module):
+    """model.py:72-117.  `config.n_upsample` (default 2, i.e. 4x) is an extension for BASELINE cfg #5."""
+
+    def __init__(self, config, compute_dtype=None):
+        super().__init__()
+        nf = config.n_filters
+        self.compute = ops.Compute(compute_dtype or _DEFAULT_DTYPE)
+        if nf % self.compute.cpad:
+            raise ValueError("n_filters=%d must be a multiple of %d in %s mode" % (nf, self.compute.cpad, self.compute.name))
+        self.neck = torch.nn.Sequential(torch.nn.Conv2d(3, nf, kernel_size=3, padding=1), torch.nn.PReLU())
+        self.stem = torch.nn.Sequential(*[ResidualBlock(nf, nf) for _ in range(config.n_layers)])
+        self.bottleneck = torch.nn.Sequential(
+            torch.nn.Conv2d(nf, nf, kernel_size=3, padding=1, bias=False), torch.nn.InstanceNorm2d(nf))
+        self.upsampling = torch.nn.Sequential(*[UpSamplingBlock(config) for _ in range(getattr(config, "n_upsample", 2))])
+        self.head = torch.nn.Sequential(torch.nn.Conv2d(nf, 3, kernel_size=3, padding=1), torch.nn.Tanh())
+        cd = self.compute
+        self._cfg_neck = ops.ConvCfg(cd, act=L.ACT_PRELU, image_in=True)
+        self._cfg_in = ops.ConvCfg(cd, stats=True)
+        self._cfg_up = ops.ConvCfg(cd, act=L.ACT_PRELU, pixel_shuffle=True)
+        self._cfg_head = ops.ConvCfg(cd, tanh_head=True)
+
+    def forward(self, x):
+        cd = self.compute
+        r, _ = ops.conv3x3(x, self.neck[0].weight, self.neck[0].bias, self.neck[1].weight, self._cfg_neck)  # :113
+        y = r
+        for blk in self.stem:                                                                           # :114
+            t, st = ops.conv3x3(y, blk.conv1.weight, None, None, self._cfg_in)
+            t = ops.instnorm_act(t, st, None, blk.relu1.weight, cd, L.ACT_PRELU)
+            u, st = ops.conv3x3(t, blk.conv2.weight, None, None, self._cfg_in)
+            y = ops.instnorm_act(u, st, y, None, cd)
+        u, st = ops.conv3x3(y, self.bottleneck[0].weight, None, None, self._cfg_in)                      # :115
+        y = ops.instnorm_act(u, st, r, None, cd)
+        for up in self.upsampling:                                                                      # :116
+            y, _ = ops.conv3x3(y, up.conv.weight, up.conv.bias, up.relu.weight, self._cfg_up)
+        out, _ = ops.conv3x3(y, self.head[0].weight, self.head[0].bias, None, self._cfg_head)           # :117
+        return out
+
+
+class SimpleBlock(torch.nn.Module):
+    """model.py:120-136 (LeakyReLU with the default slope 0.01)."""
+
+    def __init__(self, in_channels, out_channels, stride):
+        super().__init__()
+        self.conv = torch.nn.Conv2d(in_channels, out_channels, kernel_size=3, padding=1, stride=stride, bias=False)
+        self.bn = torch.nn.InstanceNorm2d(out_channels)
+        self.act = torch.nn.LeakyReLU()
+        self.stride = stride
+
+
+class Discriminator(torch.nn.Module):
+    """model.py:139-193.  config.n_layers is accepted and ignored, as in the reference."""
+
+    def __init__(self, config, compute_dtype=None):
+        super().__init__()
+        self.config = config
+        nf = config.n_filters
+        self.compute = ops.Compute(compute_dtype or _DEFAULT_DTYPE)
+        if nf % self.compute.cpad:
+            raise ValueError("n_filters=%d must be a multiple of %d in %s mode" % (nf, self.compute.cpad, self.compute.name))
+        self.neck = torch.nn.Sequential(torch.nn.Conv2d(3, nf, kernel_size=3, padding=1), torch.nn.LeakyReLU(negative_slope=0.2))
+        self.stem = torch.nn.Sequential(
+            SimpleBlock(nf, nf, 2), SimpleBlock(nf, nf * 2, 1), SimpleBlock(nf * 2, nf * 2, 2),
+            SimpleBlock(nf * 2, nf * 4, 1), SimpleBlock(nf * 4, nf * 4, 2), SimpleBlock(nf * 4, nf * 8, 1),
+            SimpleBlock(nf * 8, nf * 8, 2),
+            torch.nn.Conv2d(nf * 8, 1, kernel_size=1, padding=0, stride=1))
+        cd = self.compute
+        self._cfg_neck = ops.ConvCfg(cd, act=L.ACT_LEAKY, slope=0.2, image_in=True)
+        self._cfg_s = {1: ops.ConvCfg(cd, stride=1, stats=True), 2: ops.ConvCfg(cd, stride=2, stats=True)}
+
+    def forward(self, x):
+        cd = self.compute
+        y, _ = ops.conv3x3(x, self.neck[0].weight, self.neck[0].bias, None, self._cfg_neck)
+        for blk in list(self.stem)[:7]:
+            u, st = ops.conv3x3(y, blk.conv.weight, None, None, self._cfg_s[blk.stride])
+            y = ops.instnorm_act(u, st, None, None, cd, L.ACT_LEAKY, 0.01)
+        return ops.conv1x1_to_logits(y, self.stem[7].weight, self.stem[7].bias, cd)
+
+
+_VGG_CFG = [64, 64, "M", 128, 128, "M", 256, 256, 256, 256, "M", 512, 512, 512, 512, "M", 512, 512, 512, 512, "M"]
+
+
+class VGG19(torch.nn.Module):
+    """model.py:5-23: ImageNet normalisation + torchvision vgg19.features[:34], frozen.
+
+    torchvision is not a dependency: the feature stack is rebuilt with the same module indices (state_dict
+    keys vgg.{0,2,5,...,32}.{weight,bias} + buffers mean/std).  Pretrained weights: pass `weights=` a path
+    to torchvision's vgg19 checkpoint (keys features.N.*) or set FSR_VGG19_WEIGHTS; without one the stack
+    is initialised like torchvision's weights=None (kaiming-normal fan_out) and a warning is issued --
+    the ImageNet file cannot be downloaded from an offline machine.
+    """
+
+    def __init__(self, weights=None, compute_dtype=None, width_div=1, seed=None):
+        super().__init__()
+        self.compute = ops.Compute(compute_dtype or _DEFAULT_DTYPE)
+        layers, cin = [], 3
+        for v in _VGG_CFG:
+            if v == "M":
+                layers.append(torch.nn.MaxPool2d(kernel_size=2, stride=2))
+            else:
+                layers += [torch.nn.Conv2d(cin, v // width_div, kernel_size=3, padding=1), torch.nn.ReLU(inplace=True)]
+                cin = v // width_div
+        self.vgg = torch.nn.Sequential(*layers)[:34]
+        path = weights or os.environ.get("FSR_VGG19_WEIGHTS")
+        if path:
+            sd = torch.load(path, map_location="cpu")
+            self.vgg.load_state_dict({k[len("features."):]: v for k, v in sd.items()
+                                      if k.startswith("features.") and int(k.split(".")[1]) < 34})
+        else:
+            if seed is None:
+                warnings.warn("VGG19: no ImageNet weights given (weights= / FSR_VGG19_WEIGHTS); using a random "
+                              "kaiming-normal stand-in of the same architecture")
+            gen = torch.Generator().manual_seed(1234 if seed is None else seed)
+            for m in self.vgg:
+                if isinstance(m, torch.nn.Conv2d):
+                    with torch.no_grad():
+                        std = (2.0 / (m.out_channels * 9)) ** 0.5
+                        m.weight.copy_(torch.randn(m.weight.shape, generator=gen) * std)
+                        m.bias.zero_()
+        for param in self.vgg.parameters():
+            param.requires_grad = False
+        self.register_buffer("mean", torch.tensor([0.485, 0.456, 0.406], requires_grad=False).view(1, 3, 1, 1))
+        self.register_buffer("std", torch.tensor([0.229, 0.224, 0.225], requires_grad=False).view(1, 3, 1, 1))
+        mean, std = [0.485, 0.456, 0.406], [0.229, 0.224, 0.225]
+        cd = self.compute
+        # (x+1)/2 then (x-mean)/std  ==  x * 1/(2 std) + (0.5-mean)/std, fused into the first conv's input load
+        self._cfg_first = ops.ConvCfg(cd, act=L.ACT_RELU, image_in=True, in_scale=tuple(0.5 / s for s in std),
+                                      in_shift=tuple((0.5 - m) / s for m, s in zip(mean, std)))
+        self._cfg = ops.ConvCfg(cd, act=L.ACT_RELU)
+
+    def features_nhwc(self, x):
+        y, first = x, True
+        for m in self.vgg:
+            if isinstance(m, torch.nn.Conv2d):
+                y, _ = ops.conv3x3(y, m.weight, m.bias, None, self._cfg_first if first else self._cfg)
+                first = False
+            elif isinstance(m, torch.nn.MaxPool2d):
+                y = ops.maxpool2(y, self.compute)
+        return y
+
+    def forward(self, x):
+        return self.features_nhwc(x).permute(0, 3, 1, 2)

@@ -1,0 +1,416 @@
+"""Operators of the Fast-SRGAN hot path: torch.autograd.Functions over the C ABI of libfsr_hip.so.
+
+Layout contract: activations are NHWC tensors (N,H,W,C) in the compute dtype
+(torch.bfloat16 for FSR_BF16, torch.float32 for FSR_F32) with C a multiple of CPAD (32 / 16);
+3-channel images enter and leave as float32 NCHW-shaped tensors of any strides.  Every kernel is
+enqueued on torch's current stream; nothing here synchronises, allocates pinned memory or falls
+back to a torch implementation of the math.
+"""
+import ctypes
+
+import torch
+
+from . import _lib as L
+
+_DT = {"f32": (L.FSR_F32, torch.float32, 16), "bf16": (L.FSR_BF16, torch.bfloat16, 32)}
+
+
+class Compute:
+    """Compute mode of a module: 'bf16' (bf16 MFMA, f32 accumulate) or 'f32' (exact-f32 MFMA)."""
+
+    def __init__(self, name="bf16"):
+        if name not in _DT:
+            raise ValueError("compute dtype must be 'bf16' or 'f32', got %r" % (name,))
+        self.name = name
+        self.code, self.torch_dtype, self.cpad = _DT[name]
+
+    def pad(self, c):
+        return (c + self.cpad - 1) // self.cpad * self.cpad
+
+
+def _stream():
+    if L.is_emulation():
+        return None
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _p(t):
+    return None if t is None else t.data_ptr()
+
+
+def _check_dev(*ts):
+    for t in ts:
+        if t is not None and not L.is_emulation() and not t.is_cuda:
+            raise L.FsrError("fast-srgan_amd operators run on the GPU only (got a %s tensor); there is no CPU path" % t.device)
+
+
+# ---------------------------------------------------------------------------------- packed filters
+_pack_cache = {}
+
+
+def packed_filter(cd, weight, mode, k_pad):
+    """[9][rows_pad][k_pad] image of an OIHW float weight (fsr_pack_conv3x3), cached per weight version."""
+    key = (id(weight), mode, cd.code, k_pad)
+    ver = weight._version
+    hit = _pack_cache.get(key)
+    if hit is not None and hit[0] == ver and hit[2] == weight.data_ptr():
+        return hit[1]
+    cout, cin = weight.shape[0], weight.shape[1]
+    fwd = mode in (L.PACK_FWD, L.PACK_FWD_PS)
+    rows = cout if fwd else cin
+    rows_pad = (rows + 15) // 16 * 16
+    w = weight.detach()
+    if w.dtype != torch.float32 or not w.is_contiguous():
+        w = w.float().contiguous()
+    _check_dev(w)
+    out = torch.empty(9 * rows_pad * k_pad, dtype=cd.torch_dtype, device=w.device)
+    L.check(L.lib().fsr_pack_conv3x3(cd.code, mode, _p(w), cout, cin, k_pad, _p(out), _stream()), "fsr_pack_conv3x3")
+    _pack_cache[key] = (ver, out, weight.data_ptr())
+    if len(_pack_cache) > 4096:
+        _pack_cache.clear()
+    return out
+
+
+_ws = {}
+
+
+def _workspace(nbytes, device):
+    buf = _ws.get(device)
+    if buf is None or buf.numel() * 4 < nbytes:
+        buf = torch.empty((nbytes + 3) // 4, dtype=torch.float32, device=device)
+        _ws[device] = buf
+    return buf
+
+
+# ---------------------------------------------------------------------------------- raw launches
+def conv3x3_raw(cd, x, wpk, cout, *, mode=L.CONV_FWD, out_hw=None, stride=1, bias=None, act=L.ACT_NONE, slope=0.0,
+                prelu=None, oscale=None, pixel_shuffle=False, in_pixel_shuffled=False, out_f32=False, want_stats=False,
+                want_preact=False):
+    """One fsr_conv3x3 launch.  x: (N,IH,IW,Cin) [or its depth-to-space form when in_pixel_shuffled]."""
+    _check_dev(x)
+    n = x.shape[0]
+    if in_pixel_shuffled:
+        ih, iw, cin = x.shape[1] // 2, x.shape[2] // 2, x.shape[3] * 4
+    else:
+        ih, iw, cin = x.shape[1], x.shape[2], x.shape[3]
+    if mode == L.CONV_FWD:
+        oh, ow = (ih - 1) // stride + 1, (iw - 1) // stride + 1
+    else:
+        oh, ow = out_hw
+    odt = torch.float32 if out_f32 else cd.torch_dtype
+    oshape = (n, 2 * oh, 2 * ow, cout // 4) if pixel_shuffle else (n, oh, ow, cout)
+    out = torch.empty(oshape, dtype=odt, device=x.device)
+    pre = torch.empty(oshape, dtype=odt, device=x.device) if want_preact else None
+    stats = torch.zeros((n, cout, 2), dtype=torch.float32, device=x.device) if want_stats else None
+    d = L.ConvDesc(cd.code, mode, n, ih, iw, cin, oh, ow, cout, stride, act, float(slope), int(pixel_shuffle),
+                   int(in_pixel_shuffled), int(out_f32))
+    L.check(L.lib().fsr_conv3x3(ctypes.byref(d), _p(x), _p(wpk), _p(bias), _p(prelu), _p(oscale), _p(out), _p(pre),
+                                _p(stats), _stream()), "fsr_conv3x3")
+    return out, pre, stats
+
+
+def conv3x3_wgrad_raw(cd, x, dy, cout, cin, stride, dy_pixel_shuffled=False):
+    """OIHW float weight gradient.  x (N,IH,IW,CinPad); dy (N,OH,OW,CoutPad) or its depth-to-space form."""
+    n, ih, iw, cin_pad = x.shape
+    if dy_pixel_shuffled:
+        oh, ow, cout_pad = dy.shape[1] // 2, dy.shape[2] // 2, dy.shape[3] * 4
+    else:
+        oh, ow, cout_pad = dy.shape[1], dy.shape[2], dy.shape[3]
+    d = L.WgradDesc(cd.code, n, ih, iw, cin_pad, cin, oh, ow, cout_pad, cout, stride, int(dy_pixel_shuffled))
+    need = L.lib().fsr_conv3x3_wgrad_workspace(ctypes.byref(d))
+    if need == 0:
+        L.check(-2, "fsr_conv3x3_wgrad_workspace")
+    ws = _workspace(need, x.device)
+    dw = torch.zeros((cout, cin, 3, 3), dtype=torch.float32, device=x.device)
+    L.check(L.lib().fsr_conv3x3_wgrad(ctypes.byref(d), _p(x), _p(dy), _p(dw), _p(ws), _stream()), "fsr_conv3x3_wgrad")
+    return dw
+
+
+def image_to_nhwc(cd, img, scale=(1.0, 1.0, 1.0), shift=(0.0, 0.0, 0.0)):
+    """(N,3,H,W) float32 of any strides -> zero-padded (N,H,W,CPAD) compute-dtype tensor."""
+    _check_dev(img)
+    if img.dtype != torch.float32:
+        img = img.float()
+    n, c, h, w = img.shape
+    if c != 3:
+        raise ValueError("expected a 3-channel image batch, got %s" % (tuple(img.shape),))
+    out = torch.empty((n, h, w, cd.cpad), dtype=cd.torch_dtype, device=img.device)
+    sn, sc, sh, sw = img.stride()
+    L.check(L.lib().fsr_image_to_nhwc(cd.code, _p(img), sn, sc, sh, sw, n, h, w, scale[0], scale[1], scale[2], shift[0],
+                                      shift[1], shift[2], _p(out), cd.cpad, _stream()), "fsr_image_to_nhwc")
+    return out
+
+
+# ---------------------------------------------------------------------------------- autograd: convolution
+class ConvCfg:
+    """Static description of one fused convolution (kept out of autograd's tensor arguments)."""
+
+    def __init__(self, cd, *, stride=1, act=L.ACT_NONE, slope=0.0, pixel_shuffle=False, stats=False, image_in=False,
+                 in_scale=(1.0, 1.0, 1.0), in_shift=(0.0, 0.0, 0.0), tanh_head=False):
+        self.cd, self.stride, self.act, self.slope = cd, stride, act, slope
+        self.pixel_shuffle, self.stats, self.image_in = pixel_shuffle, stats, image_in
+        self.in_scale, self.in_shift, self.tanh_head = in_scale, in_shift, tanh_head
+
+
+class Conv3x3Fn(torch.autograd.Function):
+    """Conv2d(k=3,p=1) + bias + activation [+ PixelShuffle(2)] [+ InstanceNorm statistics].
+
+    forward(x, weight, bias, prelu_weight, cfg) -> (out, stats)
+      x      : NHWC activation, or (image_in) a float32 NCHW image batch of any strides
+      out    : NHWC activation; (tanh_head) a float32 (N,3,H,W) view of the NHWC head output
+      stats  : (N,Cout,2) float32 sums of the pre-activation, or an empty tensor
+    """
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, prelu, cfg):
+        cd = cfg.cd
+        cout, cin = weight.shape[0], weight.shape[1]
+        if cfg.image_in:
+            xin = image_to_nhwc(cd, x, cfg.in_scale, cfg.in_shift)
+        else:
+            xin = x if x.is_contiguous() else x.contiguous()
+            if xin.dtype != cd.torch_dtype:
+                raise L.FsrError("activation dtype %s does not match the module's compute dtype %s" % (xin.dtype, cd.name))
+        cin_pad = xin.shape[3]
+        wpk = packed_filter(cd, weight, L.PACK_FWD_PS if cfg.pixel_shuffle else L.PACK_FWD, cin_pad)
+        training = any(ctx.needs_input_grad)  # (grad mode is off inside Function.forward)
+        act = L.ACT_TANH if cfg.tanh_head else cfg.act
+        want_pre = training and act == L.ACT_PRELU
+        b32 = bias if bias is None or bias.dtype == torch.float32 else bias.float()
+        out, pre, stats = conv3x3_raw(cd, xin, wpk, cout, stride=cfg.stride, bias=b32, act=act, slope=cfg.slope,
+                                      prelu=prelu, pixel_shuffle=cfg.pixel_shuffle, out_f32=cfg.tanh_head,
+                                      want_stats=cfg.stats, want_preact=want_pre)
+        ctx.cfg = cfg
+        ctx.dims = (cout, cin, tuple(xin.shape))
+        ctx.has_bias = bias is not None
+        ctx.x_is_image = cfg.image_in
+        saved_act = pre if want_pre else (out if act in (L.ACT_RELU, L.ACT_LEAKY, L.ACT_TANH) else None)
+        ctx.save_for_backward(xin, weight, prelu, saved_act)
+        if stats is None:
+            stats = torch.empty(0, device=out.device)
+        ctx.mark_non_differentiable(stats)
+        if cfg.tanh_head:
+            return out.permute(0, 3, 1, 2), stats
+        return out, stats
+
+    @staticmethod
+    def backward(ctx, g, _gstats):
+        cfg, cd = ctx.cfg, ctx.cfg.cd
+        xin, weight, prelu, saved = ctx.saved_tensors
+        cout, cin, xshape = ctx.dims
+        n, ih, iw, cin_pad = xshape
+        lib, st = L.lib(), _stream()
+        dbias = torch.zeros(cout, dtype=torch.float32, device=xin.device) if ctx.has_bias else None
+        dprelu = None
+        act = L.ACT_TANH if cfg.tanh_head else cfg.act
+        if cfg.tanh_head:
+            # g: (N,3,H,W) float of any strides; saved: head output (N,H,W,3) float
+            if g.dtype != torch.float32:
+                g = g.float()
+            _, _, h, w = g.shape
+            dz = torch.empty((n, h, w, cd.cpad), dtype=cd.torch_dtype, device=xin.device)
+            sn, sc, sh, sw = g.stride()
+            L.check(lib.fsr_tanh_bwd_to_nhwc(cd.code, _p(g), sn, sc, sh, sw, _p(saved), n, h, w, _p(dz), cd.cpad, _p(dbias),
+                                             st), "fsr_tanh_bwd_to_nhwc")
+        else:
+            g = g if g.is_contiguous() else g.contiguous()
+            if act != L.ACT_NONE or ctx.has_bias:
+                if act == L.ACT_PRELU:
+                    dprelu = torch.zeros(1, dtype=torch.float32, device=xin.device)
+                dz = torch.empty_like(g)
+                _, h, w, c = g.shape
+                L.check(lib.fsr_act_bwd(cd.code, _p(g), _p(saved), act, float(cfg.slope), _p(prelu), _p(dz), _p(dbias),
+                                        _p(dprelu), n, h, w, c, int(cfg.pixel_shuffle), st), "fsr_act_bwd")
+            else:
+                dz = g
+        dx = None
+        if ctx.needs_input_grad[0]:
+            if ctx.x_is_image:
+                wpk = packed_filter(cd, weight, L.PACK_DGRAD, dz.shape[3] * (4 if cfg.pixel_shuffle else 1))
+                osc = torch.tensor(cfg.in_scale, dtype=torch.float32, device=xin.device) if tuple(cfg.in_scale) != (1.0, 1.0, 1.0) else None
+                dx, _, _ = conv3x3_raw(cd, dz, wpk, 3, mode=L.CONV_DGRAD, out_hw=(ih, iw), stride=cfg.stride, oscale=osc,
+                                       out_f32=True, in_pixel_shuffled=cfg.pixel_shuffle)
+                dx = dx.permute(0, 3, 1, 2)
+            else:
+                kpad = dz.shape[3] * (4 if cfg.pixel_shuffle else 1)
+                wpk = packed_filter(cd, weight, L.PACK_DGRAD_PS if cfg.pixel_shuffle else L.PACK_DGRAD, kpad)
+                dx, _, _ = conv3x3_raw(cd, dz, wpk, cin_pad, mode=L.CONV_DGRAD, out_hw=(ih, iw), stride=cfg.stride,
+                                       in_pixel_shuffled=cfg.pixel_shuffle)
+        dw = None
+        if ctx.needs_input_grad[1]:
+            dw = conv3x3_wgrad_raw(cd, xin, dz, cout, cin, cfg.stride, dy_pixel_shuffled=cfg.pixel_shuffle)
+        db = dbias if (ctx.has_bias and ctx.needs_input_grad[2]) else None
+        dp = dprelu if (dprelu is not None and ctx.needs_input_grad[3]) else None
+        return dx, dw, db, dp, None
+
+
+def conv3x3(x, weight, bias, prelu, cfg):
+    return Conv3x3Fn.apply(x, weight, bias, prelu, cfg)
+
+
+# ---------------------------------------------------------------------------------- autograd: InstanceNorm + act + residual
+class InstNormActFn(torch.autograd.Function):
+    """out = act(InstanceNorm(x)) + res, from the raw conv output and the statistics its epilogue made."""
+
+    @staticmethod
+    def forward(ctx, x, stats, res, prelu, cd, act, slope):
+        _check_dev(x)
+        n, h, w, c = x.shape
+        out = torch.empty_like(x)
+        if res is not None and not res.is_contiguous():
+            res = res.contiguous()
+        L.check(L.lib().fsr_instnorm_act_fwd(cd.code, _p(x), _p(stats), _p(res), act, float(slope), _p(prelu), _p(out), n,
+                                             h * w, c, _stream()), "fsr_instnorm_act_fwd")
+        ctx.meta = (cd, act, slope, res is not None)
+        ctx.save_for_backward(x, stats, prelu)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        cd, act, slope, has_res = ctx.meta
+        x, stats, prelu = ctx.saved_tensors
+        n, h, w, c = x.shape
+        g = g if g.is_contiguous() else g.contiguous()
+        lib, st = L.lib(), _stream()
+        sums = torch.zeros((n, c, 2), dtype=torch.float32, device=x.device)
+        dprelu = torch.zeros(1, dtype=torch.float32, device=x.device) if act == L.ACT_PRELU else None
+        L.check(lib.fsr_instnorm_act_bwd_reduce(cd.code, _p(g), _p(x), _p(stats), act, float(slope), _p(prelu), _p(sums),
+                                                _p(dprelu), n, h * w, c, st), "fsr_instnorm_act_bwd_reduce")
+        dx = torch.empty_like(x)
+        L.check(lib.fsr_instnorm_act_bwd_apply(cd.code, _p(g), _p(x), _p(stats), _p(sums), act, float(slope), _p(prelu),
+                                               _p(dx), n, h * w, c, st), "fsr_instnorm_act_bwd_apply")
+        return dx, None, (g if has_res else None), dprelu, None, None, None
+
+
+def instnorm_act(x, stats, res, prelu, cd, act=L.ACT_NONE, slope=0.0):
+    return InstNormActFn.apply(x, stats, res, prelu, cd, act, slope)
+
+
+# ---------------------------------------------------------------------------------- autograd: MaxPool2d(2,2)
+class MaxPool2Fn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, cd):
+        _check_dev(x)
+        n, h, w, c = x.shape
+        y = torch.empty((n, h // 2, w // 2, c), dtype=x.dtype, device=x.device)
+        L.check(L.lib().fsr_maxpool2_fwd(cd.code, _p(x), _p(y), n, h, w, c, _stream()), "fsr_maxpool2_fwd")
+        ctx.cd = cd
+        ctx.save_for_backward(x, y)
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        x, y = ctx.saved_tensors
+        n, h, w, c = x.shape
+        g = g if g.is_contiguous() else g.contiguous()
+        dx = torch.empty_like(x)
+        L.check(L.lib().fsr_maxpool2_bwd(ctx.cd.code, _p(g), _p(x), _p(y), _p(dx), n, h, w, c, _stream()), "fsr_maxpool2_bwd")
+        return dx, None
+
+
+def maxpool2(x, cd):
+    return MaxPool2Fn.apply(x, cd)
+
+
+# ---------------------------------------------------------------------------------- autograd: Conv2d(C -> 1, k=1)
+class Conv1x1ToLogitsFn(torch.autograd.Function):
+    """x (N,H,W,C) -> float32 logits (N,1,H,W) (model.py:184-186)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, cd):
+        _check_dev(x)
+        n, h, w, c = x.shape
+        x = x if x.is_contiguous() else x.contiguous()
+        wv = weight.detach().reshape(-1)
+        logits = torch.empty((n, 1, h, w), dtype=torch.float32, device=x.device)
+        L.check(L.lib().fsr_conv1x1_c1_fwd(cd.code, _p(x), _p(wv), _p(bias), _p(logits), n * h * w, c, _stream()),
+                "fsr_conv1x1_c1_fwd")
+        ctx.cd = cd
+        ctx.save_for_backward(x, weight)
+        return logits
+
+    @staticmethod
+    def backward(ctx, g):
+        x, weight = ctx.saved_tensors
+        n, h, w, c = x.shape
+        g = g.contiguous().float()
+        dx = torch.empty_like(x) if ctx.needs_input_grad[0] else None
+        dw = torch.zeros(weight.shape, dtype=torch.float32, device=x.device)
+        db = torch.zeros(1, dtype=torch.float32, device=x.device)
+        L.check(L.lib().fsr_conv1x1_c1_bwd(ctx.cd.code, _p(g), _p(x), _p(weight.detach().reshape(-1)), _p(dx), _p(dw), _p(db),
+                                           n * h * w, c, _stream()), "fsr_conv1x1_c1_bwd")
+        return dx, dw, db, None
+
+
+def conv1x1_to_logits(x, weight, bias, cd):
+    return Conv1x1ToLogitsFn.apply(x, weight, bias, cd)
+
+
+# ---------------------------------------------------------------------------------- autograd: losses
+class BCEWithLogitsFn(torch.autograd.Function):
+    """torch.nn.BCEWithLogitsLoss() (mean) on float32 logits/targets (trainer.py:41)."""
+
+    @staticmethod
+    def forward(ctx, x, t):
+        _check_dev(x, t)
+        x = x.contiguous().float()
+        t = t.contiguous().float()
+        loss = torch.zeros((), dtype=torch.float32, device=x.device)
+        L.check(L.lib().fsr_bce_logits_fwd(_p(x), _p(t), _p(loss), x.numel(), _stream()), "fsr_bce_logits_fwd")
+        ctx.save_for_backward(x, t)
+        return loss
+
+    @staticmethod
+    def backward(ctx, g):
+        x, t = ctx.saved_tensors
+        g = g.contiguous().float()
+        dx = torch.empty_like(x)
+        L.check(L.lib().fsr_bce_logits_bwd(_p(x), _p(t), _p(g), _p(dx), x.numel(), _stream()), "fsr_bce_logits_bwd")
+        return dx, None
+
+
+def _is_dense(t):
+    """True when t's elements tile its storage without gaps or overlap (e.g. a permuted contiguous tensor)."""
+    pairs = sorted((st, sz) for st, sz in zip(t.stride(), t.shape) if sz > 1)
+    expect = 1
+    for st, sz in pairs:
+        if st != expect:
+            return False
+        expect *= sz
+    return True
+
+
+class SmoothL1Fn(torch.autograd.Function):
+    """torch.nn.SmoothL1Loss() (beta 1, mean) (trainer.py:43); the second argument is the target."""
+
+    @staticmethod
+    def forward(ctx, a, b):
+        _check_dev(a, b)
+        if a.dtype != b.dtype or a.shape != b.shape:
+            raise L.FsrError("SmoothL1: operands must share dtype and shape")
+        if not (a.stride() == b.stride() and _is_dense(a)):  # elementwise: any shared dense layout will do
+            a, b = a.contiguous(), b.contiguous()
+        code = L.FSR_BF16 if a.dtype == torch.bfloat16 else L.FSR_F32
+        if code == L.FSR_F32 and a.dtype != torch.float32:
+            raise L.FsrError("SmoothL1: unsupported dtype %s" % a.dtype)
+        loss = torch.zeros((), dtype=torch.float32, device=a.device)
+        L.check(L.lib().fsr_smooth_l1_fwd(code, _p(a), _p(b), _p(loss), a.numel(), _stream()), "fsr_smooth_l1_fwd")
+        ctx.code = code
+        ctx.save_for_backward(a, b)
+        return loss
+
+    @staticmethod
+    def backward(ctx, g):
+        a, b = ctx.saved_tensors
+        g = g.contiguous().float()
+        da = torch.empty_like(a)
+        L.check(L.lib().fsr_smooth_l1_bwd(ctx.code, _p(a), _p(b), _p(g), _p(da), a.numel(), _stream()), "fsr_smooth_l1_bwd")
+        return da, None
+
+
+def bce_with_logits(x, t):
+    return BCEWithLogitsFn.apply(x, t)
+
+
+def smooth_l1(a, b):
+    return SmoothL1Fn.apply(a, b)

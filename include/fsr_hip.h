@@ -11,9 +11,13 @@
  *   - every pointer is a DEVICE pointer borrowed from the caller (a torch tensor's data_ptr());
  *     the library never allocates, frees or synchronises; calls only enqueue work on `stream`
  *     (a hipStream_t passed as void*), so they are legal inside hipGraph stream capture;
- *   - activations are NHWC; `dtype` is the storage type of activations and packed filters:
- *     FSR_F32 (exact-f32 MFMA, parity mode) or FSR_BF16 (bf16 MFMA, f32 accumulate);
- *     parameters, biases, statistics, gradients of parameters and losses are always float;
+ *   - activations are NHWC; `dtype` is the storage type of activations, activation gradients and
+ *     packed filters: FSR_F32 (exact-f32 MFMA, parity mode) or FSR_BF16 (bf16 MFMA, f32
+ *     accumulate); parameters, biases, statistics, parameter gradients and losses are float;
+ *   - channel counts of NHWC activations are multiples of FSR_CPAD(dtype) = 16 (f32) / 32 (bf16);
+ *     3-channel images are stored zero-padded to that width;
+ *   - "accumulates into" outputs (statistics, parameter gradients, losses) must be zeroed by the
+ *     caller; they are updated with float atomics (summation order is not reproducible bit for bit);
  *   - return value 0 = enqueued, < 0 = rejected (nothing enqueued); fsr_last_error() gives the
  *     reason for the calling thread.  The functions are thread-compatible.
  */
@@ -27,13 +31,12 @@
 extern "C" {
 #endif
 
-#define FSR_ABI_VERSION 1
+#define FSR_ABI_VERSION 2
 
 enum { FSR_F32 = 0, FSR_BF16 = 1 };
 enum { FSR_ACT_NONE = 0, FSR_ACT_RELU = 1, FSR_ACT_LEAKY = 2, FSR_ACT_PRELU = 3, FSR_ACT_TANH = 4 };
 enum { FSR_CONV_FWD = 0, FSR_CONV_DGRAD = 1 };
 enum { FSR_PACK_FWD = 0, FSR_PACK_FWD_PS = 1, FSR_PACK_DGRAD = 2, FSR_PACK_DGRAD_PS = 3 };
-enum { FSR_C3_IN_PLAIN = 0, FSR_C3_IN_VGG_NORM = 1, FSR_C3_IN_TANH_BWD = 2 };
 
 typedef void* fsr_stream_t; /* hipStream_t */
 
@@ -44,15 +47,16 @@ int fsr_device_info(char* buf, size_t buflen);
 
 /* ------------------------------------------------------------------ filter packing
  * torch Conv2d weights are OIHW float (state_dict layout, model.py:30-35,47-64,...).  The
- * kernels consume [9 taps][rows_pad][K] in `dtype` with K contiguous:
+ * kernels consume [9 taps][rows_pad][K_pad] in `dtype` with K contiguous:
  *   FSR_PACK_FWD       rows = cout, K = cin                  slice index = ky*3+kx
  *   FSR_PACK_FWD_PS    as FWD, rows permuted r = (co%4)*(cout/4) + co/4 so that the epilogue of
  *                      the PixelShuffle(2) convs (model.py:36,40) stores contiguous channels
  *   FSR_PACK_DGRAD     rows = cin,  K = cout                 (transposed filter for dL/dx)
  *   FSR_PACK_DGRAD_PS  as DGRAD with K permuted like FWD_PS rows
- * rows_pad = 16 when rows < 16 (head conv, model.py:103-108; first-layer data gradients), else
- * rows; padded rows are zero filled.  `packed` holds 9*rows_pad*K elements. */
-int fsr_pack_conv3x3(int dtype, int mode, const float* w_oihw, int cout, int cin, void* packed,
+ * rows_pad = rows rounded up to 16 (head conv, model.py:103-108; first-layer data gradients:
+ * 3 -> 16); K_pad = `k_pad` >= K (3-channel inputs: K zero-padded to FSR_CPAD).  Padding is zero
+ * filled.  `packed` holds 9*rows_pad*k_pad elements. */
+int fsr_pack_conv3x3(int dtype, int mode, const float* w_oihw, int cout, int cin, int k_pad, void* packed,
                      fsr_stream_t stream);
 
 /* ------------------------------------------------------------------ 3x3 convolution, pad 1
@@ -66,11 +70,16 @@ int fsr_pack_conv3x3(int dtype, int mode, const float* w_oihw, int cout, int cin
  *   mode FSR_CONV_DGRAD: in = dL/dy [n,ih,iw,cin], out = dL/dx [n,oh,ow,cout] where
  *                        (ih,iw,cin) are the forward OUTPUT dims and (oh,ow,cout) the forward
  *                        INPUT dims; stride is the forward stride.
+ * cin is the (padded) channel count of `in` and the K_pad of the packed filter.
  * pixel_shuffle (FWD): out is [n,2oh,2ow,cout/4]; filters packed FSR_PACK_FWD_PS.
  * in_pixel_shuffled (DGRAD): in is [n,2ih,2iw,cin/4]; filters packed FSR_PACK_DGRAD_PS.
- * stats (optional): float [n][cout][2], must be zeroed by the caller; accumulates the sum and
- *   sum of squares of the pre-activation over pixels.
- * addend (optional): tensor shaped/typed like out, added before the activation. */
+ * out_f32: store float whatever `dtype` is (3-channel outputs: head images, image gradients).
+ * stats (optional): float [n][cout][2]; accumulates the sum and sum of squares of the
+ *   pre-activation over pixels.
+ * preact (optional): tensor like out; receives the pre-activation (training: PReLU backward
+ *   needs its sign, which the output of a negative-slope PReLU does not reveal).
+ * oscale (optional): float [cout] multiplied into the result before bias/activation (the
+ *   1/(2 std) of VGG19.forward's normalisation, model.py:21-22, applied to input gradients). */
 typedef struct fsr_conv_desc {
   int dtype;
   int mode;
@@ -85,8 +94,105 @@ typedef struct fsr_conv_desc {
 } fsr_conv_desc;
 
 int fsr_conv3x3(const fsr_conv_desc* desc, const void* in, const void* packed_w, const float* bias,
-                const float* prelu_weight, const void* addend, void* out, float* stats,
+                const float* prelu_weight, const float* oscale, void* out, void* preact, float* stats,
                 fsr_stream_t stream);
+
+/* Weight gradient of the same convolutions: dW[co][ci][ky][kx] (OIHW float, torch .grad layout)
+ *   += sum_{n,y,x} dy[n,y,x,co] * x[n, y*stride+ky-1, x*stride+kx-1, ci]      (autograd of model.py convs)
+ * x [n,ih,iw,cin_pad], dy [n,oh,ow,cout_pad] (or [n,2oh,2ow,cout/4] when dy_pixel_shuffled).
+ * Only dW[:cout][:cin] is written (cin/cout may be smaller than the padded tensor widths).
+ * `workspace` (float, fsr_conv3x3_wgrad_workspace() bytes) holds split-K partials; dw accumulates. */
+typedef struct fsr_wgrad_desc {
+  int dtype;
+  int n, ih, iw, cin_pad, cin;
+  int oh, ow, cout_pad, cout;
+  int stride;
+  int dy_pixel_shuffled;
+} fsr_wgrad_desc;
+size_t fsr_conv3x3_wgrad_workspace(const fsr_wgrad_desc* desc);
+int fsr_conv3x3_wgrad(const fsr_wgrad_desc* desc, const void* x, const void* dy, float* dw_oihw, void* workspace,
+                      fsr_stream_t stream);
+
+/* ------------------------------------------------------------------ InstanceNorm2d (+ activation, + residual)
+ * torch.nn.InstanceNorm2d defaults (model.py:55,65,94,132: biased variance, eps 1e-5, no affine)
+ * applied to the raw conv output using the statistics the conv epilogue accumulated, fused with
+ * PReLU (model.py:56) / LeakyReLU (model.py:133) and the residual add (model.py:69,115):
+ *   out = act((x - mean) * rstd) + res.          x, res, out: [n,hw,c] `dtype`; stats [n][c][2]. */
+int fsr_instnorm_act_fwd(int dtype, const void* x, const float* stats, const void* res, int act, float slope,
+                         const float* prelu_weight, void* out, int n, int hw, int c, fsr_stream_t stream);
+/* Backward, phase 1: sums[n][c][2] += (sum gz, sum gz*xhat) with gz = g * act'(xhat);
+ * dprelu[0] += sum g*min(xhat,0).   Phase 2: dx = rstd*(gz - mean(gz) - xhat*mean(gz*xhat)). */
+int fsr_instnorm_act_bwd_reduce(int dtype, const void* g, const void* x, const float* stats, int act, float slope,
+                                const float* prelu_weight, float* sums, float* dprelu, int n, int hw, int c,
+                                fsr_stream_t stream);
+int fsr_instnorm_act_bwd_apply(int dtype, const void* g, const void* x, const float* stats, const float* sums,
+                               int act, float slope, const float* prelu_weight, void* dx, int n, int hw, int c,
+                               fsr_stream_t stream);
+
+/* ------------------------------------------------------------------ activation backward of a fused conv epilogue
+ * dz = g * act'(.) for the activations fsr_conv3x3 fuses; `saved` is the conv OUTPUT for
+ * ReLU / LeakyReLU(slope > 0) and the saved PRE-activation for PReLU.  Tensors [n,h,w,c] `dtype`.
+ * dbias (optional, float [cb]) += per-channel sums of dz; with pixel_shuffled != 0 the tensors are
+ * the depth-to-space outputs of a cb = 4c channel conv and dbias index = 4*ch + 2*(y&1) + (x&1).
+ * dprelu (optional) += sum g*min(saved,0). */
+int fsr_act_bwd(int dtype, const void* g, const void* saved, int act, float slope, const float* prelu_weight,
+                void* dz, float* dbias, float* dprelu, int n, int h, int w, int c, int pixel_shuffled,
+                fsr_stream_t stream);
+
+/* ------------------------------------------------------------------ 3-channel images <-> padded NHWC
+ * img: float, element strides (sn, sc, sh, sw) -- any of NCHW (dataloader.py:36-38 tensors) or
+ * NHWC (the head's output).  out[n,h,w,cpad] = img*scale[c] + shift[c] for c < 3, else 0.
+ * (VGG19.forward's (x+1)/2, (x-mean)/std, model.py:21-22, is scale = 1/(2 std), shift = (0.5-mean)/std.) */
+int fsr_image_to_nhwc(int dtype, const float* img, long long sn, long long sc, long long sh, long long sw, int n,
+                      int h, int w, float scale0, float scale1, float scale2, float shift0, float shift1,
+                      float shift2, void* out, int cpad, fsr_stream_t stream);
+/* Head backward (model.py:102-110): dz = g * (1 - y^2) for y = tanh(z), written zero-padded NHWC;
+ * g has element strides (sn,sc,sh,sw), y is the head output [n,h,w,3] float.  dbias[3] += sums. */
+int fsr_tanh_bwd_to_nhwc(int dtype, const float* g, long long sn, long long sc, long long sh, long long sw,
+                         const float* y_nhwc3, int n, int h, int w, void* dz, int cpad, float* dbias,
+                         fsr_stream_t stream);
+
+/* ------------------------------------------------------------------ MaxPool2d(2,2) of vgg19.features (model.py:8)
+ * x [n,h,w,c] -> y [n,h/2,w/2,c].  Backward routes g to the first maximum in window scan order. */
+int fsr_maxpool2_fwd(int dtype, const void* x, void* y, int n, int h, int w, int c, fsr_stream_t stream);
+int fsr_maxpool2_bwd(int dtype, const void* g, const void* x, const void* y, void* dx, int n, int h, int w, int c,
+                     fsr_stream_t stream);
+
+/* ------------------------------------------------------------------ Discriminator head: Conv2d(512 -> 1, k=1) (model.py:184-186)
+ * logits[p] = b + sum_c x[p][c]*w[c]; x [npix,c] `dtype`, logits float.
+ * Backward: dx[p][c] = g[p]*w[c]; dw[c] += sum_p g[p]*x[p][c]; db[0] += sum_p g[p]. */
+int fsr_conv1x1_c1_fwd(int dtype, const void* x, const float* w, const float* b, float* logits, int npix, int c,
+                       fsr_stream_t stream);
+int fsr_conv1x1_c1_bwd(int dtype, const float* g, const void* x, const float* w, void* dx, float* dw, float* db,
+                       int npix, int c, fsr_stream_t stream);
+
+/* ------------------------------------------------------------------ losses (trainer.py:41,43,177,178,188,192,109)
+ * BCEWithLogitsLoss (mean): loss[0] += mean(max(x,0) - x*t + log1p(exp(-|x|))); x, t float [count].
+ * Backward: dx = gscale[0] * (sigmoid(x) - t) / count   (gscale: device scalar, the upstream grad). */
+int fsr_bce_logits_fwd(const float* x, const float* t, float* loss, long long count, fsr_stream_t stream);
+int fsr_bce_logits_bwd(const float* x, const float* t, const float* gscale, float* dx, long long count,
+                       fsr_stream_t stream);
+/* SmoothL1Loss (beta 1, mean) between `a` and `b` (`dtype` tensors, or float when dtype_is_f32_io):
+ * loss[0] += mean(huber(a-b)).  Backward: da = gscale[0]*clamp(a-b,-1,1)/count (db = -da not produced:
+ * the target branch of trainer.py:191/:109 needs no gradient). */
+int fsr_smooth_l1_fwd(int dtype, const void* a, const void* b, float* loss, long long count, fsr_stream_t stream);
+int fsr_smooth_l1_bwd(int dtype, const void* a, const void* b, const float* gscale, void* da, long long count,
+                      fsr_stream_t stream);
+
+/* ------------------------------------------------------------------ AdamW (trainer.py:33-38, torch defaults)
+ * One fused step over a flat float parameter arena: p *= 1 - lr*wd; m, v updated; p -= lr/bc1 * m / (sqrt(v)/sqrt(bc2) + eps). */
+int fsr_adamw_step(float* p, const float* g, float* m, float* v, long long count, float lr, float beta1, float beta2,
+                   float eps, float weight_decay, int step, fsr_stream_t stream);
+
+/* ------------------------------------------------------------------ crop + antialiased bicubic down-scale (dataloader.py:24-38)
+ * For each of `n` samples: crop hr_size x hr_size at (crop_y[i], crop_x[i]) from the uint8 CHW image
+ * image[i] (device pointers, heights/widths per image), hr = crop/127.5 - 1 (float NCHW [n,3,hr,hr]);
+ * lr = antialiased bicubic (a = -0.5, support 2*scale) down-scale of the UNSCALED crop by `scale`,
+ * then /127.5 - 1 (float NCHW [n,3,hr/scale,hr/scale]).  wtab: float [hr/scale][kmax] normalised
+ * taps, xmin/xsize int [hr/scale] (identical for rows and columns; built on the host once). */
+int fsr_crop_resize(const uint8_t* const* images, const int* img_h, const int* img_w, const int* crop_y,
+                    const int* crop_x, int n, int hr_size, int scale, const float* wtab, const int* xmin,
+                    const int* xsize, int kmax, float* hr_out, float* lr_out, float* tmp, fsr_stream_t stream);
 
 #ifdef __cplusplus
 }

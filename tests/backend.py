@@ -1,0 +1,48 @@
+"""Test helper: selects where the kernels under test run.
+
+  "emu" : the UNMODIFIED kernel sources compiled for the host by tests/emu (thread-per-lane emulation of
+          waves, MFMA, LDS) -- index arithmetic and numerics can be checked without a GPU (CPU suite);
+  "hip" : libfsr_hip.so on cuda:0 -- the product path (`-m gpu`).
+"""
+import importlib
+import os
+import sys
+
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tests", "emu"))
+
+L = importlib.import_module("fast-srgan_amd._lib")
+ops = importlib.import_module("fast-srgan_amd.ops")
+
+_emu_lib = None
+
+
+def select(kind):
+    """Returns the torch device for `kind` after routing the binding to the right library."""
+    global _emu_lib
+    if kind == "emu":
+        if _emu_lib is None:
+            from build_emu import build_emu
+            _emu_lib = build_emu()
+        L._install_for_testing(_emu_lib)
+        return torch.device("cpu")
+    L._install_for_testing(None)
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    L.lib()  # raises when libfsr_hip.so is missing: the GPU tests must exercise the HIP path
+    return torch.device("cuda:0")
+
+
+BACKENDS = ["emu", pytest.param("hip", marks=pytest.mark.gpu)]
+
+
+def tol(cd_name, f32=2e-4, bf16=3e-2):
+    return f32 if cd_name == "f32" else bf16
+
+
+def relerr(a, b):
+    a, b = a.detach().float().cpu(), b.detach().float().cpu()
+    return float((a - b).abs().max() / b.abs().max().clamp_min(1e-20))

@@ -1,0 +1,237 @@
+"""Operator-level parity: every kernel of libfsr_hip.so against the plain PyTorch fp32 op it replaces
+(torch CPU), through the same C ABI on both backends (see tests/backend.py)."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+from backend import BACKENDS, L, ops, relerr, select, tol
+from oracle import srgan_cpu as O
+
+
+def _nhwc(x, cd, dev):
+    return x.permute(0, 2, 3, 1).contiguous().to(cd.torch_dtype).to(dev)
+
+
+def _nchw(y):
+    return y.float().cpu().permute(0, 3, 1, 2)
+
+
+def leaf(t, dev=None):
+    t = t.detach().clone()
+    return (t if dev is None else t.to(dev)).requires_grad_(True)
+
+
+def _q(x, cd):  # quantise test inputs to the compute dtype so the fp32 reference sees the same numbers
+    return x.to(cd.torch_dtype).float()
+
+
+@pytest.fixture(params=BACKENDS)
+def dev(request):
+    return select(request.param)
+
+
+def _big(dev):
+    return dev.type == "cuda"
+
+
+@pytest.mark.parametrize("cdn", ["f32", "bf16"])
+@pytest.mark.parametrize("stride,cin,cout,ps", [(1, 32, 64, False), (2, 64, 64, False), (1, 32, 64, True), (1, 64, 3, False)])
+def test_conv_fwd_dgrad_wgrad(dev, cdn, stride, cin, cout, ps):
+    cd = ops.Compute(cdn)
+    torch.manual_seed(1)
+    n, h, w = (3, 37, 45) if _big(dev) else (1, 7, 19)
+    x = _q(torch.randn(n, cin, h, w), cd)
+    wt = _q(torch.randn(cout, cin, 3, 3) * 0.1, cd)
+    bias = torch.randn(cout) * 0.1
+    xd = _nhwc(x, cd, dev)
+    wpk = ops.packed_filter(cd, wt.to(dev), L.PACK_FWD_PS if ps else L.PACK_FWD, cin)
+    y, _, stats = ops.conv3x3_raw(cd, xd, wpk, cout, stride=stride, bias=bias.to(dev), pixel_shuffle=ps, want_stats=not ps,
+                                  out_f32=(cout == 3))
+    ref = F.conv2d(x, wt, bias, stride, 1)
+    refo = F.pixel_shuffle(ref, 2) if ps else ref
+    assert relerr(_nchw(y), refo) < tol(cdn, 1e-5, 1e-2)
+    if not ps:
+        s = stats.cpu()
+        assert relerr(s[..., 0], ref.sum((2, 3))) < tol(cdn, 1e-4, 1e-3)
+        assert relerr(s[..., 1], (ref * ref).sum((2, 3))) < tol(cdn, 1e-4, 1e-3)
+    # data gradient: conv on the transposed filter
+    g = _q(torch.randn_like(refo), cd)
+    xr = leaf(x)
+    wr = leaf(wt)
+    yr = F.conv2d(xr, wr, None, stride, 1)
+    yr = F.pixel_shuffle(yr, 2) if ps else yr
+    yr.backward(g)
+    cpad_out = cd.pad(cout)
+    gd = torch.zeros(n, g.shape[2], g.shape[3], (cpad_out // 4) if ps else cpad_out)
+    gd[..., :g.shape[1]] = g.permute(0, 2, 3, 1)
+    gd = gd.to(cd.torch_dtype).to(dev)
+    wpk_d = ops.packed_filter(cd, wt.to(dev), L.PACK_DGRAD_PS if ps else L.PACK_DGRAD, cpad_out)
+    dx, _, _ = ops.conv3x3_raw(cd, gd, wpk_d, cin, mode=L.CONV_DGRAD, out_hw=(h, w), stride=stride, in_pixel_shuffled=ps)
+    assert relerr(_nchw(dx), xr.grad) < tol(cdn, 1e-5, 1e-2)
+    dw = ops.conv3x3_wgrad_raw(cd, xd, gd, cout, cin, stride, dy_pixel_shuffled=ps)
+    assert relerr(dw, wr.grad) < tol(cdn, 2e-5, 2e-3)
+
+
+@pytest.mark.parametrize("cdn", ["f32", "bf16"])
+def test_conv_image_in_and_tanh_head_autograd(dev, cdn):
+    """First-layer conv on a strided NCHW image (with the VGG normalisation fused) and the tanh head."""
+    cd = ops.Compute(cdn)
+    torch.manual_seed(2)
+    n, h, w, nf = (2, 40, 56, 64) if _big(dev) else (1, 6, 17, 32)
+    img = (torch.rand(n, h, w, 3) * 2 - 1).permute(0, 3, 1, 2)          # NHWC-strided NCHW view
+    wt = _q(torch.randn(nf, 3, 3, 3) * 0.2, cd)
+    b = torch.randn(nf) * 0.1
+    mean, std = torch.tensor(O.VGG_MEAN).view(1, 3, 1, 1), torch.tensor(O.VGG_STD).view(1, 3, 1, 1)
+    cfg = ops.ConvCfg(cd, act=L.ACT_LEAKY, slope=0.2, image_in=True, in_scale=tuple(0.5 / s for s in O.VGG_STD),
+                      in_shift=tuple((0.5 - m) / s for m, s in zip(O.VGG_MEAN, O.VGG_STD)))
+    xi = leaf(img, dev)
+    wd, bd = leaf(wt, dev), leaf(b, dev)
+    y, _ = ops.conv3x3(xi, wd, bd, None, cfg)
+    xr, wr, br = leaf(img), leaf(wt), leaf(b)
+    xn = ((xr + 1) / 2 - mean) / std
+    xn = xn + (_q(xn.detach(), cd) - xn.detach())   # the kernel stores the normalised image in the compute dtype
+    yr = F.leaky_relu(F.conv2d(xn, wr, br, 1, 1), 0.2)
+    assert relerr(_nchw(y), yr) < tol(cdn, 1e-5, 2e-2)
+    g = _q(torch.randn_like(yr), cd)
+    y.backward(_nhwc(g, cd, dev))
+    yr.backward(g)
+    assert relerr(xi.grad, xr.grad) < tol(cdn, 1e-4, 2e-2)
+    assert relerr(wd.grad, wr.grad) < tol(cdn, 1e-4, 2e-2)
+    assert relerr(bd.grad, br.grad) < tol(cdn, 1e-4, 1e-2)
+    # tanh head: NHWC activation -> (N,3,H,W) float
+    x = _q(torch.randn(n, nf, h, w), cd)
+    wt = _q(torch.randn(3, nf, 3, 3) * 0.05, cd)
+    b = torch.randn(3) * 0.1
+    xd = leaf(_nhwc(x, cd, dev))
+    wd, bd = leaf(wt, dev), leaf(b, dev)
+    y, _ = ops.conv3x3(xd, wd, bd, None, ops.ConvCfg(cd, tanh_head=True))
+    xr, wr, br = leaf(x), leaf(wt), leaf(b)
+    yr = torch.tanh(F.conv2d(xr, wr, br, 1, 1))
+    assert y.shape == yr.shape and y.dtype == torch.float32
+    assert relerr(y, yr) < tol(cdn, 1e-5, 1e-5 if cdn == "f32" else 2e-2)
+    g = torch.randn_like(yr)
+    y.backward(g.to(dev))
+    yr.backward(g)
+    assert relerr(_nchw(xd.grad), xr.grad) < tol(cdn, 1e-4, 2e-2)
+    assert relerr(wd.grad, wr.grad) < tol(cdn, 1e-4, 2e-2)
+    assert relerr(bd.grad, br.grad) < tol(cdn, 1e-4, 1e-2)
+
+
+@pytest.mark.parametrize("cdn", ["f32", "bf16"])
+@pytest.mark.parametrize("act,slope", [(L.ACT_PRELU, -0.28), (L.ACT_LEAKY, 0.01), (L.ACT_NONE, 0.0)])
+def test_instnorm_act_residual_fwd_bwd(dev, cdn, act, slope):
+    cd = ops.Compute(cdn)
+    torch.manual_seed(3)
+    n, c, h, w = (3, 64, 24, 40) if _big(dev) else (2, 32, 5, 9)
+    x = _q(torch.randn(n, c, h, w) * 2 + 0.5, cd)
+    res = _q(torch.randn(n, c, h, w), cd)
+    a = torch.tensor([slope])
+    xd, rd = leaf(_nhwc(x, cd, dev)), leaf(_nhwc(res, cd, dev))
+    ad = leaf(a, dev)
+    stats = torch.stack([x.sum((2, 3)), (x * x).sum((2, 3))], dim=-1).to(dev)
+    prelu = ad if act == L.ACT_PRELU else None
+    y = ops.instnorm_act(xd, stats, rd, prelu, cd, act, slope)
+    xr, rr, ar = leaf(x), leaf(res), leaf(a)
+    z = O.instance_norm(xr)
+    z = O.prelu(z, ar) if act == L.ACT_PRELU else (F.leaky_relu(z, slope) if act == L.ACT_LEAKY else z)
+    yr = z + rr
+    assert relerr(_nchw(y), yr) < tol(cdn, 1e-5, 1e-2)
+    g = _q(torch.randn_like(yr), cd)
+    y.backward(_nhwc(g, cd, dev))
+    yr.backward(g)
+    assert relerr(_nchw(xd.grad), xr.grad) < tol(cdn, 1e-4, 2e-2)
+    assert relerr(_nchw(rd.grad), rr.grad) < 1e-6
+    if act == L.ACT_PRELU:
+        assert relerr(ad.grad, ar.grad) < tol(cdn, 1e-4, 1e-2)
+
+
+@pytest.mark.parametrize("cdn", ["f32", "bf16"])
+def test_conv_fused_prelu_pixelshuffle_autograd(dev, cdn):
+    """UpSamplingBlock (model.py:26-40) as one fused op, including a NEGATIVE PReLU slope."""
+    cd = ops.Compute(cdn)
+    torch.manual_seed(4)
+    n, nf, h, w = (2, 64, 20, 28) if _big(dev) else (1, 32, 5, 7)
+    x = _q(torch.randn(n, nf, h, w), cd)
+    wt = _q(torch.randn(nf * 4, nf, 3, 3) * 0.05, cd)
+    b, a = torch.randn(nf * 4) * 0.1, torch.tensor([-0.25])
+    xd = leaf(_nhwc(x, cd, dev))
+    wd, bd, ad = (leaf(t, dev) for t in (wt, b, a))
+    y, _ = ops.conv3x3(xd, wd, bd, ad, ops.ConvCfg(cd, act=L.ACT_PRELU, pixel_shuffle=True))
+    xr, wr, br, ar = (leaf(t) for t in (x, wt, b, a))
+    yr = O.prelu(O.pixel_shuffle2(F.conv2d(xr, wr, br, 1, 1)), ar)
+    assert relerr(_nchw(y), yr) < tol(cdn, 1e-5, 1e-2)
+    g = _q(torch.randn_like(yr), cd)
+    y.backward(_nhwc(g, cd, dev))
+    yr.backward(g)
+    assert relerr(_nchw(xd.grad), xr.grad) < tol(cdn, 1e-4, 2e-2)
+    assert relerr(wd.grad, wr.grad) < tol(cdn, 1e-4, 2e-2)
+    assert relerr(bd.grad, br.grad) < tol(cdn, 1e-4, 1e-2)
+    assert relerr(ad.grad, ar.grad) < tol(cdn, 1e-4, 2e-2)
+
+
+@pytest.mark.parametrize("cdn", ["f32", "bf16"])
+def test_maxpool_relu_conv1x1(dev, cdn):
+    cd = ops.Compute(cdn)
+    torch.manual_seed(5)
+    n, c, h, w = (2, 128, 16, 24) if _big(dev) else (1, 32, 4, 6)
+    x = _q(torch.relu(torch.randn(n, c, h, w)), cd)
+    xd = leaf(_nhwc(x, cd, dev))
+    y = ops.maxpool2(xd, cd)
+    xr = leaf(x)
+    yr = F.max_pool2d(xr, 2, 2)
+    assert torch.equal(_nchw(y), yr.detach())
+    g = _q(torch.randn_like(yr), cd)
+    y.backward(_nhwc(g, cd, dev))
+    yr.backward(g)
+    nz = (x > 0)  # ties only happen at ReLU zeros, where the ReLU behind the pool kills the gradient anyway
+    assert torch.equal(_nchw(xd.grad)[nz], xr.grad[nz])
+    # 1x1 conv to one logit
+    wt, b = torch.randn(1, c, 1, 1) * 0.1, torch.randn(1)
+    xd2 = leaf(_nhwc(x, cd, dev))
+    wd, bd = leaf(wt, dev), leaf(b, dev)
+    lg = ops.conv1x1_to_logits(xd2, wd, bd, cd)
+    xr, wr, br = leaf(x), leaf(wt), leaf(b)
+    lr = F.conv2d(xr, wr, br)
+    assert relerr(lg, lr) < 1e-5
+    g = torch.randn_like(lr)
+    lg.backward(g.to(dev))
+    lr.backward(g)
+    assert relerr(_nchw(xd2.grad), xr.grad) < tol(cdn, 1e-5, 1e-2)
+    assert relerr(wd.grad, wr.grad) < 1e-4
+    assert relerr(bd.grad, br.grad) < 1e-4
+
+
+def test_losses_and_adamw(dev):
+    torch.manual_seed(6)
+    n = 40000 if _big(dev) else 3000
+    x, t = torch.randn(n) * 3, torch.rand(n)
+    xd = leaf(x, dev)
+    loss = ops.bce_with_logits(xd, t.to(dev))
+    xr = leaf(x)
+    lr = F.binary_cross_entropy_with_logits(xr, t)
+    assert abs(loss.item() - lr.item()) < 1e-5 * abs(lr.item())
+    (0.05 * loss).backward()
+    (0.05 * lr).backward()
+    assert relerr(xd.grad, xr.grad) < 1e-5
+    for dt, tl in ((torch.float32, 1e-5), (torch.bfloat16, 1e-2)):
+        a, b = (torch.randn(n) * 1.5).to(dt), torch.randn(n).to(dt)
+        ad = leaf(a, dev)
+        l2 = ops.smooth_l1(ad, b.to(dev))
+        ar = leaf(a.float())
+        l2r = F.smooth_l1_loss(ar, b.float())
+        assert abs(l2.item() - l2r.item()) < 1e-5 * abs(l2r.item())
+        (0.5 * l2).backward()
+        (0.5 * l2r).backward()
+        assert relerr(ad.grad, ar.grad) < tl
+    # AdamW: three steps against torch.optim.AdamW
+    p = torch.randn(n)
+    ref = torch.nn.Parameter(p.clone())
+    opt = torch.optim.AdamW([ref], lr=1e-4)
+    pd, m, v = p.to(dev), torch.zeros(n, device=dev), torch.zeros(n, device=dev)
+    for step in range(1, 4):
+        g = torch.randn(n) * (10.0 ** -step)
+        ref.grad = g.clone()
+        opt.step()
+        L.check(L.lib().fsr_adamw_step(pd.data_ptr(), g.to(dev).data_ptr(), m.data_ptr(), v.data_ptr(), n, 1e-4, 0.9, 0.999,
+                                       1e-8, 0.01, step, ops._stream()))
+    assert (pd.cpu() - ref.detach()).abs().max() < 2e-7
