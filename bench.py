@@ -1,0 +1,190 @@
+"""Benchmark of the Fast-SRGAN hot path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+A "step" is one full GAN training iteration (/root/reference/trainer.py:171-196: D step + G step with the VGG
+perceptual loss and both AdamW updates) over one synthetic batch that is already resident in HBM
+(BASELINE.json configs[2]: 8 residual blocks / 64 filters, batch 32 per GPU, 96x96 -> 384x384, bf16 MFMA with
+f32 accumulation, random-init weights, kaiming-normal VGG19 stand-in).  N > 1 shards by batch (weak scaling):
+one process per GPU, two RCCL gradient all-reduces per step.  Rank 0 prints ONE JSON line.
+
+Extra keys of that line:
+  roofline      the dominant kernel (the implicit-GEMM 3x3 convolution, forward + data-gradient launches):
+                algorithmic FLOPs per launch / average launch duration measured with HIP events on the launch
+                stream during an instrumented step, against the dense bf16 MFMA peak (2.5 PFLOP/s);
+  cpu_baseline  the oracle's CPU restatement of the same iteration, timed on the host cores (N=1, rank 0);
+  inference     generator-only FPS at 90x160 and 180x320 (BASELINE.json configs[1]), batch 1 and batch 32.
+"""
+import argparse
+import importlib
+import json
+import os
+import sys
+import time
+import types
+import warnings
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+MFMA_PEAK_TFLOPS = {"bf16": 2500.0, "f32": 157.3}   # /opt/skills/guides/MI355X_MICROARCH.md, dense
+STEP_GFLOP_PER_IMAGE = 686.71                         # BASELINE.md section 2, as the reference graph executes it
+
+
+def ns(**k):
+    return types.SimpleNamespace(**k)
+
+
+def make_config(batch, dtype, device):
+    return ns(experiment=ns(name="bench", seed=1234), generator=ns(n_filters=64, n_layers=8),
+              discriminator=ns(n_filters=64, n_layers=7),
+              training=ns(compiled=False, device=device, log_iter=10 ** 9, checkpoint_iter=10 ** 9, generator_lr=1e-4,
+                          discriminator_lr=1e-4, batch_size=batch, compute_dtype=dtype))
+
+
+def conv_profile(ops, fn):
+    """Runs fn() with every conv3x3 forward/dgrad launch bracketed by HIP events on the launch stream.
+    Returns (launches, total_ms, total_flops)."""
+    rec = []
+    ops.PROFILE_CONV = rec
+    try:
+        fn()
+        torch.cuda.synchronize()
+    finally:
+        ops.PROFILE_CONV = None
+    ms = sum(s.elapsed_time(e) for s, e, _ in rec)
+    return len(rec), ms, sum(f for _, _, f in rec)
+
+
+def cpu_baseline(seconds_budget=25.0):
+    """The oracle (CPU restatement of trainer.py:171-196, fp32, torch CPU kernels) on a bounded sample of the same
+    workload: full-size networks, 96 -> 384, batch 2, ONE iteration (the survey measured ~2.5 s per image on 8 cores)."""
+    from oracle import srgan_cpu as O
+    pkg = importlib.import_module("fast-srgan_amd")
+    torch.manual_seed(0)
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        G = pkg.Generator(ns(n_filters=64, n_layers=8))
+        Dm = pkg.Discriminator(ns(n_filters=64, n_layers=7))
+    g_sd = {k: v.detach().clone() for k, v in G.state_dict().items()}
+    d_sd = {k: v.detach().clone() for k, v in Dm.state_dict().items()}
+    v_sd = O.vgg_standin_state_dict(1234, 1)
+    b = 2
+    lr, hr = torch.rand(b, 3, 96, 96) * 2 - 1, torch.rand(b, 3, 384, 384) * 2 - 1
+    noise = [torch.rand(b, 1, 24, 24) for _ in range(3)]
+    t0 = time.perf_counter()
+    O.train_step(g_sd, d_sd, v_sd, lr, hr, noise, {}, {})
+    dt = time.perf_counter() - t0
+    return {"value": round(b / dt, 4), "unit": "images/s", "cores": cores, "kind": "port",
+            "sample": "1 full GAN iteration (oracle/srgan_cpu.train_step), batch %d, 96->384, fp32, %.1f s" % (b, dt)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=32, help="per-GPU batch")
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-inference", action="store_true")
+    args = ap.parse_args()
+
+    pkg = importlib.import_module("fast-srgan_amd")
+    ops = importlib.import_module("fast-srgan_amd.ops")
+    dist_mod = importlib.import_module("fast-srgan_amd.distributed")
+    rank, world, local_rank = dist_mod.init_from_env()
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (no GPU visible)")
+    torch.cuda.set_device(local_rank)
+    device = "cuda:%d" % local_rank
+    pkg._lib.lib()  # fail loudly if the HIP extension is missing
+    if world != args.gpus:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run)" % (args.gpus, world))
+
+    torch.manual_seed(1234)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        trainer = pkg.Trainer(make_config(args.batch, args.dtype, device))
+    torch.manual_seed(100 + rank)
+    B = args.batch
+    lr = torch.rand(B, 3, 96, 96, device=device) * 2 - 1
+    hr = torch.rand(B, 3, 384, 384, device=device) * 2 - 1
+
+    def barrier():
+        if world > 1:
+            torch.distributed.barrier()
+
+    for _ in range(args.warmup):
+        trainer.train_step(lr, hr)
+    torch.cuda.synchronize()
+    barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        trainer.train_step(lr, hr)
+    torch.cuda.synchronize()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], device=device, dtype=torch.float64)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        elapsed = float(t.item())
+    ms_per_step = elapsed / args.steps * 1e3
+    value = world * B * args.steps / elapsed
+
+    # ---- roofline of the dominant kernel: one instrumented iteration (outside the timed region)
+    launches, conv_ms, conv_flops = conv_profile(ops, lambda: trainer.train_step(lr, hr))
+    achieved = conv_flops / (conv_ms * 1e-3) / 1e12 if conv_ms > 0 else 0.0
+    peak = MFMA_PEAK_TFLOPS[args.dtype]
+    roofline = {"bound": "mfma", "kernel": "conv_igemm_kernel (3x3 conv forward + data-gradient launches)",
+                "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(achieved / peak, 4),
+                "traffic": None, "launches_per_step": launches,
+                "avg_launch_us": round(conv_ms * 1e3 / max(launches, 1), 2),
+                "algorithmic_gflop_per_launch": round(conv_flops / max(launches, 1) / 1e9, 3),
+                "share_of_step_time": round(conv_ms / ms_per_step, 3)}
+
+    out = {"metric": "SR train-step images/sec (96->384 4x, full GAN step: G+D+VGG perceptual loss)",
+           "value": round(value, 3), "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+           "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+           "dtype": args.dtype, "data": "synthetic (uniform [-1,1) LR/HR tensors resident in HBM; random-init G/D, kaiming-normal VGG19 stand-in)",
+           "config": {"workload": "BASELINE configs[2]: full GAN training step, 8 residual blocks / 64 filters, 96x96->384x384",
+                      "per_gpu_batch": B, "global_batch": B * world, "parallelism": "dp%d" % world},
+           "step_tflops_equiv": round(value * STEP_GFLOP_PER_IMAGE / 1e3, 2),
+           "roofline": roofline}
+
+    if rank == 0 and not args.no_inference:
+        inf = {}
+        with torch.no_grad():
+            G = trainer.generator.eval()
+            for name, (h, w) in (("90x160", (90, 160)), ("180x320", (180, 320))):
+                for bsz in (1, 32):
+                    x = torch.rand(bsz, 3, h, w, device=device) * 2 - 1
+                    for _ in range(3):
+                        G(x)
+                    torch.cuda.synchronize()
+                    iters = 20 if bsz == 1 else 5
+                    t0 = time.perf_counter()
+                    for _ in range(iters):
+                        G(x)
+                    torch.cuda.synchronize()
+                    inf["fps_%s_b%d" % (name, bsz)] = round(bsz * iters / (time.perf_counter() - t0), 2)
+        out["inference"] = inf
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline()
+    if world > 1:
+        torch.distributed.barrier()
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

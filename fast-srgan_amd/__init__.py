@@ -4,6 +4,11 @@ The directory name carries a hyphen (it mirrors the upstream repository name), s
 `importlib.import_module("fast-srgan_amd")` or through the `fast_srgan_amd` alias module at the repo root.
 """
 from . import _lib  # noqa: F401
+from .config import load_config  # noqa: F401
+from .dataloader import DeviceBatchLoader, NumpyImagesDataset  # noqa: F401
 from .model import VGG19, Discriminator, Generator  # noqa: F401
+from .optim import ArenaAdamW  # noqa: F401
+from .trainer import Trainer  # noqa: F401
 
-__all__ = ["Generator", "Discriminator", "VGG19"]
+__all__ = ["Generator", "Discriminator", "VGG19", "Trainer", "NumpyImagesDataset", "DeviceBatchLoader", "ArenaAdamW",
+           "load_config"]

@@ -183,9 +183,9 @@ __global__ __launch_bounds__(256) void conv1x1_c1_bwd_kernel(const float* __rest
 
 __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
                                                     float* __restrict__ v, long long count, float lr, float b1, float b2,
-                                                    float eps, float wd, float bc1, float rsqrt_bc2) {
+                                                    float eps, float wd, float bc1, float rsqrt_bc2, float gscale) {
   for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < count; i += (long long)gridDim.x * 256) {
-    const float gi = g[i];
+    const float gi = g[i] * gscale;
     float pi = p[i] * (1.f - lr * wd);
     const float mi = m[i] + (gi - m[i]) * (1.f - b1);   // torch: exp_avg.lerp_(grad, 1 - beta1)
     const float vi = v[i] * b2 + (1.f - b2) * gi * gi;
@@ -288,13 +288,14 @@ extern "C" int fsr_conv1x1_c1_bwd(int dtype, const float* g, const void* x, cons
 }
 
 extern "C" int fsr_adamw_step(float* p, const float* g, float* m, float* v, long long count, float lr, float beta1,
-                              float beta2, float eps, float weight_decay, int step, fsr_stream_t stream_) {
+                              float beta2, float eps, float weight_decay, int step, float grad_scale,
+                              fsr_stream_t stream_) {
   if (!p || !g || !m || !v || count <= 0 || step < 1) return fsr_fail(-1, "fsr_adamw_step: bad argument");
   const float bc1 = 1.f - powf(beta1, (float)step);
   const float bc2 = 1.f - powf(beta2, (float)step);
   long long blocks = (count + 256 * 4 - 1) / (256 * 4);
   if (blocks > 2048) blocks = 2048;
   hipLaunchKernelGGL(adamw_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream_, p, g, m, v, count, lr, beta1,
-                     beta2, eps, weight_decay, bc1, 1.f / sqrtf(bc2));
+                     beta2, eps, weight_decay, bc1, 1.f / sqrtf(bc2), grad_scale);
   return fsr_check_launch("adamw_kernel");
 }

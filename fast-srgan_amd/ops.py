@@ -51,7 +51,7 @@ _pack_cache = {}
 def packed_filter(cd, weight, mode, k_pad):
     """[9][rows_pad][k_pad] image of an OIHW float weight (fsr_pack_conv3x3), cached per weight version."""
     key = (id(weight), mode, cd.code, k_pad)
-    ver = weight._version
+    ver = (weight._version, getattr(weight, "_fsr_epoch", 0))
     hit = _pack_cache.get(key)
     if hit is not None and hit[0] == ver and hit[2] == weight.data_ptr():
         return hit[1]
@@ -73,6 +73,9 @@ def packed_filter(cd, weight, mode, k_pad):
 
 _ws = {}
 
+# bench.py sets this to a list to collect (start_event, end_event, algorithmic_flops) per conv launch
+PROFILE_CONV = None
+
 
 def _workspace(nbytes, device):
     buf = _ws.get(device)
@@ -85,7 +88,7 @@ def _workspace(nbytes, device):
 # ---------------------------------------------------------------------------------- raw launches
 def conv3x3_raw(cd, x, wpk, cout, *, mode=L.CONV_FWD, out_hw=None, stride=1, bias=None, act=L.ACT_NONE, slope=0.0,
                 prelu=None, oscale=None, pixel_shuffle=False, in_pixel_shuffled=False, out_f32=False, want_stats=False,
-                want_preact=False):
+                want_preact=False, alg_k=None):
     """One fsr_conv3x3 launch.  x: (N,IH,IW,Cin) [or its depth-to-space form when in_pixel_shuffled]."""
     _check_dev(x)
     n = x.shape[0]
@@ -104,12 +107,21 @@ def conv3x3_raw(cd, x, wpk, cout, *, mode=L.CONV_FWD, out_hw=None, stride=1, bia
     stats = torch.zeros((n, cout, 2), dtype=torch.float32, device=x.device) if want_stats else None
     d = L.ConvDesc(cd.code, mode, n, ih, iw, cin, oh, ow, cout, stride, act, float(slope), int(pixel_shuffle),
                    int(in_pixel_shuffled), int(out_f32))
+    prof = PROFILE_CONV
+    if prof is not None:
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        ev0.record()
     L.check(L.lib().fsr_conv3x3(ctypes.byref(d), _p(x), _p(wpk), _p(bias), _p(prelu), _p(oscale), _p(out), _p(pre),
                                 _p(stats), _stream()), "fsr_conv3x3")
+    if prof is not None:
+        ev1.record()
+        k = cin if alg_k is None else alg_k
+        pix = oh * ow if mode == L.CONV_FWD else ih * iw      # dgrad: one MAC per forward MAC
+        prof.append((ev0, ev1, 2.0 * n * pix * cout * k * 9))
     return out, pre, stats
 
 
-def conv3x3_wgrad_raw(cd, x, dy, cout, cin, stride, dy_pixel_shuffled=False):
+def conv3x3_wgrad_raw(cd, x, dy, cout, cin, stride, dy_pixel_shuffled=False, out=None):
     """OIHW float weight gradient.  x (N,IH,IW,CinPad); dy (N,OH,OW,CoutPad) or its depth-to-space form."""
     n, ih, iw, cin_pad = x.shape
     if dy_pixel_shuffled:
@@ -121,7 +133,7 @@ def conv3x3_wgrad_raw(cd, x, dy, cout, cin, stride, dy_pixel_shuffled=False):
     if need == 0:
         L.check(-2, "fsr_conv3x3_wgrad_workspace")
     ws = _workspace(need, x.device)
-    dw = torch.zeros((cout, cin, 3, 3), dtype=torch.float32, device=x.device)
+    dw = out if out is not None else torch.zeros((cout, cin, 3, 3), dtype=torch.float32, device=x.device)
     L.check(L.lib().fsr_conv3x3_wgrad(ctypes.byref(d), _p(x), _p(dy), _p(dw), _p(ws), _stream()), "fsr_conv3x3_wgrad")
     return dw
 
@@ -179,7 +191,7 @@ class Conv3x3Fn(torch.autograd.Function):
         b32 = bias if bias is None or bias.dtype == torch.float32 else bias.float()
         out, pre, stats = conv3x3_raw(cd, xin, wpk, cout, stride=cfg.stride, bias=b32, act=act, slope=cfg.slope,
                                       prelu=prelu, pixel_shuffle=cfg.pixel_shuffle, out_f32=cfg.tanh_head,
-                                      want_stats=cfg.stats, want_preact=want_pre)
+                                      want_stats=cfg.stats, want_preact=want_pre, alg_k=cin)
         ctx.cfg = cfg
         ctx.dims = (cout, cin, tuple(xin.shape))
         ctx.has_bias = bias is not None
@@ -229,16 +241,19 @@ class Conv3x3Fn(torch.autograd.Function):
                 wpk = packed_filter(cd, weight, L.PACK_DGRAD, dz.shape[3] * (4 if cfg.pixel_shuffle else 1))
                 osc = torch.tensor(cfg.in_scale, dtype=torch.float32, device=xin.device) if tuple(cfg.in_scale) != (1.0, 1.0, 1.0) else None
                 dx, _, _ = conv3x3_raw(cd, dz, wpk, 3, mode=L.CONV_DGRAD, out_hw=(ih, iw), stride=cfg.stride, oscale=osc,
-                                       out_f32=True, in_pixel_shuffled=cfg.pixel_shuffle)
+                                       out_f32=True, in_pixel_shuffled=cfg.pixel_shuffle, alg_k=cout)
                 dx = dx.permute(0, 3, 1, 2)
             else:
                 kpad = dz.shape[3] * (4 if cfg.pixel_shuffle else 1)
                 wpk = packed_filter(cd, weight, L.PACK_DGRAD_PS if cfg.pixel_shuffle else L.PACK_DGRAD, kpad)
                 dx, _, _ = conv3x3_raw(cd, dz, wpk, cin_pad, mode=L.CONV_DGRAD, out_hw=(ih, iw), stride=cfg.stride,
-                                       in_pixel_shuffled=cfg.pixel_shuffle)
+                                       in_pixel_shuffled=cfg.pixel_shuffle, alg_k=cout)
         dw = None
         if ctx.needs_input_grad[1]:
-            dw = conv3x3_wgrad_raw(cd, xin, dz, cout, cin, cfg.stride, dy_pixel_shuffled=cfg.pixel_shuffle)
+            arena = getattr(weight, "_fsr_grad", None)  # optim.ArenaAdamW: accumulate in place, hand autograd nothing
+            dw = conv3x3_wgrad_raw(cd, xin, dz, cout, cin, cfg.stride, dy_pixel_shuffled=cfg.pixel_shuffle, out=arena)
+            if arena is not None:
+                dw = None
         db = dbias if (ctx.has_bias and ctx.needs_input_grad[2]) else None
         dp = dprelu if (dprelu is not None and ctx.needs_input_grad[3]) else None
         return dx, dw, db, dp, None

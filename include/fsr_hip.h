@@ -180,9 +180,10 @@ int fsr_smooth_l1_bwd(int dtype, const void* a, const void* b, const float* gsca
                       fsr_stream_t stream);
 
 /* ------------------------------------------------------------------ AdamW (trainer.py:33-38, torch defaults)
- * One fused step over a flat float parameter arena: p *= 1 - lr*wd; m, v updated; p -= lr/bc1 * m / (sqrt(v)/sqrt(bc2) + eps). */
+ * One fused step over a flat float parameter arena: g' = g*grad_scale (1/world_size after a SUM
+ * all-reduce); p *= 1 - lr*wd; m, v updated; p -= lr/bc1 * m / (sqrt(v)/sqrt(bc2) + eps). */
 int fsr_adamw_step(float* p, const float* g, float* m, float* v, long long count, float lr, float beta1, float beta2,
-                   float eps, float weight_decay, int step, fsr_stream_t stream);
+                   float eps, float weight_decay, int step, float grad_scale, fsr_stream_t stream);
 
 /* ------------------------------------------------------------------ crop + antialiased bicubic down-scale (dataloader.py:24-38)
  * For each of `n` samples: crop hr_size x hr_size at (crop_y[i], crop_x[i]) from the uint8 CHW image

@@ -31,7 +31,7 @@ import torch.nn.functional as F
 
 from oracle import srgan_cpu as O
 
-VGG_WIDTH_DIV = 8  # golden VGG stand-in: 8..64 channels instead of 64..512 (fixture size)
+VGG_WIDTH_DIV = 4  # golden VGG stand-in: 16..128 channels instead of 64..512 (fixture size)
 
 
 def install_stubs(vgg_seed=1234, vgg_width_div=VGG_WIDTH_DIV):
@@ -193,6 +193,35 @@ def main():
     r = torch.randn_like(y)
     (y * r).sum().backward()
     np.savez(os.path.join(HERE, "vgg_small.npz"), x=x.detach().numpy(), r=r.numpy(), y=y.detach().numpy(),
+             dx=x.grad.numpy(), width_div=VGG_WIDTH_DIV, seed=1234,
+             w0_sum=np.float64(V.vgg[0].weight.double().sum().item()))
+
+    # ---- 4b. tiny variants of 2-4 for the CPU suite (the host emulator runs them in seconds)
+    torch.manual_seed(13)
+    Gt = ref_model.Generator(ns(n_filters=16, n_layers=1))
+    with torch.no_grad():
+        Gt.stem[0].relu1.weight.fill_(-0.28)
+    x = (torch.rand(1, 3, 5, 6) * 2 - 1).requires_grad_(True)
+    y = Gt(x)
+    r = torch.randn_like(y)
+    (y * r).sum().backward()
+    np.savez(os.path.join(HERE, "g_tiny.npz"), x=x.detach().numpy(), r=r.numpy(), y=y.detach().numpy(),
+             dx=x.grad.numpy(), **sd_np(Gt.state_dict(), "sd."),
+             **{"grad." + k: p.grad.numpy() for k, p in Gt.named_parameters()})
+    torch.manual_seed(14)
+    Dt = ref_model.Discriminator(ns(n_filters=16, n_layers=7))
+    x = (torch.rand(1, 3, 32, 16) * 2 - 1).requires_grad_(True)
+    y = Dt(x)
+    r = torch.randn_like(y)
+    (y * r).sum().backward()
+    np.savez(os.path.join(HERE, "d_tiny.npz"), x=x.detach().numpy(), r=r.numpy(), y=y.detach().numpy(),
+             dx=x.grad.numpy(), **sd_np(Dt.state_dict(), "sd."),
+             **{"grad." + k: p.grad.numpy() for k, p in Dt.named_parameters()})
+    x = (torch.rand(1, 3, 16, 16) * 2 - 1).requires_grad_(True)
+    y = V(x)
+    r = torch.randn_like(y)
+    (y * r).sum().backward()
+    np.savez(os.path.join(HERE, "vgg_tiny.npz"), x=x.detach().numpy(), r=r.numpy(), y=y.detach().numpy(),
              dx=x.grad.numpy(), width_div=VGG_WIDTH_DIV, seed=1234,
              w0_sum=np.float64(V.vgg[0].weight.double().sum().item()))
 

@@ -1,0 +1,145 @@
+"""Module-level parity: the drop-in Generator / Discriminator / VGG19 against the golden outputs of the
+reference's own modules (tests/golden, made by make_golden.py) and against the oracle restatement."""
+import os
+import types
+import warnings
+
+import pytest
+import torch
+
+from backend import BACKENDS, relerr, select
+from conftest import load_npz, sd_from
+from oracle import srgan_cpu as O
+
+
+@pytest.fixture(params=BACKENDS)
+def dev(request):
+    # whole networks on the thread-per-lane emulator take minutes: opt in with FSR_EMU_MODULES=1
+    if request.param == "emu" and os.environ.get("FSR_EMU_MODULES") != "1":
+        pytest.skip("set FSR_EMU_MODULES=1 to run whole modules on the host emulator (about 4 minutes)")
+    return select(request.param)
+
+
+def _fx(dev, stem):
+    """The host emulator gets the tiny fixture, the GPU the small one."""
+    return load_npz(stem + ("_small.npz" if dev.type == "cuda" else "_tiny.npz"))
+
+
+def ns(**k):
+    return types.SimpleNamespace(**k)
+
+
+def _grad_check(mod, ref_grads, tol_w):
+    for k, p in mod.named_parameters():
+        if p.requires_grad:
+            assert p.grad is not None, k
+            assert relerr(p.grad, ref_grads[k]) < tol_w, k
+
+
+def test_generator_small_golden_f32(dev, pkg):
+    """fp32 mode vs the reference Generator (n_filters=16, 2 blocks): outputs and every gradient, 1e-3 relative."""
+    z = _fx(dev, "g")
+    G = pkg.Generator(ns(n_filters=16, n_layers=2 if dev.type == "cuda" else 1), compute_dtype="f32")
+    G.load_state_dict(sd_from(z, "sd."))
+    G.to(dev)
+    x = torch.from_numpy(z["x"]).to(dev).requires_grad_(True)
+    y = G(x)
+    assert y.shape == tuple(z["y"].shape) and y.dtype == torch.float32
+    assert relerr(y, torch.from_numpy(z["y"])) < 1e-3
+    (y * torch.from_numpy(z["r"]).to(dev)).sum().backward()
+    assert relerr(x.grad, torch.from_numpy(z["dx"])) < 1e-3
+    _grad_check(G, {k[5:]: torch.from_numpy(z[k]) for k in z.files if k.startswith("grad.")}, 1e-3)
+
+
+def test_discriminator_small_golden_f32(dev, pkg):
+    z = _fx(dev, "d")
+    D = pkg.Discriminator(ns(n_filters=16, n_layers=7), compute_dtype="f32")
+    D.load_state_dict(sd_from(z, "sd."))
+    D.to(dev)
+    x = torch.from_numpy(z["x"]).to(dev).requires_grad_(True)
+    y = D(x)
+    assert y.shape == tuple(z["y"].shape) and y.dtype == torch.float32
+    assert relerr(y, torch.from_numpy(z["y"])) < 1e-3
+    (y * torch.from_numpy(z["r"]).to(dev)).sum().backward()
+    assert relerr(x.grad, torch.from_numpy(z["dx"])) < 1e-3
+    _grad_check(D, {k[5:]: torch.from_numpy(z[k]) for k in z.files if k.startswith("grad.")}, 1e-3)
+
+
+def test_vgg_small_golden_f32(dev, pkg):
+    z = _fx(dev, "vgg")
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        V = pkg.VGG19(compute_dtype="f32", width_div=int(z["width_div"]), seed=int(z["seed"]))
+    assert abs(V.vgg[0].weight.double().sum().item() - float(z["w0_sum"])) < 1e-9
+    assert all(not p.requires_grad for p in V.parameters()) and len(V.state_dict()) == 32
+    V.to(dev)
+    x = torch.from_numpy(z["x"]).to(dev).requires_grad_(True)
+    y = V(x)
+    assert y.shape == tuple(z["y"].shape)
+    assert relerr(y, torch.from_numpy(z["y"])) < 1e-3
+    (y.float() * torch.from_numpy(z["r"]).to(dev)).sum().backward()
+    assert relerr(x.grad, torch.from_numpy(z["dx"])) < 1e-3
+
+
+@pytest.mark.gpu
+def test_generator_shipped_weights_kat_gpu(pkg):
+    """models/model.pt (36 tensors) loads unchanged; fp32 mode reproduces the reference's known answer."""
+    dev = select("hip")
+    z = load_npz("g_model_pt.npz")
+    sd = sd_from(z, "sd.")
+    G = pkg.Generator(ns(n_filters=64, n_layers=8), compute_dtype="f32")
+    assert G.load_state_dict(sd).missing_keys == []
+    G.to(dev).eval()
+    with torch.no_grad():
+        ys = G(torch.from_numpy(z["x_small"]).to(dev))
+        assert relerr(ys, torch.from_numpy(z["y_small"])) < 1e-3
+        torch.manual_seed(0)
+        x = torch.rand(4, 3, 96, 96) * 2 - 1
+        y = G(x.to(dev)).cpu()
+    assert y.shape == (4, 3, 384, 384)
+    assert abs(y.double().sum().item() - float(z["y_sum"])) < 1e-3 * abs(float(z["y_sum"]))
+    assert relerr(y[:, :, ::16, ::16], torch.from_numpy(z["y_strided"])) < 1e-3
+    assert (y[0, 0, 0, :4] - torch.tensor([-0.37453923, -0.60736173, -0.31874713, 0.24013290])).abs().max() < 1e-3
+    # per-sample independence: a sample's result does not depend on its batch neighbours
+    with torch.no_grad():
+        y1 = G(x[1:2].to(dev)).cpu()
+    assert relerr(y1, y[1:2]) < 1e-5
+    # bf16 mode on the same weights stays close to fp32 (reported, loose gate: 18 stacked convs + IN)
+    Gb = pkg.Generator(ns(n_filters=64, n_layers=8), compute_dtype="bf16")
+    Gb.load_state_dict(sd)
+    Gb.to(dev).eval()
+    with torch.no_grad():
+        yb = Gb(x.to(dev)).cpu()
+    assert (yb - y).abs().mean() < 0.02
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("cdn", ["f32", "bf16"])
+def test_full_size_modules_vs_oracle_gpu(pkg, cdn):
+    """Full-width G and D (64 filters) at a moderate size against the CPU oracle: forward and gradients."""
+    dev = select("hip")
+    torch.manual_seed(3)
+    G = pkg.Generator(ns(n_filters=64, n_layers=2), compute_dtype=cdn)
+    D = pkg.Discriminator(ns(n_filters=64, n_layers=7), compute_dtype=cdn)
+    gsd = {k: v.clone() for k, v in G.state_dict().items()}
+    dsd = {k: v.clone() for k, v in D.state_dict().items()}
+    G.to(dev), D.to(dev)
+    x = torch.rand(2, 3, 24, 40) * 2 - 1
+    xd = x.to(dev)
+    sr = G(xd)
+    logits = D(sr)
+    r = torch.randn(logits.shape)
+    (logits * r.to(dev)).sum().backward()
+    gp = {k: v.clone().requires_grad_(True) for k, v in gsd.items()}
+    dp = {k: v.clone().requires_grad_(True) for k, v in dsd.items()}
+    sr_ref = O.generator_forward(gp, x)
+    lg_ref = O.discriminator_forward(dp, sr_ref)
+    grads = torch.autograd.grad((lg_ref * r).sum(), list(gp.values()) + list(dp.values()))
+    ref = dict(zip([("g", k) for k in gp] + [("d", k) for k in dp], grads))
+    t_out, t_grad = (1e-3, 2e-3) if cdn == "f32" else (6e-2, 0.25)
+    assert relerr(sr, sr_ref) < t_out
+    assert relerr(logits, lg_ref) < t_out * 2
+    for k, p in G.named_parameters():
+        assert relerr(p.grad, ref[("g", k)]) < t_grad, ("g", k)
+    for k, p in D.named_parameters():
+        assert relerr(p.grad, ref[("d", k)]) < t_grad, ("d", k)

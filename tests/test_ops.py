@@ -233,5 +233,5 @@ def test_losses_and_adamw(dev):
         ref.grad = g.clone()
         opt.step()
         L.check(L.lib().fsr_adamw_step(pd.data_ptr(), g.to(dev).data_ptr(), m.data_ptr(), v.data_ptr(), n, 1e-4, 0.9, 0.999,
-                                       1e-8, 0.01, step, ops._stream()))
+                                       1e-8, 0.01, step, 1.0, ops._stream()))
     assert (pd.cpu() - ref.detach()).abs().max() < 2e-7

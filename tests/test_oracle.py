@@ -64,7 +64,7 @@ def test_vgg_wrapper_forward_backward():
     assert abs(sd["vgg.0.weight"].double().sum().item() - float(z["w0_sum"])) < 1e-9
     x = torch.from_numpy(z["x"]).requires_grad_(True)
     y = O.vgg_forward(sd, x)
-    assert y.shape == (2, 512 // int(z["width_div"]), 2, 3)
+    assert y.shape == (2, 512 // int(z["width_div"]), 2, 3) and int(z["width_div"]) == 4
     assert rel(y.detach(), torch.from_numpy(z["y"])) < 1e-5
     (dx,) = torch.autograd.grad((y * torch.from_numpy(z["r"])).sum(), [x])
     assert rel(dx, torch.from_numpy(z["dx"])) < 1e-4

@@ -1,0 +1,159 @@
+"""Step-level parity (trainer.py:171-196) and the host logic around it."""
+import os
+import random
+import types
+import warnings
+
+import numpy as np
+import pytest
+import torch
+
+from backend import L, ops, relerr, select
+from conftest import load_npz, sd_from
+from oracle import srgan_cpu as O
+
+
+def ns(**k):
+    return types.SimpleNamespace(**k)
+
+
+def _cfg(device, cdt, nf=16, n_layers=1):
+    return ns(experiment=ns(name="t", seed=1234), generator=ns(n_filters=nf, n_layers=n_layers),
+              discriminator=ns(n_filters=nf, n_layers=7),
+              training=ns(compiled=False, device=device, log_iter=1, checkpoint_iter=10 ** 9, generator_lr=1e-4,
+                          discriminator_lr=1e-4, batch_size=2, compute_dtype=cdt))
+
+
+def _trainer(pkg, dev, cdt, z=None, nf=16, n_layers=1, width_div=4):
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        V = pkg.VGG19(compute_dtype=cdt, width_div=width_div, seed=1234)
+        T = pkg.Trainer(_cfg(str(dev), cdt, nf, n_layers), perceptual_network=V)
+    if z is not None:
+        T.generator.load_state_dict(sd_from(z, "g0."))
+        T.discriminator.load_state_dict(sd_from(z, "d0."))
+    return T
+
+
+@pytest.mark.gpu
+def test_two_train_steps_match_reference_trainer_f32(pkg):
+    """Two iterations of the REFERENCE's Trainer.train (golden, recorded label noise) vs Trainer.train_step on the
+    HIP path in exact-f32 MFMA mode: the four logged losses within 1e-3 relative, parameter updates in the mean."""
+    dev = select("hip")
+    z = load_npz("train_steps.npz")
+    T = _trainer(pkg, dev, "f32", z, width_div=int(z["vgg_width_div"]))
+    for it in range(2):
+        noise = [torch.from_numpy(z[f"noise{3 * it + j}"]).to(dev) for j in range(3)]
+        out = T.train_step(torch.from_numpy(z[f"lr{it}"]).to(dev), torch.from_numpy(z[f"hr{it}"]).to(dev), noise)
+        got = np.array([float(out[k]) for k in ("loss_real", "loss_fake", "adv_loss", "content_loss")])
+        assert np.allclose(got, z["losses"][it], rtol=1e-3), (it, got, z["losses"][it])
+    for pre, mod in (("g", T.generator), ("d", T.discriminator)):
+        for k, p in mod.state_dict().items():
+            p0, p2 = torch.from_numpy(z[f"{pre}0.{k}"]), torch.from_numpy(z[f"{pre}2.{k}"])
+            upd = (p2 - p0).abs().mean()
+            assert (p.cpu() - p2).abs().mean() <= 0.12 * upd, (pre, k)   # see tests/test_oracle.py on Adam's noise gain
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("cdt", ["f32", "bf16"])
+def test_full_width_train_step_vs_oracle(pkg, cdt):
+    """64-filter G (2 blocks) and D, width/4 VGG stand-in, 16->64 crops: losses and one AdamW update vs the oracle."""
+    dev = select("hip")
+    torch.manual_seed(9)
+    T = _trainer(pkg, dev, cdt, nf=64, n_layers=2)
+    g_sd = {k: v.detach().cpu().clone() for k, v in T.generator.state_dict().items()}
+    d_sd = {k: v.detach().cpu().clone() for k, v in T.discriminator.state_dict().items()}
+    g0, d0 = {k: v.clone() for k, v in g_sd.items()}, {k: v.clone() for k, v in d_sd.items()}
+    v_sd = O.vgg_standin_state_dict(1234, 4)
+    lr, hr = torch.rand(2, 3, 16, 16) * 2 - 1, torch.rand(2, 3, 64, 64) * 2 - 1
+    noise = [torch.rand(2, 1, 4, 4) for _ in range(3)]
+    got = T.train_step(lr.to(dev), hr.to(dev), [n.to(dev) for n in noise])
+    want = O.train_step(g_sd, d_sd, v_sd, lr, hr, noise, {}, {})
+    tl = 1e-3 if cdt == "f32" else 5e-2
+    for k in want:
+        assert abs(float(got[k]) - float(want[k])) <= tl * abs(float(want[k])), (k, float(got[k]), float(want[k]))
+    if cdt == "f32":   # one AdamW step each: compare the updates in the mean (Adam amplifies tiny-gradient noise)
+        for sd_ref, sd0, mod in ((g_sd, g0, T.generator), (d_sd, d0, T.discriminator)):
+            for k, p in mod.state_dict().items():
+                upd = (sd_ref[k] - sd0[k]).abs().mean()
+                assert (p.cpu() - sd_ref[k]).abs().mean() <= 0.1 * upd + 1e-12, k
+
+
+@pytest.mark.gpu
+def test_pretrain_step_vs_oracle(pkg):
+    dev = select("hip")
+    torch.manual_seed(10)
+    T = _trainer(pkg, dev, "f32")
+    g_sd = {k: v.detach().cpu().clone() for k, v in T.generator.state_dict().items()}
+    lr, hr = torch.rand(2, 3, 8, 12) * 2 - 1, torch.rand(2, 3, 32, 48) * 2 - 1
+    got = T.pretrain_step(lr.to(dev), hr.to(dev))
+    want = O.pretrain_step(g_sd, lr, hr, {})
+    assert abs(float(got) - float(want)) <= 1e-4 * abs(float(want))
+    for k, p in T.generator.state_dict().items():
+        assert (p.cpu() - g_sd[k]).abs().mean() <= 0.1 * 1e-4 + 1e-9, k   # both moved by ~lr in the same direction
+
+
+# ------------------------------------------------------------------ host logic (CPU suite)
+def test_config_loader_keys_and_overrides(pkg, tmp_path):
+    cfg = pkg.load_config(os.path.join(os.path.dirname(os.path.dirname(__file__)), "configs", "config.yaml"),
+                          ["training.batch_size=8", "generator.n_layers=12", "experiment.name=x", "training.generator_lr=2e-4"])
+    ref_keys = {"experiment": {"name", "seed"}, "data": {"image_dir", "numpy_dir", "lr_image_size", "scale_factor"},
+                "generator": {"n_filters", "n_layers"}, "discriminator": {"n_filters", "n_layers"},
+                "training": {"compiled", "pretrain_iterations", "iterations", "device", "log_iter", "checkpoint_iter",
+                             "batch_size", "num_workers", "generator_lr", "discriminator_lr"}}
+    for group, keys in ref_keys.items():                      # configs/config.yaml:1-25 of the reference
+        assert keys <= set(vars(getattr(cfg, group))), group
+    assert cfg.training.batch_size == 8 and cfg.generator.n_layers == 12 and cfg.experiment.name == "x"
+    assert cfg.training.generator_lr == 2e-4 and cfg.training.discriminator_lr == 1e-4
+    with pytest.raises(ValueError):
+        pkg.load_config(None, ["nonsense"])
+
+
+def test_resize_taps_match_oracle(pkg):
+    data = __import__("importlib").import_module("fast-srgan_amd.dataloader")
+    for n_in, n_out in ((384, 96), (48, 12), (100, 25), (64, 8)):
+        xmin, xsize, w, kmax = data.aa_bicubic_taps(n_in, n_out)
+        oxm, oxs, ow = O.aa_bicubic_weights(n_in, n_out)
+        assert np.array_equal(xmin, oxm) and np.array_equal(xsize, oxs) and np.array_equal(w, ow) and kmax == ow.shape[1]
+
+
+def test_device_crop_pipeline_matches_reference_dataset(pkg, tmp_path):
+    """NumpyImagesDataset on the (emulated) device kernels vs the golden samples the REFERENCE dataset produced."""
+    dev = select("emu")
+    z = load_npz("dataset.npz")
+    path = str(tmp_path / "img.npy")
+    np.save(path, z["image"])
+    ds = pkg.NumpyImagesDataset([path], lr_image_size=12, scale_factor=4, device=dev)
+    random.seed(int(z["seed"]))
+    for i in range(3):
+        lr, hr = ds[0]
+        assert torch.equal(hr, torch.from_numpy(z[f"hr{i}"]))
+        assert (lr - torch.from_numpy(z[f"lr{i}"])).abs().max() < 1e-5
+    loader = pkg.DeviceBatchLoader(ds, batch_size=2, iterations=2, seed=3)
+    a = [tuple(t.clone() for t in b) for b in loader]
+    b = [tuple(t.clone() for t in b) for b in pkg.DeviceBatchLoader(ds, batch_size=2, iterations=2, seed=3)]
+    assert len(a) == 2 and a[0][0].shape == (2, 3, 12, 12) and a[0][1].shape == (2, 3, 48, 48)
+    assert all(torch.equal(x[0], y[0]) and torch.equal(x[1], y[1]) for x, y in zip(a, b))
+
+
+def test_arena_adamw_matches_torch(pkg):
+    """ArenaAdamW (flat arena + fsr_adamw_step) vs torch.optim.AdamW over several parameters and steps."""
+    dev = select("emu")
+    torch.manual_seed(0)
+    ps = [torch.nn.Parameter(torch.randn(5, 4, 3, 3)), torch.nn.Parameter(torch.randn(7)), torch.nn.Parameter(torch.randn(1))]
+    ref = [torch.nn.Parameter(p.detach().clone()) for p in ps]
+    opt, ropt = pkg.ArenaAdamW(ps, lr=1e-3), torch.optim.AdamW(ref, lr=1e-3)
+    assert ps[0].data_ptr() == opt.flat_param.data_ptr() and ps[0].grad.data_ptr() == opt.flat_grad.data_ptr()
+    for step in range(3):
+        opt.zero_grad()
+        ropt.zero_grad()
+        for p, r in zip(ps, ref):
+            g = torch.randn_like(p)
+            p.grad.add_(g)
+            r.grad = g.clone()
+        opt.step()
+        ropt.step()
+    for p, r in zip(ps, ref):
+        assert (p.detach() - r.detach()).abs().max() < 1e-6
+    sd = opt.state_dict()
+    assert set(sd["state"][0]) == {"step", "exp_avg", "exp_avg_sq"} and sd["state"][0]["exp_avg"].shape == (5, 4, 3, 3)
