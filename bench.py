@@ -62,11 +62,15 @@ def conv_profile(ops, fn):
 
 def cpu_baseline(seconds_budget=25.0):
     """The oracle (CPU restatement of trainer.py:171-196, fp32, torch CPU kernels) on a bounded sample of the same
-    workload: full-size networks, 96 -> 384, batch 2, ONE iteration (the survey measured ~2.5 s per image on 8 cores)."""
+    workload: full-size networks, 96 -> 384, batch 1, ONE iteration (the survey measured ~2.5 s per image on 8 cores)."""
     from oracle import srgan_cpu as O
     pkg = importlib.import_module("fast-srgan_amd")
     torch.manual_seed(0)
-    cores = os.cpu_count() or 1
+    try:
+        avail = len(os.sched_getaffinity(0))
+    except AttributeError:
+        avail = os.cpu_count() or 1
+    cores = max(1, min(avail, 32))   # oneDNN convolutions at batch 1 stop scaling (and thrash) far below 256 threads
     torch.set_num_threads(cores)
     with warnings.catch_warnings():
         warnings.simplefilter("ignore")
@@ -75,7 +79,7 @@ def cpu_baseline(seconds_budget=25.0):
     g_sd = {k: v.detach().clone() for k, v in G.state_dict().items()}
     d_sd = {k: v.detach().clone() for k, v in Dm.state_dict().items()}
     v_sd = O.vgg_standin_state_dict(1234, 1)
-    b = 2
+    b = 1
     lr, hr = torch.rand(b, 3, 96, 96) * 2 - 1, torch.rand(b, 3, 384, 384) * 2 - 1
     noise = [torch.rand(b, 1, 24, 24) for _ in range(3)]
     t0 = time.perf_counter()

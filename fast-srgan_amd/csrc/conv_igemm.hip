@@ -40,16 +40,6 @@ __device__ __forceinline__ unsigned tap_code(const ConvKArgs& a, int t) {
   return (t < 8) ? (unsigned)((a.taps_lo >> (8 * t)) & 0xffull) : a.taps_hi;
 }
 
-// acc_row[n] with a compile-time-resolvable select chain (n comes from an unrolled loop)
-template <int NT>
-__device__ __forceinline__ f32x4 pick_col(const f32x4 (&row)[NT], int n) {
-  f32x4 r = row[0];
-#pragma unroll
-  for (int j = 1; j < NT; ++j)
-    if (n == j) r = row[j];
-  return r;
-}
-
 // 4 consecutive channels of one pixel -> memory (16/8-byte vector when the channel count allows)
 template <typename T>
 __device__ __forceinline__ void store4(void* base, size_t off, f32x4 v, int co, int Cout, bool f32_out) {
@@ -102,13 +92,6 @@ __device__ __forceinline__ void conv_store(const ConvKArgs& a, int img, int gy, 
 #pragma unroll
   for (int r = 0; r < 4; ++r) v[r] = act_apply(v[r], a.act, slope);
   store4<T>(a.out, off, v, co, climit, f32_out);
-}
-
-template <typename T, int MT, int NT, int... Ms>
-__device__ __forceinline__ void epilogue_rows(const ConvKArgs& a, int img, int gy_base, int gx, int co,
-                                              f32x4 (&acc)[MT][NT], int n, f32x4 sv, f32x4 bv, float slope, f32x4& s1,
-                                              f32x4& s2, std::integer_sequence<int, Ms...>) {
-  (conv_store<T>(a, img, gy_base + Ms, gx, co, pick_col<NT>(acc[Ms], n) * sv + bv, slope, s1, s2), ...);
 }
 
 template <typename T, int TH, int BN, int WM, int WN, int KC, int S>
@@ -248,8 +231,8 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvKArgs a) {
 
   // ---------------------------------------------------------------- epilogue
   const float slope = (a.act == FSR_ACT_PRELU) ? a.prelu[0] : a.slope;
-#pragma unroll
-  for (int n = 0; n < NT; ++n) {
+  static_for<0, NT>([&](auto nc) {
+    constexpr int n = decltype(nc)::value;
     const int co = nb * BN + (wn * NT + n) * 16 + lg * 4;  // this lane's 4 consecutive channels
     f32x4 bv = (f32x4){0.f, 0.f, 0.f, 0.f};
     if (a.bias) {
@@ -268,10 +251,10 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvKArgs a) {
         if (co + r < a.Cout) sv[r] = a.oscale[co + r];
     }
     f32x4 s1 = (f32x4){0.f, 0.f, 0.f, 0.f}, s2 = (f32x4){0.f, 0.f, 0.f, 0.f};
-    // static row indices (fold expression): keeps the accumulator array in registers even when
-    // the unrolled epilogue exceeds the compiler's pragma-unroll size threshold
-    epilogue_rows<T, MT, NT>(a, img, gy0 + wm * MT, gx0 + l15, co, acc, n, sv, bv, slope, s1, s2,
-                             std::make_integer_sequence<int, MT>());
+    static_for<0, MT>([&](auto mc) {
+      constexpr int m = decltype(mc)::value;
+      conv_store<T>(a, img, gy0 + wm * MT + m, gx0 + l15, co, acc[m][n] * sv + bv, slope, s1, s2);
+    });
     if (a.stats) {
       // per-(image, channel) partial sums over this wave's pixels: xor-reduce the 16 pixel lanes
       // of each lane group, then one atomic per (wave, channel).
@@ -290,7 +273,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvKArgs a) {
         }
       }
     }
-  }
+  });
 }
 
 #undef FSR_WLOAD
@@ -343,7 +326,7 @@ static int dispatch_T(ConvKArgs& a, int S, hipStream_t stream) {
   if (a.CoutPad % 128 == 0) {
     if (S == 2) return launch_cfg<T, 8, 128, 2, 2, KCN, 2>(a, stream);
     if (th8) return launch_cfg<T, 8, 128, 2, 2, KCN, 1>(a, stream);
-    return launch_cfg<T, 16, 128, 2, 2, KCN, 1>(a, stream);
+    return launch_cfg<T, 16, 128, 4, 1, KCN, 1>(a, stream);
   }
   if (a.CoutPad % 64 == 0) {
     if (S == 2) return launch_cfg<T, 8, 64, 2, 2, KCN, 2>(a, stream);

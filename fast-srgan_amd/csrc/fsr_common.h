@@ -11,6 +11,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <type_traits>
+
 typedef unsigned short bf16_t;  // raw bf16 bits
 
 typedef short s16x8 __attribute__((ext_vector_type(8)));
@@ -71,6 +73,16 @@ __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
   for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o, 64);
   return v;
+}
+
+// compile-time loop: f(std::integral_constant<int, I>) for I in [I0, N).  Keeps every index into
+// register arrays (accumulators) a constant -- a runtime index sends the whole array to scratch.
+template <int I, int N, typename F>
+__device__ __forceinline__ void static_for(F&& f) {
+  if constexpr (I < N) {
+    f(std::integral_constant<int, I>{});
+    static_for<I + 1, N>(f);
+  }
 }
 
 // XCD-aware bijective remap of a linear workgroup id: consecutive logical ids land on
