@@ -128,27 +128,43 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvKArgs a) {
   const T* wpk = (const T*)a.wpk;
   const int nchunks = a.Cin / KC;
 
-  auto load_halo = [&](int c) {
-    const int total = a.HH * a.HW * UNITS;
-    for (int u = tid; u < total; u += 256) {
-      const int unit = u % UNITS;
-      const int p = u / UNITS;
-      const int hx = p % a.HW, hy = p / a.HW;
-      const int iy = iy0 + hy, ix = ix0 + hx;
+  // Halo staging is split (issue early / commit late): the global loads of chunk c+1 are issued into
+  // registers at the start of chunk c and written to LDS after its last tap, so their latency hides
+  // under a whole chunk of MFMAs instead of stalling every workgroup once per chunk.
+  constexpr int HPT = (((TH - 1) * S + 3) * (15 * S + 3) * UNITS + 255) / 256;  // upper bound on units per thread
+  u32x4 hreg[HPT];
+  const int halo_total = a.HH * a.HW * UNITS;
+  auto halo_issue = [&](int c) {
+#pragma unroll
+    for (int i = 0; i < HPT; ++i) {
+      const int u = tid + i * 256;
       u32x4 v = (u32x4){0u, 0u, 0u, 0u};
-      if (iy >= 0 && iy < a.IH && ix >= 0 && ix < a.IW) {
-        const int ch = c * KC + unit * EPB;
-        unsigned eoff;  // 32-bit element offset (host guarantees the tensor has < 2^31 elements)
-        if (!a.in_ps) {
-          eoff = (unsigned)((img * a.IH + iy) * a.IW + ix) * (unsigned)a.Cin + (unsigned)ch;
-        } else {
-          const int cps = a.Cin >> 2;
-          const int q = ch / cps, cc = ch - q * cps;
-          eoff = (unsigned)((img * 2 * a.IH + 2 * iy + (q >> 1)) * (2 * a.IW) + 2 * ix + (q & 1)) * (unsigned)cps + (unsigned)cc;
+      if (u < halo_total) {
+        const int unit = u % UNITS;
+        const int p = u / UNITS;
+        const int hx = p % a.HW, hy = p / a.HW;
+        const int iy = iy0 + hy, ix = ix0 + hx;
+        if (iy >= 0 && iy < a.IH && ix >= 0 && ix < a.IW) {
+          const int ch = c * KC + unit * EPB;
+          unsigned eoff;  // 32-bit element offset (host guarantees the tensor has < 2^31 elements)
+          if (!a.in_ps) {
+            eoff = (unsigned)((img * a.IH + iy) * a.IW + ix) * (unsigned)a.Cin + (unsigned)ch;
+          } else {
+            const int cps = a.Cin >> 2;
+            const int q = ch / cps, cc = ch - q * cps;
+            eoff = (unsigned)((img * 2 * a.IH + 2 * iy + (q >> 1)) * (2 * a.IW) + 2 * ix + (q & 1)) * (unsigned)cps + (unsigned)cc;
+          }
+          v = *(const u32x4*)(in + eoff);
         }
-        v = *(const u32x4*)(in + eoff);
       }
-      *(u32x4*)(halo + (size_t)p * PITCH + unit * EPB) = v;
+      hreg[i] = v;
+    }
+  };
+  auto halo_commit = [&]() {
+#pragma unroll
+    for (int i = 0; i < HPT; ++i) {
+      const int u = tid + i * 256;
+      if (u < halo_total) *(u32x4*)(halo + (size_t)(u / UNITS) * PITCH + (u % UNITS) * EPB) = hreg[i];
     }
   };
 
@@ -185,13 +201,15 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvKArgs a) {
 #pragma unroll
   for (int n = 0; n < NT; ++n) wbase[n] = ((wn * NT + n) * 16 + l15) * PITCH + lg * EPB;
 
-  load_halo(0);
+  halo_issue(0);
+  halo_commit();
   FSR_WLOAD(0, 0)
   FSR_WSTORE(0)
   __syncthreads();
 
   int cur = 0;
   for (int c = 0; c < nchunks; ++c) {
+    if (c + 1 < nchunks) halo_issue(c + 1);
     for (int t = 0; t < a.ntaps; ++t) {
       const bool last_tap = (t + 1 == a.ntaps);
       const bool has_next = !(last_tap && c + 1 == nchunks);
@@ -224,13 +242,18 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvKArgs a) {
       cur ^= 1;
     }
     if (c + 1 < nchunks) {
-      load_halo(c + 1);
+      halo_commit();
       __syncthreads();
     }
   }
 
   // ---------------------------------------------------------------- epilogue
   const float slope = (a.act == FSR_ACT_PRELU) ? a.prelu[0] : a.slope;
+  float* sred = (float*)smem;  // [BN][2] statistics of this workgroup (reuses the halo image)
+  if (a.stats) {               // the main loop ended on a barrier: every wave is done with LDS
+    for (int i = tid; i < 2 * BN; i += 256) sred[i] = 0.f;
+    __syncthreads();
+  }
   static_for<0, NT>([&](auto nc) {
     constexpr int n = decltype(nc)::value;
     const int co = nb * BN + (wn * NT + n) * 16 + lg * 4;  // this lane's 4 consecutive channels
@@ -256,8 +279,9 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvKArgs a) {
       conv_store<T>(a, img, gy0 + wm * MT + m, gx0 + l15, co, acc[m][n] * sv + bv, slope, s1, s2);
     });
     if (a.stats) {
-      // per-(image, channel) partial sums over this wave's pixels: xor-reduce the 16 pixel lanes
-      // of each lane group, then one atomic per (wave, channel).
+      // per-(image, channel) partial sums: xor-reduce the 16 pixel lanes of each lane group, meet the
+      // other waves of the workgroup in LDS (the halo image is dead by now), one global atomic per
+      // (workgroup, channel, quantity) below.
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         float x1 = s1[r], x2 = s2[r];
@@ -266,14 +290,21 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvKArgs a) {
           x1 += __shfl_xor(x1, o, 64);
           x2 += __shfl_xor(x2, o, 64);
         }
-        if (l15 == 0 && co + r < a.Cout) {
-          float* st = a.stats + ((size_t)img * a.Cout + co + r) * 2;
-          atomicAdd(st, x1);
-          atomicAdd(st + 1, x2);
+        if (l15 == 0) {
+          const int cl = (wn * NT + n) * 16 + lg * 4 + r;
+          atomicAdd(sred + 2 * cl, x1);
+          atomicAdd(sred + 2 * cl + 1, x2);
         }
       }
     }
   });
+  if (a.stats) {
+    __syncthreads();
+    for (int i = tid; i < 2 * BN; i += 256) {
+      const int co = nb * BN + (i >> 1);
+      if (co < a.Cout) atomicAdd(a.stats + ((size_t)img * a.Cout + co) * 2 + (i & 1), sred[i]);
+    }
+  }
 }
 
 #undef FSR_WLOAD
@@ -320,23 +351,25 @@ static int launch_cfg(ConvKArgs& a, hipStream_t stream) {
 
 template <typename T, int KCW, int KCN>
 static int dispatch_T(ConvKArgs& a, int S, hipStream_t stream) {
-  // KCW: chunk used by the 64-channel "whole filter row in one chunk" config; KCN: normal chunk
+  // KCW: wide input-channel chunk (bf16: 64 channels = 128 B per pixel) used whenever Cin allows it at
+  // stride 1 (half the barriers and halo passes per FLOP); KCN: narrow chunk (stride 2 halos are 4x larger)
   const int w16 = ((a.GH + 15) / 16) * 16 - a.GH, w8 = ((a.GH + 7) / 8) * 8 - a.GH;
-  const bool th8 = (S == 2) || (w16 - w8 >= 8);
+  const bool th8 = (w16 - w8 >= 8);
+  const bool wide = (a.Cin % KCW == 0);
   if (a.CoutPad % 128 == 0) {
     if (S == 2) return launch_cfg<T, 8, 128, 2, 2, KCN, 2>(a, stream);
-    if (th8) return launch_cfg<T, 8, 128, 2, 2, KCN, 1>(a, stream);
-    return launch_cfg<T, 16, 128, 4, 1, KCN, 1>(a, stream);
+    if (wide) return launch_cfg<T, 8, 128, 2, 2, KCW, 1>(a, stream);
+    return launch_cfg<T, 8, 128, 2, 2, KCN, 1>(a, stream);
   }
   if (a.CoutPad % 64 == 0) {
     if (S == 2) return launch_cfg<T, 8, 64, 2, 2, KCN, 2>(a, stream);
-    if (th8) return launch_cfg<T, 8, 64, 2, 2, KCN, 1>(a, stream);
-    if (a.Cin % KCW == 0) return launch_cfg<T, 16, 64, 4, 1, KCW, 1>(a, stream);
+    if (th8) return wide ? launch_cfg<T, 8, 64, 2, 2, KCW, 1>(a, stream) : launch_cfg<T, 8, 64, 2, 2, KCN, 1>(a, stream);
+    if (wide) return launch_cfg<T, 16, 64, 4, 1, KCW, 1>(a, stream);
     return launch_cfg<T, 16, 64, 4, 1, KCN, 1>(a, stream);
   }
   if (a.CoutPad % 16 == 0) {  // thin outputs (head conv, image gradients) and small test networks
     if (S == 2) return launch_cfg<T, 8, 16, 4, 1, KCN, 2>(a, stream);
-    if (a.Cin % KCW == 0) return launch_cfg<T, 16, 16, 4, 1, KCW, 1>(a, stream);
+    if (wide) return launch_cfg<T, 16, 16, 4, 1, KCW, 1>(a, stream);
     return launch_cfg<T, 16, 16, 4, 1, KCN, 1>(a, stream);
   }
   return fsr_fail(-2, "conv3x3: unsupported padded Cout=%d (need a multiple of 16)", a.CoutPad);
