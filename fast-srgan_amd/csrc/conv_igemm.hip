@@ -40,58 +40,24 @@ __device__ __forceinline__ unsigned tap_code(const ConvKArgs& a, int t) {
   return (t < 8) ? (unsigned)((a.taps_lo >> (8 * t)) & 0xffull) : a.taps_hi;
 }
 
-// 4 consecutive channels of one pixel -> memory (16/8-byte vector when the channel count allows)
+// ---------------------------------------------------------------------------- epilogue
+// The epilogue runs once per workgroup over MT*NT accumulator tiles; with a few thousand MFMA cycles of
+// main loop per workgroup its instruction count matters as much as the loop's.  Three compact paths, picked
+// by a wave-uniform branch, replace one path with per-element flag tests:
+//   plain : T output, every channel valid (Cout % 16 == 0), optional pre-activation copy   (all big layers)
+//   ps    : as plain, stored depth-to-space (PixelShuffle(2) fused, model.py:36)
+//   thin  : float output with fewer than 16 channels per tile (head conv + tanh, image gradients)
+// ReLU / LeakyReLU / PReLU / identity are ONE formula: v > 0 ? v : v * slope with slope 0 / s / a / 1.
 template <typename T>
-__device__ __forceinline__ void store4(void* base, size_t off, f32x4 v, int co, int Cout, bool f32_out) {
-  const bool full = (co + 4 <= Cout) && ((Cout & 3) == 0);
-  if (f32_out) {
-    float* o = (float*)base + off;
-    if (full) {
-      *(f32x4*)o = v;
-    } else {
-#pragma unroll
-      for (int r = 0; r < 4; ++r)
-        if (co + r < Cout) o[r] = v[r];
-    }
+__device__ __forceinline__ void store_vec4(T* p, f32x4 v) {
+  if constexpr (sizeof(T) == 4) {
+    *(f32x4*)p = v;
   } else {
-    bf16_t* o = (bf16_t*)base + off;
-    if (full) {
-      u32x2 pk;
-      pk.x = (unsigned)f2bf(v[0]) | ((unsigned)f2bf(v[1]) << 16);
-      pk.y = (unsigned)f2bf(v[2]) | ((unsigned)f2bf(v[3]) << 16);
-      *(u32x2*)o = pk;
-    } else {
-#pragma unroll
-      for (int r = 0; r < 4; ++r)
-        if (co + r < Cout) o[r] = f2bf(v[r]);
-    }
+    u32x2 pk;
+    pk.x = pack_bf16x2(v[0], v[1]);
+    pk.y = pack_bf16x2(v[2], v[3]);
+    *(u32x2*)p = pk;
   }
-}
-
-// Epilogue for one (pixel, 4 consecutive output channels): statistics of the pre-activation,
-// optional pre-activation store, activation, NHWC (or depth-to-space) vector store.
-template <typename T>
-__device__ __forceinline__ void conv_store(const ConvKArgs& a, int img, int gy, int gx, int co, f32x4 v, float slope,
-                                           f32x4& s1, f32x4& s2) {
-  if (gy >= a.GH || gx >= a.GW || co >= a.Cout) return;
-  const int oy = gy * a.osy + a.ooy, ox = gx * a.osx + a.oox;
-  size_t off;
-  if (!a.ps) {
-    off = (((size_t)img * a.FOH + oy) * a.FOW + ox) * a.Cout + co;
-  } else {
-    const int cps = a.Cout >> 2;
-    const int q = co / cps, cc = co - q * cps;
-    off = (((size_t)img * 2 * a.FOH + 2 * oy + (q >> 1)) * (size_t)(2 * a.FOW) + 2 * ox + (q & 1)) * cps + cc;
-  }
-  const bool f32_out = a.out_f32 || sizeof(T) == 4;
-  // a pixel-shuffled store keeps 4-channel groups intact only inside one quadrant slice
-  const int climit = a.ps ? (co / (a.Cout >> 2) + 1) * (a.Cout >> 2) : a.Cout;
-  s1 += v;
-  s2 += v * v;
-  if (a.preact) store4<T>(a.preact, off, v, co, climit, f32_out);
-#pragma unroll
-  for (int r = 0; r < 4; ++r) v[r] = act_apply(v[r], a.act, slope);
-  store4<T>(a.out, off, v, co, climit, f32_out);
 }
 
 template <typename T, int TH, int BN, int WM, int WN, int KC, int S>
@@ -108,7 +74,8 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvKArgs a) {
 
   HIP_DYNAMIC_SHARED(char, smem)
   T* halo = (T*)smem;
-  T* wl = halo + a.HH * a.HW * PITCH;
+  constexpr int HH = (TH - 1) * S + 3, HW = 15 * S + 3;  // halo extent for the full 3x3 footprint (fewer taps use less)
+  T* wl = halo + HH * HW * PITCH;
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave / WN, wn = wave % WN;
@@ -131,9 +98,9 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvKArgs a) {
   // Halo staging is split (issue early / commit late): the global loads of chunk c+1 are issued into
   // registers at the start of chunk c and written to LDS after its last tap, so their latency hides
   // under a whole chunk of MFMAs instead of stalling every workgroup once per chunk.
-  constexpr int HPT = (((TH - 1) * S + 3) * (15 * S + 3) * UNITS + 255) / 256;  // upper bound on units per thread
+  constexpr int halo_total = HH * HW * UNITS;
+  constexpr int HPT = (halo_total + 255) / 256;  // 16-byte units per thread
   u32x4 hreg[HPT];
-  const int halo_total = a.HH * a.HW * UNITS;
   auto halo_issue = [&](int c) {
 #pragma unroll
     for (int i = 0; i < HPT; ++i) {
@@ -142,7 +109,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvKArgs a) {
       if (u < halo_total) {
         const int unit = u % UNITS;
         const int p = u / UNITS;
-        const int hx = p % a.HW, hy = p / a.HW;
+        const int hx = p % HW, hy = p / HW;
         const int iy = iy0 + hy, ix = ix0 + hx;
         if (iy >= 0 && iy < a.IH && ix >= 0 && ix < a.IW) {
           const int ch = c * KC + unit * EPB;
@@ -197,7 +164,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvKArgs a) {
 
   int pixbase[MT], wbase[NT];
 #pragma unroll
-  for (int m = 0; m < MT; ++m) pixbase[m] = (((wm * MT + m) * S) * a.HW + l15 * S) * PITCH + lg * EPB;
+  for (int m = 0; m < MT; ++m) pixbase[m] = (((wm * MT + m) * S) * HW + l15 * S) * PITCH + lg * EPB;
 #pragma unroll
   for (int n = 0; n < NT; ++n) wbase[n] = ((wn * NT + n) * 16 + l15) * PITCH + lg * EPB;
 
@@ -217,7 +184,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvKArgs a) {
 
       const T* wcur = wl + (size_t)cur * BN * PITCH;
       const unsigned tc = tap_code(a, t);
-      const int toff = ((int)(tc & 3u) * a.HW + (int)((tc >> 2) & 3u)) * PITCH;
+      const int toff = ((int)(tc & 3u) * HW + (int)((tc >> 2) & 3u)) * PITCH;
 #pragma unroll
       for (int ks = 0; ks < KC / KSTEP; ++ks) {
         frag_t wf[NT], xf[MT];
@@ -248,37 +215,82 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvKArgs a) {
   }
 
   // ---------------------------------------------------------------- epilogue
-  const float slope = (a.act == FSR_ACT_PRELU) ? a.prelu[0] : a.slope;
+  float slope = (a.act == FSR_ACT_PRELU) ? a.prelu[0] : a.slope;
+  if (a.act == FSR_ACT_NONE || a.act == FSR_ACT_TANH) slope = 1.f;
+  if (a.act == FSR_ACT_RELU) slope = 0.f;
   float* sred = (float*)smem;  // [BN][2] statistics of this workgroup (reuses the halo image)
   if (a.stats) {               // the main loop ended on a barrier: every wave is done with LDS
     for (int i = tid; i < 2 * BN; i += 256) sred[i] = 0.f;
     __syncthreads();
   }
+  const int gx = gx0 + l15;
+  const int gyb = gy0 + wm * MT;            // first grid row of this wave
+  const int cob = nb * BN + wn * NT * 16 + lg * 4;  // first of this lane's channels (tile n adds 16 n)
+  const bool col_ok = gx < a.GW;
+  if (BN == 16 && ((a.out_f32 && sizeof(T) == 2) || a.Cout % 16 != 0)) {  // only the 16-wide configs carry this code
+    // ---- thin / float path (memory-bound layers): per-element guards, optional scale, tanh
+    static_for<0, NT>([&](auto nc) {
+      constexpr int n = decltype(nc)::value;
+      const int co = cob + n * 16;
+      static_for<0, MT>([&](auto mc) {
+        constexpr int m = decltype(mc)::value;
+        const int gy = gyb + m;
+        if (col_ok && gy < a.GH) {
+          const size_t off = (((size_t)img * a.FOH + gy * a.osy + a.ooy) * a.FOW + gx * a.osx + a.oox) * a.Cout + co;
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+            if (co + r < a.Cout) {
+              float v = acc[m][n][r];
+              if (a.oscale) v *= a.oscale[co + r];
+              if (a.bias) v += a.bias[co + r];
+              v = (a.act == FSR_ACT_TANH) ? tanhf(v) : (v > 0.f ? v : v * slope);
+              if (a.out_f32 || sizeof(T) == 4) ((float*)a.out)[off + r] = v;
+              else ((bf16_t*)a.out)[off + r] = f2bf(v);
+            }
+        }
+      });
+    });
+    return;
+  }
+  T* outp = (T*)a.out;
+  T* prep = (T*)a.preact;
+  const bool want_stats = a.stats != nullptr;
   static_for<0, NT>([&](auto nc) {
     constexpr int n = decltype(nc)::value;
-    const int co = nb * BN + (wn * NT + n) * 16 + lg * 4;  // this lane's 4 consecutive channels
+    const int co = cob + n * 16;
     f32x4 bv = (f32x4){0.f, 0.f, 0.f, 0.f};
-    if (a.bias) {
+    unsigned base, rstride;  // 32-bit element offsets (tensors hold < 2^31 elements): grid row gyb, and the row stride
+    if (!a.ps) {
+      if (a.bias) bv = *(const f32x4*)(a.bias + co);
+      base = (unsigned)((img * a.FOH + gyb * a.osy + a.ooy) * a.FOW + gx * a.osx + a.oox) * (unsigned)a.Cout + (unsigned)co;
+      rstride = (unsigned)(a.osy * a.FOW * a.Cout);
+    } else {
+      // filter rows were packed [quadrant q][channel cc]; the bias stays in torch order 4*cc + q
+      const int cps = a.Cout >> 2;
+      const int q = co / cps, cc = co - q * cps;
+      if (a.bias) {
 #pragma unroll
-      for (int r = 0; r < 4; ++r)
-        if (co + r < a.Cout) {
-          // pixel-shuffle launches use filter rows permuted to [q][c]; the bias stays in torch order
-          const int cps = a.Cout >> 2;
-          bv[r] = a.bias[a.ps ? 4 * ((co + r) % cps) + (co + r) / cps : co + r];
-        }
-    }
-    f32x4 sv = (f32x4){1.f, 1.f, 1.f, 1.f};
-    if (a.oscale) {
-#pragma unroll
-      for (int r = 0; r < 4; ++r)
-        if (co + r < a.Cout) sv[r] = a.oscale[co + r];
+        for (int r = 0; r < 4; ++r) bv[r] = a.bias[4 * (cc + r) + q];
+      }
+      base = (unsigned)((img * 2 * a.FOH + 2 * gyb + (q >> 1)) * (2 * a.FOW) + 2 * gx + (q & 1)) * (unsigned)cps + (unsigned)cc;
+      rstride = (unsigned)(4 * a.FOW * cps);
     }
     f32x4 s1 = (f32x4){0.f, 0.f, 0.f, 0.f}, s2 = (f32x4){0.f, 0.f, 0.f, 0.f};
     static_for<0, MT>([&](auto mc) {
       constexpr int m = decltype(mc)::value;
-      conv_store<T>(a, img, gy0 + wm * MT + m, gx0 + l15, co, acc[m][n] * sv + bv, slope, s1, s2);
+      if (col_ok && gyb + m < a.GH) {
+        f32x4 v = acc[m][n] + bv;
+        if (want_stats) {
+          s1 += v;
+          s2 += v * v;
+        }
+        if (prep) store_vec4<T>(prep + (base + m * rstride), v);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f) + slope * fminf(v[r], 0.f);
+        store_vec4<T>(outp + (base + m * rstride), v);
+      }
     });
-    if (a.stats) {
+    if (want_stats) {
       // per-(image, channel) partial sums: xor-reduce the 16 pixel lanes of each lane group, meet the
       // other waves of the workgroup in LDS (the halo image is dead by now), one global atomic per
       // (workgroup, channel, quantity) below.
@@ -332,8 +344,9 @@ static int launch_cfg(ConvKArgs& a, hipStream_t stream) {
     if (t < 8) a.taps_lo |= (unsigned long long)code << (8 * t);
     else a.taps_hi = code;
   }
-  a.HH = (TH - 1) * S + maxdy + 1;
-  a.HW = 15 * S + maxdx + 1;
+  a.HH = (TH - 1) * S + 3;
+  a.HW = 15 * S + 3;
+  if (maxdy > 2 || maxdx > 2) return fsr_fail(-2, "conv3x3: tap offsets exceed the 3x3 footprint");
   const size_t lds = ((size_t)a.HH * a.HW * PITCH + 2 * (size_t)BN * PITCH) * sizeof(T);
   auto kern = conv_igemm_kernel<T, TH, BN, WM, WN, KC, S>;
   static bool attr_set = false;

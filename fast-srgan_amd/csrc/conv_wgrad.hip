@@ -226,7 +226,10 @@ int make_plan(const fsr_wgrad_desc* d, WgradPlan& p) {
   p.tiles_total = p.tiles_x * p.tiles_y * d->n;
   p.nbm = d->cout_pad / p.BM;
   p.nbn = d->cin_pad / p.BN;
-  int want = (256 + p.nbm * p.nbn - 1) / (p.nbm * p.nbn);  // about one workgroup per CU: the partials cost HBM traffic
+  // about one workgroup per CU (the partials cost HBM traffic); thin layers (3-channel side) are
+  // bandwidth-bound with tiny partials, so they get four per CU to keep more loads in flight
+  const int target = (p.BM == 16 || p.BN < 64) ? 1024 : 256;
+  int want = (target + p.nbm * p.nbn - 1) / (p.nbm * p.nbn);
   if (want > p.tiles_total) want = p.tiles_total;
   if (want < 1) want = 1;
   p.tiles_per_slab = (p.tiles_total + want - 1) / want;

@@ -69,6 +69,8 @@ extern "C" int fsr_conv3x3(const fsr_conv_desc* d, const void* in, const void* p
   a.in_ps = d->in_pixel_shuffled;
   a.out_f32 = d->out_f32;
   if (a.ps && stats) return fsr_fail(-2, "fsr_conv3x3: statistics are not available together with pixel shuffle");
+  if ((stats || preact) && (d->cout % 16 != 0 || (d->out_f32 && d->dtype != FSR_F32)))
+    return fsr_fail(-2, "fsr_conv3x3: statistics / pre-activation outputs need cout %% 16 == 0 and a `dtype` output");
   if (a.ps && (d->cout % 16 != 0)) return fsr_fail(-2, "fsr_conv3x3: pixel shuffle needs cout %% 16 == 0");
   if (a.in_ps && (d->cin % 4 != 0)) return fsr_fail(-2, "fsr_conv3x3: in_pixel_shuffled needs cin %% 4 == 0");
 

@@ -32,12 +32,13 @@ typedef __bf16 bf16x8_hw __attribute__((ext_vector_type(8)));
 __device__ __forceinline__ float bf2f(bf16_t h) {
   return __uint_as_float(((unsigned)h) << 16);
 }
-// round-to-nearest-even, NaN kept quiet
-__device__ __forceinline__ bf16_t f2bf(float f) {
-  unsigned u = __float_as_uint(f);
-  if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)((u >> 16) | 0x40);
-  u += 0x7fffu + ((u >> 16) & 1u);
-  return (bf16_t)(u >> 16);
+// round-to-nearest-even (v_cvt_pk_bf16_f32 on gfx950)
+typedef __bf16 bf16x2_hw __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ bf16_t f2bf(float f) { return __builtin_bit_cast(unsigned short, (__bf16)f); }
+__device__ __forceinline__ unsigned pack_bf16x2(float lo, float hi) {
+  const f32x2 v = {lo, hi};
+  return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2_hw));
 }
 
 template <typename T> struct ElemIO;

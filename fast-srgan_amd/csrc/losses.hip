@@ -71,7 +71,7 @@ template <> struct LV<bf16_t> {
   static __device__ __forceinline__ void st(bf16_t* p, const float (&v)[8]) {
     u32x4 t;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) t[i] = (unsigned)f2bf(v[2 * i]) | ((unsigned)f2bf(v[2 * i + 1]) << 16);
+    for (int i = 0; i < 4; ++i) t[i] = pack_bf16x2(v[2 * i], v[2 * i + 1]);
     *(u32x4*)p = t;
   }
 };
