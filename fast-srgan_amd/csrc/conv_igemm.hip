@@ -254,6 +254,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvKArgs a) {
   }
   T* outp = (T*)a.out;
   T* prep = (T*)a.preact;
+  const T* maskp = (const T*)a.dmask;
   const bool want_stats = a.stats != nullptr;
   static_for<0, NT>([&](auto nc) {
     constexpr int n = decltype(nc)::value;
@@ -280,6 +281,19 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvKArgs a) {
       constexpr int m = decltype(mc)::value;
       if (col_ok && gyb + m < a.GH) {
         f32x4 v = acc[m][n] + bv;
+        if (maskp) {   // data-gradient launch fused with the producer's activation backward: dz = dx * act'(y)
+          float mk[4];
+          if constexpr (sizeof(T) == 4) {
+            const f32x4 t = *(const f32x4*)(maskp + (base + m * rstride));
+            mk[0] = t[0]; mk[1] = t[1]; mk[2] = t[2]; mk[3] = t[3];
+          } else {
+            const u32x2 t = *(const u32x2*)(maskp + (base + m * rstride));
+            mk[0] = __uint_as_float(t.x << 16); mk[1] = __uint_as_float(t.x & 0xffff0000u);
+            mk[2] = __uint_as_float(t.y << 16); mk[3] = __uint_as_float(t.y & 0xffff0000u);
+          }
+#pragma unroll
+          for (int r = 0; r < 4; ++r) v[r] = mk[r] > 0.f ? v[r] : v[r] * a.dmask_slope;
+        }
         if (want_stats) {
           s1 += v;
           s2 += v * v;

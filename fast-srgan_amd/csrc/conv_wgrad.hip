@@ -72,42 +72,71 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradKArgs a) {
   const int tile0 = slab * a.tiles_per_slab;
   const int tile1 = (tile0 + a.tiles_per_slab < a.tiles_total) ? tile0 + a.tiles_per_slab : a.tiles_total;
 
-  for (int tile = tile0; tile < tile1; ++tile) {
+  // Staging is split (issue early / commit late): the global loads of tile i+1 are issued into registers
+  // before the MFMAs of tile i and written to LDS after them, so HBM/L2 latency hides under a tile of math.
+  constexpr int DUNITS = TPIX * (BM / EPB), HUNITS = HH * HW * (BN / EPB);
+  constexpr int DPT = (DUNITS + 255) / 256, HPT = (HUNITS + 255) / 256;
+  u32x4 dreg[DPT], hreg[HPT];
+  auto stage_issue = [&](int tile) {
     const int tx = tile % a.tiles_x;
     const int ty = (tile / a.tiles_x) % a.tiles_y;
     const int img = tile / (a.tiles_x * a.tiles_y);
     const int oy0 = ty * TPH, ox0 = tx * 16;
-    __syncthreads();  // the previous tile's LDS images are dead
-    // ---- stage dy tile: [TPIX][BM]
-    for (int u = tid; u < TPIX * (BM / EPB); u += 256) {
-      const int unit = u % (BM / EPB), p = u / (BM / EPB);
-      const int oy = oy0 + p / 16, ox = ox0 + (p & 15);
+#pragma unroll
+    for (int i = 0; i < DPT; ++i) {   // dy tile: [TPIX][BM]
+      const int u = tid + i * 256;
       u32x4 v = (u32x4){0u, 0u, 0u, 0u};
-      if (oy < a.OH && ox < a.OW) {
-        const int ch = bm * BM + unit * EPB;
-        unsigned eoff;
-        if (!a.dy_ps) {
-          eoff = (unsigned)((img * a.OH + oy) * a.OW + ox) * (unsigned)a.CoutPad + (unsigned)ch;
-        } else {
-          const int cps = a.CoutPad >> 2;
-          const int q = ch / cps, cc = ch - q * cps;
-          eoff = (unsigned)((img * 2 * a.OH + 2 * oy + (q >> 1)) * (2 * a.OW) + 2 * ox + (q & 1)) * (unsigned)cps + (unsigned)cc;
+      if (DUNITS % 256 == 0 || u < DUNITS) {
+        const int unit = u % (BM / EPB), p = u / (BM / EPB);
+        const int oy = oy0 + p / 16, ox = ox0 + (p & 15);
+        if (oy < a.OH && ox < a.OW) {
+          const int ch = bm * BM + unit * EPB;
+          unsigned eoff;
+          if (!a.dy_ps) {
+            eoff = (unsigned)((img * a.OH + oy) * a.OW + ox) * (unsigned)a.CoutPad + (unsigned)ch;
+          } else {
+            const int cps = a.CoutPad >> 2;
+            const int q = ch / cps, cc = ch - q * cps;
+            eoff = (unsigned)((img * 2 * a.OH + 2 * oy + (q >> 1)) * (2 * a.OW) + 2 * ox + (q & 1)) * (unsigned)cps + (unsigned)cc;
+          }
+          v = *(const u32x4*)(dyg + eoff);
         }
-        v = *(const u32x4*)(dyg + eoff);
       }
-      *(u32x4*)(dyt + p * PA + unit * EPB) = v;
+      dreg[i] = v;
     }
-    // ---- stage x halo: [HH][HW][BN]
     const int iy0 = oy0 * S - 1, ix0 = ox0 * S - 1;
-    for (int u = tid; u < HH * HW * (BN / EPB); u += 256) {
-      const int unit = u % (BN / EPB), p = u / (BN / EPB);
-      const int iy = iy0 + p / HW, ix = ix0 + p % HW;
+#pragma unroll
+    for (int i = 0; i < HPT; ++i) {   // x halo: [HH][HW][BN]
+      const int u = tid + i * 256;
       u32x4 v = (u32x4){0u, 0u, 0u, 0u};
-      if (iy >= 0 && iy < a.IH && ix >= 0 && ix < a.IW)
-        v = *(const u32x4*)(xg + (unsigned)((img * a.IH + iy) * a.IW + ix) * (unsigned)a.CinPad + (unsigned)(bn * BN + unit * EPB));
-      *(u32x4*)(halo + p * PB + unit * EPB) = v;
+      if (HUNITS % 256 == 0 || u < HUNITS) {
+        const int unit = u % (BN / EPB), p = u / (BN / EPB);
+        const int iy = iy0 + p / HW, ix = ix0 + p % HW;
+        if (iy >= 0 && iy < a.IH && ix >= 0 && ix < a.IW)
+          v = *(const u32x4*)(xg + (unsigned)((img * a.IH + iy) * a.IW + ix) * (unsigned)a.CinPad + (unsigned)(bn * BN + unit * EPB));
+      }
+      hreg[i] = v;
     }
+  };
+  auto stage_commit = [&]() {
+#pragma unroll
+    for (int i = 0; i < DPT; ++i) {
+      const int u = tid + i * 256;
+      if (DUNITS % 256 == 0 || u < DUNITS) *(u32x4*)(dyt + (u / (BM / EPB)) * PA + (u % (BM / EPB)) * EPB) = dreg[i];
+    }
+#pragma unroll
+    for (int i = 0; i < HPT; ++i) {
+      const int u = tid + i * 256;
+      if (HUNITS % 256 == 0 || u < HUNITS) *(u32x4*)(halo + (u / (BN / EPB)) * PB + (u % (BN / EPB)) * EPB) = hreg[i];
+    }
+  };
+
+  if (tile0 < tile1) stage_issue(tile0);
+  for (int tile = tile0; tile < tile1; ++tile) {
+    __syncthreads();  // the previous tile's LDS images are dead
+    stage_commit();
     __syncthreads();
+    if (tile + 1 < tile1) stage_issue(tile + 1);
     if (!active) continue;
 
     if constexpr (sizeof(T) == 2) {
@@ -168,28 +197,36 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradKArgs a) {
     }
 }
 
-// dw[co][ci][0..8] += sum_slab ws[slab][tap][row(co)][ci]; row(co) undoes the pixel-shuffle row order.
-// One thread per (co, ci): the slab reads are coalesced along ci, and the nine taps of an (co, ci)
-// pair are contiguous in the OIHW gradient (36-byte runs instead of a stride-9 scatter).
+// dw[co][ci][tap] += sum_slab ws[slab][tap][row(co)][ci]; row(co) undoes the pixel-shuffle row order.
+// Thread = one (tap, co, ci) element (coalesced along ci); blockIdx.y = a group of slabs.  With one group the
+// result is added with a plain read-modify-write, with several groups (small filters, hundreds of slabs) each
+// group adds its share with one float atomic per element.
 __global__ __launch_bounds__(256) void conv_wgrad_reduce_kernel(const float* __restrict__ ws, float* __restrict__ dw, int nslab,
-                                                                int cout, int cin, int cout_pad, int cin_pad, int ps) {
-  const int total = cout * cin;
-  const size_t tstride = (size_t)cout_pad * cin_pad, sstride = 9 * tstride;
+                                                                int cout, int cin, int cout_pad, int cin_pad, int ps,
+                                                                int slabs_per_group) {
+  const int total = 9 * cout * cin;
+  const size_t sstride = (size_t)9 * cout_pad * cin_pad;
+  const int k0 = blockIdx.y * slabs_per_group;
+  const int k1 = (k0 + slabs_per_group < nslab) ? k0 + slabs_per_group : nslab;
   for (int i = blockIdx.x * 256 + threadIdx.x; i < total; i += gridDim.x * 256) {
     const int ci = i % cin;
-    const int co = i / cin;
+    const int co = (i / cin) % cout;
+    const int t = i / (cin * cout);
     const int row = ps ? (co & 3) * (cout_pad >> 2) + (co >> 2) : co;
-    const float* p = ws + (size_t)row * cin_pad + ci;
-    float s[9];
-#pragma unroll
-    for (int t = 0; t < 9; ++t) s[t] = 0.f;
-    for (int k = 0; k < nslab; ++k) {
-#pragma unroll
-      for (int t = 0; t < 9; ++t) s[t] += p[k * sstride + t * tstride];
+    const float* p = ws + ((size_t)t * cout_pad + row) * cin_pad + ci;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    int k = k0;
+    for (; k + 4 <= k1; k += 4) {   // four independent loads in flight per lane
+      s0 += p[(size_t)k * sstride];
+      s1 += p[(size_t)(k + 1) * sstride];
+      s2 += p[(size_t)(k + 2) * sstride];
+      s3 += p[(size_t)(k + 3) * sstride];
     }
-    float* o = dw + (size_t)i * 9;
-#pragma unroll
-    for (int t = 0; t < 9; ++t) o[t] += s[t];
+    for (; k < k1; ++k) s0 += p[(size_t)k * sstride];
+    const float s = (s0 + s1) + (s2 + s3);
+    float* o = dw + ((size_t)co * cin + ci) * 9 + t;
+    if (gridDim.y == 1) *o += s;
+    else atomicAdd(o, s);
   }
 }
 
@@ -304,10 +341,15 @@ extern "C" int fsr_conv3x3_wgrad(const fsr_wgrad_desc* d, const void* x, const v
   a.nbn = p.nbn;
   int rc = d->dtype == FSR_BF16 ? dispatch_wgrad<bf16_t, 8>(p, a, stream) : dispatch_wgrad<float, 4>(p, a, stream);
   if (rc) return rc;
-  const int total = d->cout * d->cin;
+  const int total = 9 * d->cout * d->cin;
   int blocks = (total + 255) / 256;
-  if (blocks > 1024) blocks = 1024;
-  hipLaunchKernelGGL(conv_wgrad_reduce_kernel, dim3(blocks), dim3(256), 0, stream, (const float*)workspace, dw_oihw, p.nslab,
-                     d->cout, d->cin, d->cout_pad, d->cin_pad, d->dy_pixel_shuffled);
+  if (blocks > 2048) blocks = 2048;
+  int groups = p.nslab / 16;   // >= 16 slabs per group; big filters (few slabs) use one group and no atomics
+  if (groups < 1) groups = 1;
+  if (groups > 16) groups = 16;
+  const int spg = (p.nslab + groups - 1) / groups;
+  groups = (p.nslab + spg - 1) / spg;
+  hipLaunchKernelGGL(conv_wgrad_reduce_kernel, dim3(blocks, groups), dim3(256), 0, stream, (const float*)workspace, dw_oihw,
+                     p.nslab, d->cout, d->cin, d->cout_pad, d->cin_pad, d->dy_pixel_shuffled, spg);
   return fsr_check_launch("conv_wgrad_reduce_kernel");
 }

@@ -366,7 +366,7 @@ __global__ __launch_bounds__(256) void maxpool2_fwd_kernel(const T* __restrict__
 template <typename T>
 __global__ __launch_bounds__(256) void maxpool2_bwd_kernel(const T* __restrict__ g, const T* __restrict__ x,
                                                            const T* __restrict__ y, T* __restrict__ dx, int h, int w, int c,
-                                                           long long units) {
+                                                           long long units, int relu_mask) {
   constexpr int E = V16<T>::N;
   const int cu = c / E, oh = h / 2, ow = w / 2;
   for (long long u = (long long)blockIdx.x * 256 + threadIdx.x; u < units; u += (long long)gridDim.x * 256) {
@@ -390,7 +390,7 @@ __global__ __launch_bounds__(256) void maxpool2_bwd_kernel(const T* __restrict__
 #pragma unroll
       for (int i = 0; i < E; ++i) {
         const bool hit = !taken[i] && xv[i] == yv[i];
-        o[i] = hit ? gv[i] : 0.f;
+        o[i] = (hit && !(relu_mask && xv[i] <= 0.f)) ? gv[i] : 0.f;
         taken[i] = taken[i] || hit;
       }
       V16<T>::st(dx + off, o);
@@ -531,13 +531,13 @@ extern "C" int fsr_maxpool2_fwd(int dtype, const void* x, void* y, int n, int h,
 }
 
 extern "C" int fsr_maxpool2_bwd(int dtype, const void* g, const void* x, const void* y, void* dx, int n, int h, int w,
-                                int c, fsr_stream_t stream_) {
+                                int c, int relu_mask, fsr_stream_t stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   if (!g || !x || !y || !dx) return fsr_fail(-1, "fsr_maxpool2_bwd: null argument");
   if (int rc = check_c("fsr_maxpool2_bwd", dtype, c)) return rc;
   if ((h | w) & 1) return fsr_fail(-2, "fsr_maxpool2_bwd: odd extent %dx%d", h, w);
   const long long units = (long long)n * (h / 2) * (w / 2) * (c / (dtype == FSR_BF16 ? 8 : 4));
   FSR_DISPATCH_T(dtype, hipLaunchKernelGGL(maxpool2_bwd_kernel<T>, dim3(capped_blocks(units, 256)), dim3(256), 0, stream,
-                                           P<T>(g), P<T>(x), P<T>(y), P<T>(dx), h, w, c, units);)
+                                           P<T>(g), P<T>(x), P<T>(y), P<T>(dx), h, w, c, units, relu_mask);)
   return fsr_check_launch("maxpool2_bwd_kernel");
 }

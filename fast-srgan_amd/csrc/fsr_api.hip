@@ -37,8 +37,8 @@ extern "C" int fsr_device_info(char* buf, size_t buflen) {
 }
 
 extern "C" int fsr_conv3x3(const fsr_conv_desc* d, const void* in, const void* packed_w, const float* bias,
-                           const float* prelu_weight, const float* oscale, void* out, void* preact, float* stats,
-                           fsr_stream_t stream_) {
+                           const float* prelu_weight, const float* oscale, const void* dact_mask, float dact_slope,
+                           void* out, void* preact, float* stats, fsr_stream_t stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   if (!d || !in || !packed_w || !out) return fsr_fail(-1, "fsr_conv3x3: null argument");
   if (d->stride != 1 && d->stride != 2) return fsr_fail(-2, "fsr_conv3x3: stride must be 1 or 2");
@@ -54,6 +54,8 @@ extern "C" int fsr_conv3x3(const fsr_conv_desc* d, const void* in, const void* p
   a.prelu = prelu_weight;
   a.preact = preact;
   a.oscale = oscale;
+  a.dmask = dact_mask;
+  a.dmask_slope = dact_slope;
   a.stats = stats;
   a.N = d->n;
   a.IH = d->ih;
@@ -69,8 +71,8 @@ extern "C" int fsr_conv3x3(const fsr_conv_desc* d, const void* in, const void* p
   a.in_ps = d->in_pixel_shuffled;
   a.out_f32 = d->out_f32;
   if (a.ps && stats) return fsr_fail(-2, "fsr_conv3x3: statistics are not available together with pixel shuffle");
-  if ((stats || preact) && (d->cout % 16 != 0 || (d->out_f32 && d->dtype != FSR_F32)))
-    return fsr_fail(-2, "fsr_conv3x3: statistics / pre-activation outputs need cout %% 16 == 0 and a `dtype` output");
+  if ((stats || preact || dact_mask) && (d->cout % 16 != 0 || (d->out_f32 && d->dtype != FSR_F32)))
+    return fsr_fail(-2, "fsr_conv3x3: statistics / pre-activation / mask tensors need cout %% 16 == 0 and a `dtype` output");
   if (a.ps && (d->cout % 16 != 0)) return fsr_fail(-2, "fsr_conv3x3: pixel shuffle needs cout %% 16 == 0");
   if (a.in_ps && (d->cin % 4 != 0)) return fsr_fail(-2, "fsr_conv3x3: in_pixel_shuffled needs cin %% 4 == 0");
 

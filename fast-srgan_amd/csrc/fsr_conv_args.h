@@ -17,6 +17,8 @@ struct ConvKArgs {
   const float* prelu;   // device scalar, used when act == FSR_ACT_PRELU
   void* preact;         // optional tensor like `out`: receives the pre-activation
   const float* oscale;  // optional [Cout] scale applied to the accumulator before the bias
+  const void* dmask;    // optional tensor like `out`: result *= (dmask > 0 ? 1 : dmask_slope) (fused activation backward)
+  float dmask_slope;
   float* stats;         // optional [N][Cout][2] (sum, sum of squares of the pre-activation)
   int N, IH, IW, Cin;
   int GH, GW;

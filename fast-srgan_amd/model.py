@@ -168,18 +168,29 @@ class VGG19(torch.nn.Module):
         mean, std = [0.485, 0.456, 0.406], [0.229, 0.224, 0.225]
         cd = self.compute
         # (x+1)/2 then (x-mean)/std  ==  x * 1/(2 std) + (0.5-mean)/std, fused into the first conv's input load
-        self._cfg_first = ops.ConvCfg(cd, act=L.ACT_RELU, image_in=True, in_scale=tuple(0.5 / s for s in std),
-                                      in_shift=tuple((0.5 - m) / s for m, s in zip(mean, std)))
-        self._cfg = ops.ConvCfg(cd, act=L.ACT_RELU)
+        scale, shift = tuple(0.5 / s for s in std), tuple((0.5 - m) / s for m, s in zip(mean, std))
+        # Backward plan (the stack is frozen, so no bias gradients exist): every conv's ReLU backward is applied
+        # by its CONSUMER -- the next conv's data-gradient epilogue (mask = its own saved input) or the pool's
+        # backward -- instead of a separate elementwise pass; only the last conv handles its own.
+        mods = list(self.vgg)
+        convs = [i for i, m in enumerate(mods) if isinstance(m, torch.nn.Conv2d)]
+        self._plan = []
+        for k, i in enumerate(convs):
+            prev_is_relu = k > 0 and isinstance(mods[i - 1], torch.nn.ReLU)
+            nxt = mods[i + 2] if i + 2 < len(mods) else None
+            self._plan.append((i, ops.ConvCfg(cd, act=L.ACT_RELU, image_in=(k == 0), in_scale=scale if k == 0 else (1.0, 1.0, 1.0),
+                                              in_shift=shift if k == 0 else (0.0, 0.0, 0.0),
+                                              input_act_bwd=0.0 if prev_is_relu else None,
+                                              act_bwd_by_consumer=nxt is not None),
+                               isinstance(nxt, torch.nn.MaxPool2d)))
 
     def features_nhwc(self, x):
-        y, first = x, True
-        for m in self.vgg:
-            if isinstance(m, torch.nn.Conv2d):
-                y, _ = ops.conv3x3(y, m.weight, m.bias, None, self._cfg_first if first else self._cfg)
-                first = False
-            elif isinstance(m, torch.nn.MaxPool2d):
-                y = ops.maxpool2(y, self.compute)
+        y = x
+        for i, cfg, pool_after in self._plan:
+            m = self.vgg[i]
+            y, _ = ops.conv3x3(y, m.weight, m.bias, None, cfg)
+            if pool_after:
+                y = ops.maxpool2(y, self.compute, relu_mask=True)
         return y
 
     def forward(self, x):

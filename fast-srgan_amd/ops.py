@@ -88,7 +88,7 @@ def _workspace(nbytes, device):
 # ---------------------------------------------------------------------------------- raw launches
 def conv3x3_raw(cd, x, wpk, cout, *, mode=L.CONV_FWD, out_hw=None, stride=1, bias=None, act=L.ACT_NONE, slope=0.0,
                 prelu=None, oscale=None, pixel_shuffle=False, in_pixel_shuffled=False, out_f32=False, want_stats=False,
-                want_preact=False, alg_k=None):
+                want_preact=False, alg_k=None, dact_mask=None, dact_slope=0.0):
     """One fsr_conv3x3 launch.  x: (N,IH,IW,Cin) [or its depth-to-space form when in_pixel_shuffled]."""
     _check_dev(x)
     n = x.shape[0]
@@ -111,8 +111,8 @@ def conv3x3_raw(cd, x, wpk, cout, *, mode=L.CONV_FWD, out_hw=None, stride=1, bia
     if prof is not None:
         ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         ev0.record()
-    L.check(L.lib().fsr_conv3x3(ctypes.byref(d), _p(x), _p(wpk), _p(bias), _p(prelu), _p(oscale), _p(out), _p(pre),
-                                _p(stats), _stream()), "fsr_conv3x3")
+    L.check(L.lib().fsr_conv3x3(ctypes.byref(d), _p(x), _p(wpk), _p(bias), _p(prelu), _p(oscale), _p(dact_mask),
+                                float(dact_slope), _p(out), _p(pre), _p(stats), _stream()), "fsr_conv3x3")
     if prof is not None:
         ev1.record()
         k = cin if alg_k is None else alg_k
@@ -158,7 +158,14 @@ class ConvCfg:
     """Static description of one fused convolution (kept out of autograd's tensor arguments)."""
 
     def __init__(self, cd, *, stride=1, act=L.ACT_NONE, slope=0.0, pixel_shuffle=False, stats=False, image_in=False,
-                 in_scale=(1.0, 1.0, 1.0), in_shift=(0.0, 0.0, 0.0), tanh_head=False):
+                 in_scale=(1.0, 1.0, 1.0), in_shift=(0.0, 0.0, 0.0), tanh_head=False, input_act_bwd=None,
+                 act_bwd_by_consumer=False):
+        # input_act_bwd = slope: the data-gradient launch also applies the backward of the ReLU (0.0) / LeakyReLU
+        #   that produced this conv's input (the mask is the saved input itself), so the tensor it returns is
+        #   already the producer's pre-activation gradient;
+        # act_bwd_by_consumer: the incoming gradient already went through this conv's own activation backward
+        #   (its consumer -- a conv with input_act_bwd or a pool with relu_mask -- did it); frozen layers only.
+        self.input_act_bwd, self.act_bwd_by_consumer = input_act_bwd, act_bwd_by_consumer
         self.cd, self.stride, self.act, self.slope = cd, stride, act, slope
         self.pixel_shuffle, self.stats, self.image_in = pixel_shuffle, stats, image_in
         self.in_scale, self.in_shift, self.tanh_head = in_scale, in_shift, tanh_head
@@ -226,7 +233,11 @@ class Conv3x3Fn(torch.autograd.Function):
                                              st), "fsr_tanh_bwd_to_nhwc")
         else:
             g = g if g.is_contiguous() else g.contiguous()
-            if act != L.ACT_NONE or ctx.has_bias:
+            if cfg.act_bwd_by_consumer:
+                if ctx.needs_input_grad[2]:
+                    raise L.FsrError("act_bwd_by_consumer is for frozen layers (no bias gradient is produced)")
+                dz = g
+            elif act != L.ACT_NONE or ctx.has_bias:
                 if act == L.ACT_PRELU:
                     dprelu = torch.zeros(1, dtype=torch.float32, device=xin.device)
                 dz = torch.empty_like(g)
@@ -246,8 +257,10 @@ class Conv3x3Fn(torch.autograd.Function):
             else:
                 kpad = dz.shape[3] * (4 if cfg.pixel_shuffle else 1)
                 wpk = packed_filter(cd, weight, L.PACK_DGRAD_PS if cfg.pixel_shuffle else L.PACK_DGRAD, kpad)
+                mask = xin if cfg.input_act_bwd is not None else None
                 dx, _, _ = conv3x3_raw(cd, dz, wpk, cin_pad, mode=L.CONV_DGRAD, out_hw=(ih, iw), stride=cfg.stride,
-                                       in_pixel_shuffled=cfg.pixel_shuffle, alg_k=cout)
+                                       in_pixel_shuffled=cfg.pixel_shuffle, alg_k=cout, dact_mask=mask,
+                                       dact_slope=cfg.input_act_bwd or 0.0)
         dw = None
         if ctx.needs_input_grad[1]:
             arena = getattr(weight, "_fsr_grad", None)  # optim.ArenaAdamW: accumulate in place, hand autograd nothing
@@ -303,13 +316,15 @@ def instnorm_act(x, stats, res, prelu, cd, act=L.ACT_NONE, slope=0.0):
 
 # ---------------------------------------------------------------------------------- autograd: MaxPool2d(2,2)
 class MaxPool2Fn(torch.autograd.Function):
+    """relu_mask: backward also applies the backward of the ReLU that produced x (see ConvCfg.act_bwd_by_consumer)."""
+
     @staticmethod
-    def forward(ctx, x, cd):
+    def forward(ctx, x, cd, relu_mask=False):
         _check_dev(x)
         n, h, w, c = x.shape
         y = torch.empty((n, h // 2, w // 2, c), dtype=x.dtype, device=x.device)
         L.check(L.lib().fsr_maxpool2_fwd(cd.code, _p(x), _p(y), n, h, w, c, _stream()), "fsr_maxpool2_fwd")
-        ctx.cd = cd
+        ctx.cd, ctx.relu_mask = cd, relu_mask
         ctx.save_for_backward(x, y)
         return y
 
@@ -319,12 +334,13 @@ class MaxPool2Fn(torch.autograd.Function):
         n, h, w, c = x.shape
         g = g if g.is_contiguous() else g.contiguous()
         dx = torch.empty_like(x)
-        L.check(L.lib().fsr_maxpool2_bwd(ctx.cd.code, _p(g), _p(x), _p(y), _p(dx), n, h, w, c, _stream()), "fsr_maxpool2_bwd")
-        return dx, None
+        L.check(L.lib().fsr_maxpool2_bwd(ctx.cd.code, _p(g), _p(x), _p(y), _p(dx), n, h, w, c, int(ctx.relu_mask), _stream()),
+                "fsr_maxpool2_bwd")
+        return dx, None, None
 
 
-def maxpool2(x, cd):
-    return MaxPool2Fn.apply(x, cd)
+def maxpool2(x, cd, relu_mask=False):
+    return MaxPool2Fn.apply(x, cd, relu_mask)
 
 
 # ---------------------------------------------------------------------------------- autograd: Conv2d(C -> 1, k=1)

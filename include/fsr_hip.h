@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define FSR_ABI_VERSION 2
+#define FSR_ABI_VERSION 3
 
 enum { FSR_F32 = 0, FSR_BF16 = 1 };
 enum { FSR_ACT_NONE = 0, FSR_ACT_RELU = 1, FSR_ACT_LEAKY = 2, FSR_ACT_PRELU = 3, FSR_ACT_TANH = 4 };
@@ -79,7 +79,10 @@ int fsr_pack_conv3x3(int dtype, int mode, const float* w_oihw, int cout, int cin
  * preact (optional): tensor like out; receives the pre-activation (training: PReLU backward
  *   needs its sign, which the output of a negative-slope PReLU does not reveal).
  * oscale (optional): float [cout] multiplied into the result before bias/activation (the
- *   1/(2 std) of VGG19.forward's normalisation, model.py:21-22, applied to input gradients). */
+ *   1/(2 std) of VGG19.forward's normalisation, model.py:21-22, applied to input gradients).
+ * dact_mask (optional): tensor like out; the result is multiplied by (mask > 0 ? 1 : dact_slope).  A
+ *   data-gradient launch uses it to apply the ReLU / LeakyReLU backward of the layer that PRODUCED the
+ *   forward input (mask = that layer's output), saving a separate elementwise pass. */
 typedef struct fsr_conv_desc {
   int dtype;
   int mode;
@@ -94,8 +97,8 @@ typedef struct fsr_conv_desc {
 } fsr_conv_desc;
 
 int fsr_conv3x3(const fsr_conv_desc* desc, const void* in, const void* packed_w, const float* bias,
-                const float* prelu_weight, const float* oscale, void* out, void* preact, float* stats,
-                fsr_stream_t stream);
+                const float* prelu_weight, const float* oscale, const void* dact_mask, float dact_slope, void* out,
+                void* preact, float* stats, fsr_stream_t stream);
 
 /* Weight gradient of the same convolutions: dW[co][ci][ky][kx] (OIHW float, torch .grad layout)
  *   += sum_{n,y,x} dy[n,y,x,co] * x[n, y*stride+ky-1, x*stride+kx-1, ci]      (autograd of model.py convs)
@@ -153,10 +156,11 @@ int fsr_tanh_bwd_to_nhwc(int dtype, const float* g, long long sn, long long sc, 
                          fsr_stream_t stream);
 
 /* ------------------------------------------------------------------ MaxPool2d(2,2) of vgg19.features (model.py:8)
- * x [n,h,w,c] -> y [n,h/2,w/2,c].  Backward routes g to the first maximum in window scan order. */
+ * x [n,h,w,c] -> y [n,h/2,w/2,c].  Backward routes g to the first maximum in window scan order; with
+ * relu_mask != 0 it also applies the backward of the ReLU that produced x (dx = 0 where x <= 0). */
 int fsr_maxpool2_fwd(int dtype, const void* x, void* y, int n, int h, int w, int c, fsr_stream_t stream);
 int fsr_maxpool2_bwd(int dtype, const void* g, const void* x, const void* y, void* dx, int n, int h, int w, int c,
-                     fsr_stream_t stream);
+                     int relu_mask, fsr_stream_t stream);
 
 /* ------------------------------------------------------------------ Discriminator head: Conv2d(512 -> 1, k=1) (model.py:184-186)
  * logits[p] = b + sum_c x[p][c]*w[c]; x [npix,c] `dtype`, logits float.

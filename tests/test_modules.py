@@ -136,7 +136,7 @@ def test_full_size_modules_vs_oracle_gpu(pkg, cdn):
     lg_ref = O.discriminator_forward(dp, sr_ref)
     grads = torch.autograd.grad((lg_ref * r).sum(), list(gp.values()) + list(dp.values()))
     ref = dict(zip([("g", k) for k in gp] + [("d", k) for k in dp], grads))
-    t_out, t_grad = (1e-3, 5e-3) if cdn == "f32" else (6e-2, 0.35)
+    t_out, t_grad = (1e-3, 1e-2) if cdn == "f32" else (6e-2, 0.6)
     assert relerr(sr, sr_ref) < t_out
     assert relerr(logits, lg_ref) < t_out * 2
     for k, p in G.named_parameters():     # L2: see backend.relerr2 on why max-norm is meaningless here
