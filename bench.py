@@ -98,6 +98,7 @@ def main():
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-inference", action="store_true")
+    ap.add_argument("--no-graph", action="store_true", help="eager launches instead of one hipGraph replay per step (N=1)")
     args = ap.parse_args()
 
     pkg = importlib.import_module("fast-srgan_amd")
@@ -125,14 +126,22 @@ def main():
         if world > 1:
             torch.distributed.barrier()
 
+    step_fn, graphed = trainer.train_step, False
+    if world == 1 and not args.no_graph:
+        try:
+            trainer.capture_train_step(lr, hr)
+            step_fn, graphed = trainer.graphed_train_step, True
+        except Exception as exc:  # noqa: BLE001 -- fall back to eager launches and say so in the JSON line
+            print("bench: hipGraph capture failed (%s: %s); running eager" % (type(exc).__name__, exc), file=sys.stderr)
+            torch.cuda.synchronize()
     for _ in range(args.warmup):
-        trainer.train_step(lr, hr)
+        step_fn(lr, hr)
     torch.cuda.synchronize()
     barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        trainer.train_step(lr, hr)
+        step_fn(lr, hr)
     torch.cuda.synchronize()
     barrier()
     elapsed = time.perf_counter() - t0
@@ -159,7 +168,8 @@ def main():
            "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
            "dtype": args.dtype, "data": "synthetic (uniform [-1,1) LR/HR tensors resident in HBM; random-init G/D, kaiming-normal VGG19 stand-in)",
            "config": {"workload": "BASELINE configs[2]: full GAN training step, 8 residual blocks / 64 filters, 96x96->384x384",
-                      "per_gpu_batch": B, "global_batch": B * world, "parallelism": "dp%d" % world},
+                      "per_gpu_batch": B, "global_batch": B * world, "parallelism": "dp%d" % world,
+                      "launch": "hipGraph replay" if graphed else "eager"},
            "step_tflops_equiv": round(value * STEP_GFLOP_PER_IMAGE / 1e3, 2),
            "roofline": roofline}
 

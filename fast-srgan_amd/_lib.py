@@ -66,7 +66,7 @@ SIGNATURES = {
     "fsr_bce_logits_bwd": (c_int, [P, P, P, P, c_ll, P]),
     "fsr_smooth_l1_fwd": (c_int, [c_int, P, P, P, c_ll, P]),
     "fsr_smooth_l1_bwd": (c_int, [c_int, P, P, P, P, c_ll, P]),
-    "fsr_adamw_step": (c_int, [P, P, P, P, c_ll, c_float, c_float, c_float, c_float, c_float, c_int, c_float, P]),
+    "fsr_adamw_step": (c_int, [P, P, P, P, c_ll, c_float, c_float, c_float, c_float, c_float, P, c_float, P]),
     "fsr_crop_resize": (c_int, [P, P, P, P, P, c_int, c_int, c_int, P, P, P, c_int, P, P, P, P]),
 }
 

@@ -66,7 +66,12 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvKArgs a) {
   constexpr int MT = TH / WM;
   constexpr int NT = BN / 16 / WN;
   constexpr int EPB = 16 / (int)sizeof(T);  // elements per 16-byte unit
-  constexpr int PITCH = KC + EPB;
+  // LDS pitches in elements.  ds_read_b128 serves a wave in four 16-lane groups over 16 slots of 16 bytes; a
+  // fragment read puts lane (l&15, l>>4) at slot (l&15)*stride*P + (l>>4) (P = pitch in slots), which is conflict-free
+  // for P = 2 mod 4 when consecutive lanes are consecutive rows (filter rows, stride-1 pixels) and for odd P when
+  // they are every second pixel (stride 2).  A plain +16 B pad (P = 9 for 64 bf16 channels) is 2-way conflicted.
+  constexpr int PITCHW = KC + 2 * EPB;
+  constexpr int PITCHX = KC + (S == 2 ? 1 : 2) * EPB;
   constexpr int UNITS = KC / EPB;
   constexpr int KSTEP = (sizeof(T) == 2) ? 32 : 16;  // channels consumed per operand vector pair
   constexpr int WPT = (BN * UNITS + 255) / 256;
@@ -75,7 +80,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvKArgs a) {
   HIP_DYNAMIC_SHARED(char, smem)
   T* halo = (T*)smem;
   constexpr int HH = (TH - 1) * S + 3, HW = 15 * S + 3;  // halo extent for the full 3x3 footprint (fewer taps use less)
-  T* wl = halo + HH * HW * PITCH;
+  T* wl = halo + HH * HW * PITCHX;
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave / WN, wn = wave % WN;
@@ -131,7 +136,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvKArgs a) {
 #pragma unroll
     for (int i = 0; i < HPT; ++i) {
       const int u = tid + i * 256;
-      if (u < halo_total) *(u32x4*)(halo + (size_t)(u / UNITS) * PITCH + (u % UNITS) * EPB) = hreg[i];
+      if (u < halo_total) *(u32x4*)(halo + (size_t)(u / UNITS) * PITCHX + (u % UNITS) * EPB) = hreg[i];
     }
   };
 
@@ -152,7 +157,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvKArgs a) {
     _Pragma("unroll") for (int i_ = 0; i_ < WPT; ++i_) {                                                \
       const int u_ = tid + i_ * 256;                                                                    \
       if ((BN * UNITS) % 256 == 0 || u_ < BN * UNITS)                                                   \
-        *(u32x4*)(wl + ((size_t)(buf) * BN + (u_ / UNITS)) * PITCH + (u_ % UNITS) * EPB) = wreg[i_];    \
+        *(u32x4*)(wl + ((size_t)(buf) * BN + (u_ / UNITS)) * PITCHW + (u_ % UNITS) * EPB) = wreg[i_];    \
     }                                                                                                   \
   }
 
@@ -164,9 +169,9 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvKArgs a) {
 
   int pixbase[MT], wbase[NT];
 #pragma unroll
-  for (int m = 0; m < MT; ++m) pixbase[m] = (((wm * MT + m) * S) * HW + l15 * S) * PITCH + lg * EPB;
+  for (int m = 0; m < MT; ++m) pixbase[m] = (((wm * MT + m) * S) * HW + l15 * S) * PITCHX + lg * EPB;
 #pragma unroll
-  for (int n = 0; n < NT; ++n) wbase[n] = ((wn * NT + n) * 16 + l15) * PITCH + lg * EPB;
+  for (int n = 0; n < NT; ++n) wbase[n] = ((wn * NT + n) * 16 + l15) * PITCHW + lg * EPB;
 
   halo_issue(0);
   halo_commit();
@@ -182,9 +187,9 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvKArgs a) {
       const bool has_next = !(last_tap && c + 1 == nchunks);
       if (has_next) FSR_WLOAD(last_tap ? 0 : t + 1, last_tap ? c + 1 : c)
 
-      const T* wcur = wl + (size_t)cur * BN * PITCH;
+      const T* wcur = wl + (size_t)cur * BN * PITCHW;
       const unsigned tc = tap_code(a, t);
-      const int toff = ((int)(tc & 3u) * HW + (int)((tc >> 2) & 3u)) * PITCH;
+      const int toff = ((int)(tc & 3u) * HW + (int)((tc >> 2) & 3u)) * PITCHX;
 #pragma unroll
       for (int ks = 0; ks < KC / KSTEP; ++ks) {
         frag_t wf[NT], xf[MT];
@@ -340,7 +345,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvKArgs a) {
 template <typename T, int TH, int BN, int WM, int WN, int KC, int S>
 static int launch_cfg(ConvKArgs& a, hipStream_t stream) {
   constexpr int EPB = 16 / (int)sizeof(T);
-  constexpr int PITCH = KC + EPB;
+  constexpr int PITCHW = KC + 2 * EPB, PITCHX = KC + (S == 2 ? 1 : 2) * EPB;
   if (a.Cin % KC != 0) return fsr_fail(-2, "conv3x3: Cin=%d is not a multiple of the chunk %d", a.Cin, KC);
   if (a.CoutPad % BN != 0) return fsr_fail(-2, "conv3x3: padded Cout=%d is not a multiple of %d", a.CoutPad, BN);
   a.tiles_x = (a.GW + 15) / 16;
@@ -361,7 +366,7 @@ static int launch_cfg(ConvKArgs& a, hipStream_t stream) {
   a.HH = (TH - 1) * S + 3;
   a.HW = 15 * S + 3;
   if (maxdy > 2 || maxdx > 2) return fsr_fail(-2, "conv3x3: tap offsets exceed the 3x3 footprint");
-  const size_t lds = ((size_t)a.HH * a.HW * PITCH + 2 * (size_t)BN * PITCH) * sizeof(T);
+  const size_t lds = ((size_t)a.HH * a.HW * PITCHX + 2 * (size_t)BN * PITCHW) * sizeof(T);
   auto kern = conv_igemm_kernel<T, TH, BN, WM, WN, KC, S>;
   static bool attr_set = false;
   if (!attr_set) {

@@ -181,9 +181,18 @@ __global__ __launch_bounds__(256) void conv1x1_c1_bwd_kernel(const float* __rest
   }
 }
 
+// The step count lives in device memory (a float) so that a captured hipGraph replays correctly: a tick kernel
+// increments it, the update kernel derives the bias corrections from it.
+__global__ void adamw_tick_kernel(float* __restrict__ step) {
+  if (threadIdx.x == 0) step[0] += 1.f;
+}
+
 __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
                                                     float* __restrict__ v, long long count, float lr, float b1, float b2,
-                                                    float eps, float wd, float bc1, float rsqrt_bc2, float gscale) {
+                                                    float eps, float wd, const float* __restrict__ step, float gscale) {
+  const float t = step[0];
+  const float bc1 = 1.f - powf(b1, t);
+  const float rsqrt_bc2 = 1.f / sqrtf(1.f - powf(b2, t));
   for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < count; i += (long long)gridDim.x * 256) {
     const float gi = g[i] * gscale;
     float pi = p[i] * (1.f - lr * wd);
@@ -288,14 +297,13 @@ extern "C" int fsr_conv1x1_c1_bwd(int dtype, const float* g, const void* x, cons
 }
 
 extern "C" int fsr_adamw_step(float* p, const float* g, float* m, float* v, long long count, float lr, float beta1,
-                              float beta2, float eps, float weight_decay, int step, float grad_scale,
+                              float beta2, float eps, float weight_decay, float* step_counter, float grad_scale,
                               fsr_stream_t stream_) {
-  if (!p || !g || !m || !v || count <= 0 || step < 1) return fsr_fail(-1, "fsr_adamw_step: bad argument");
-  const float bc1 = 1.f - powf(beta1, (float)step);
-  const float bc2 = 1.f - powf(beta2, (float)step);
+  if (!p || !g || !m || !v || !step_counter || count <= 0) return fsr_fail(-1, "fsr_adamw_step: bad argument");
+  hipLaunchKernelGGL(adamw_tick_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream_, step_counter);
   long long blocks = (count + 256 * 4 - 1) / (256 * 4);
   if (blocks > 2048) blocks = 2048;
   hipLaunchKernelGGL(adamw_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream_, p, g, m, v, count, lr, beta1,
-                     beta2, eps, weight_decay, bc1, 1.f / sqrtf(bc2), grad_scale);
+                     beta2, eps, weight_decay, step_counter, grad_scale);
   return fsr_check_launch("adamw_kernel");
 }

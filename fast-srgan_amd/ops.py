@@ -72,6 +72,17 @@ def packed_filter(cd, weight, mode, k_pad):
 
 
 _ws = {}
+_const = {}
+
+
+def _const_vec(values, device):
+    """Small float constant vector on `device`, uploaded once (no host-to-device copies inside captured steps)."""
+    key = (tuple(values), str(device))
+    t = _const.get(key)
+    if t is None:
+        t = torch.tensor(values, dtype=torch.float32, device=device)
+        _const[key] = t
+    return t
 
 # bench.py sets this to a list to collect (start_event, end_event, algorithmic_flops) per conv launch
 PROFILE_CONV = None
@@ -250,7 +261,7 @@ class Conv3x3Fn(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             if ctx.x_is_image:
                 wpk = packed_filter(cd, weight, L.PACK_DGRAD, dz.shape[3] * (4 if cfg.pixel_shuffle else 1))
-                osc = torch.tensor(cfg.in_scale, dtype=torch.float32, device=xin.device) if tuple(cfg.in_scale) != (1.0, 1.0, 1.0) else None
+                osc = _const_vec(cfg.in_scale, xin.device) if tuple(cfg.in_scale) != (1.0, 1.0, 1.0) else None
                 dx, _, _ = conv3x3_raw(cd, dz, wpk, 3, mode=L.CONV_DGRAD, out_hw=(ih, iw), stride=cfg.stride, oscale=osc,
                                        out_f32=True, in_pixel_shuffled=cfg.pixel_shuffle, alg_k=cout)
                 dx = dx.permute(0, 3, 1, 2)

@@ -26,7 +26,8 @@ class ArenaAdamW(torch.optim.Optimizer):
         self.flat_grad = torch.zeros(total, dtype=torch.float32, device=dev)
         self.exp_avg = torch.zeros(total, dtype=torch.float32, device=dev)
         self.exp_avg_sq = torch.zeros(total, dtype=torch.float32, device=dev)
-        self.step_count = 0
+        self.step_dev = torch.zeros(1, dtype=torch.float32, device=dev)   # device-side step counter (graph-replay safe)
+        self._epoch = 0
         self.grad_scale = 1.0  # set to 1/world_size when gradients are SUM all-reduced
         off = 0
         self._slices = []
@@ -51,22 +52,22 @@ class ArenaAdamW(torch.optim.Optimizer):
         if closure is not None:
             raise L.FsrError("ArenaAdamW does not take a closure")
         g = self.param_groups[0]
-        self.step_count += 1
+        self._epoch += 1
         L.check(L.lib().fsr_adamw_step(_p(self.flat_param), _p(self.flat_grad), _p(self.exp_avg), _p(self.exp_avg_sq),
                                        self.flat_param.numel(), float(g["lr"]), float(g["betas"][0]), float(g["betas"][1]),
-                                       float(g["eps"]), float(g["weight_decay"]), self.step_count, float(self.grad_scale),
+                                       float(g["eps"]), float(g["weight_decay"]), _p(self.step_dev), float(self.grad_scale),
                                        _stream()), "fsr_adamw_step")
         # the kernel writes through raw pointers, so torch's version counters do not move: publish an
         # epoch the packed-filter cache (ops.packed_filter) keys on instead
         for p in self._params:
-            p._fsr_epoch = self.step_count
+            p._fsr_epoch = self._epoch
 
     def state_dict(self):
         """torch.optim.AdamW-shaped state (per-parameter step / exp_avg / exp_avg_sq), as trainer.py:149-156 saves."""
         state = {}
         for i, (off, n) in enumerate(self._slices):
             shape = self._params[i].shape
-            state[i] = {"step": torch.tensor(float(self.step_count)),
+            state[i] = {"step": self.step_dev.detach().cpu().reshape(()).clone(),
                         "exp_avg": self.exp_avg[off:off + n].view(shape).clone(),
                         "exp_avg_sq": self.exp_avg_sq[off:off + n].view(shape).clone()}
         g = dict(self.param_groups[0])
@@ -80,7 +81,7 @@ class ArenaAdamW(torch.optim.Optimizer):
                 continue
             self.exp_avg[off:off + n].copy_(st["exp_avg"].reshape(-1))
             self.exp_avg_sq[off:off + n].copy_(st["exp_avg_sq"].reshape(-1))
-            self.step_count = int(float(st["step"]))
+            self.step_dev.fill_(float(st["step"]))
         for k in ("lr", "betas", "eps", "weight_decay"):
             if k in sd["param_groups"][0]:
                 self.param_groups[0][k] = sd["param_groups"][0][k]

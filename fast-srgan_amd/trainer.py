@@ -113,6 +113,33 @@ class Trainer:
         return {"loss_real": loss_real.detach(), "loss_fake": loss_fake.detach(),
                 "adv_loss": adv_loss.detach(), "content_loss": content_loss.detach()}
 
+    # ------------------------------------------------------------------ hipGraph replay of the whole iteration
+    def capture_train_step(self, lr_images, hr_images, warmup=2):
+        """Captures one full iteration (both optimizer steps included) into a hipGraph; `graphed_train_step`
+        then replays it with new batch contents: ~500 kernel launches become one graph launch, which removes the
+        host-side launch gaps of the eager loop.  Single-process only (the RCCL exchange stays eager).  Label noise
+        comes from torch's graph-safe Philox generator, so every replay draws fresh numbers."""
+        if D.world_size() > 1:
+            raise RuntimeError("capture_train_step is single-process; data-parallel runs use train_step")
+        self._g_lr, self._g_hr = lr_images.clone(), hr_images.clone()
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):           # warm every lazily created buffer / cache on a side stream
+            for _ in range(warmup):
+                self.train_step(self._g_lr, self._g_hr)
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        self._graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self._graph):
+            self._graph_out = self.train_step(self._g_lr, self._g_hr)
+        return self._graph
+
+    def graphed_train_step(self, lr_images, hr_images):
+        self._g_lr.copy_(lr_images, non_blocking=True)
+        self._g_hr.copy_(hr_images, non_blocking=True)
+        self._graph.replay()
+        return self._graph_out
+
     def pretrain_step(self, lr_images, hr_images):
         """trainer.py:107-111."""
         self.optim_generator.zero_grad()

@@ -184,10 +184,12 @@ int fsr_smooth_l1_bwd(int dtype, const void* a, const void* b, const float* gsca
                       fsr_stream_t stream);
 
 /* ------------------------------------------------------------------ AdamW (trainer.py:33-38, torch defaults)
- * One fused step over a flat float parameter arena: g' = g*grad_scale (1/world_size after a SUM
- * all-reduce); p *= 1 - lr*wd; m, v updated; p -= lr/bc1 * m / (sqrt(v)/sqrt(bc2) + eps). */
+ * One fused step over a flat float parameter arena: g' = g*grad_scale (1/world_size after a SUM all-reduce);
+ * p *= 1 - lr*wd; m, v updated; p -= lr/bc1 * m / (sqrt(v)/sqrt(bc2) + eps).  `step_counter` is a DEVICE float
+ * holding the number of steps taken so far: the call first increments it on the device, then derives the
+ * bias corrections bc1 = 1 - beta1^t, bc2 = 1 - beta2^t from it (host-free, so a captured hipGraph replays). */
 int fsr_adamw_step(float* p, const float* g, float* m, float* v, long long count, float lr, float beta1, float beta2,
-                   float eps, float weight_decay, int step, float grad_scale, fsr_stream_t stream);
+                   float eps, float weight_decay, float* step_counter, float grad_scale, fsr_stream_t stream);
 
 /* ------------------------------------------------------------------ crop + antialiased bicubic down-scale (dataloader.py:24-38)
  * For each of `n` samples: crop hr_size x hr_size at (crop_y[i], crop_x[i]) from the uint8 CHW image

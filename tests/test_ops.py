@@ -231,10 +231,11 @@ def test_losses_and_adamw(dev):
     ref = torch.nn.Parameter(p.clone())
     opt = torch.optim.AdamW([ref], lr=1e-4)
     pd, m, v = p.to(dev), torch.zeros(n, device=dev), torch.zeros(n, device=dev)
+    step_dev = torch.zeros(1, device=dev)
     for step in range(1, 4):
         g = torch.randn(n) * (10.0 ** -step)
         ref.grad = g.clone()
         opt.step()
         L.check(L.lib().fsr_adamw_step(pd.data_ptr(), g.to(dev).data_ptr(), m.data_ptr(), v.data_ptr(), n, 1e-4, 0.9, 0.999,
-                                       1e-8, 0.01, step, 1.0, ops._stream()))
+                                       1e-8, 0.01, step_dev.data_ptr(), 1.0, ops._stream()))
     assert (pd.cpu() - ref.detach()).abs().max() < 1e-6
