@@ -60,9 +60,9 @@ def conv_profile(ops, fn):
     return len(rec), ms, sum(f for _, _, f in rec)
 
 
-def cpu_baseline(seconds_budget=25.0):
+def cpu_baseline():
     """The oracle (CPU restatement of trainer.py:171-196, fp32, torch CPU kernels) on a bounded sample of the same
-    workload: full-size networks, 96 -> 384, batch 1, ONE iteration (the survey measured ~2.5 s per image on 8 cores)."""
+    workload: full-size networks, 96 -> 384, batch 4 (BASELINE configs[0]), 1 warm-up + 3 timed iterations."""
     from oracle import srgan_cpu as O
     pkg = importlib.import_module("fast-srgan_amd")
     torch.manual_seed(0)
@@ -70,7 +70,7 @@ def cpu_baseline(seconds_budget=25.0):
         avail = len(os.sched_getaffinity(0))
     except AttributeError:
         avail = os.cpu_count() or 1
-    cores = max(1, min(avail, 32))   # oneDNN convolutions at batch 1 stop scaling (and thrash) far below 256 threads
+    cores = max(1, min(avail, 32))   # oneDNN convolutions at this batch stop scaling (and thrash) far below 256 threads
     torch.set_num_threads(cores)
     with warnings.catch_warnings():
         warnings.simplefilter("ignore")
@@ -79,14 +79,19 @@ def cpu_baseline(seconds_budget=25.0):
     g_sd = {k: v.detach().clone() for k, v in G.state_dict().items()}
     d_sd = {k: v.detach().clone() for k, v in Dm.state_dict().items()}
     v_sd = O.vgg_standin_state_dict(1234, 1)
-    b = 1
+    b = 4
     lr, hr = torch.rand(b, 3, 96, 96) * 2 - 1, torch.rand(b, 3, 384, 384) * 2 - 1
     noise = [torch.rand(b, 1, 24, 24) for _ in range(3)]
+    gs, ds = {}, {}
+    O.train_step(g_sd, d_sd, v_sd, lr, hr, noise, gs, ds)
     t0 = time.perf_counter()
-    O.train_step(g_sd, d_sd, v_sd, lr, hr, noise, {}, {})
-    dt = time.perf_counter() - t0
+    iters = 3
+    for _ in range(iters):
+        O.train_step(g_sd, d_sd, v_sd, lr, hr, noise, gs, ds)
+    dt = (time.perf_counter() - t0) / iters
     return {"value": round(b / dt, 4), "unit": "images/s", "cores": cores, "kind": "port",
-            "sample": "1 full GAN iteration (oracle/srgan_cpu.train_step), batch %d, 96->384, fp32, %.1f s" % (b, dt)}
+            "sample": "oracle/srgan_cpu.train_step (full GAN iteration, fp32, torch CPU), batch %d, 96->384, "
+                      "1 warm-up + %d timed iterations, %.2f s each" % (b, iters, dt)}
 
 
 def main():

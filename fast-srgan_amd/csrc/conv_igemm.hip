@@ -140,26 +140,32 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvKArgs a) {
     }
   };
 
-  // filter-slice staging registers: global loads for tap t+1 are issued before the MFMAs of tap
-  // t and written to the other LDS buffer after them.
-  u32x4 wreg[WPT];
-#define FSR_WLOAD(tapi, c)                                                                              \
-  {                                                                                                     \
-    const T* base_ = wpk + ((size_t)(tap_code(a, (tapi)) >> 4) * a.CoutPad + (size_t)nb * BN) * a.Cin + (c) * KC; \
-    _Pragma("unroll") for (int i_ = 0; i_ < WPT; ++i_) {                                                \
-      const int u_ = tid + i_ * 256;                                                                    \
-      if ((BN * UNITS) % 256 == 0 || u_ < BN * UNITS)                                                   \
-        wreg[i_] = *(const u32x4*)(base_ + (unsigned)((u_ / UNITS) * a.Cin + (u_ % UNITS) * EPB));      \
-    }                                                                                                   \
-  }
-#define FSR_WSTORE(buf)                                                                                 \
-  {                                                                                                     \
-    _Pragma("unroll") for (int i_ = 0; i_ < WPT; ++i_) {                                                \
-      const int u_ = tid + i_ * 256;                                                                    \
-      if ((BN * UNITS) % 256 == 0 || u_ < BN * UNITS)                                                   \
-        *(u32x4*)(wl + ((size_t)(buf) * BN + (u_ / UNITS)) * PITCHW + (u_ % UNITS) * EPB) = wreg[i_];    \
-    }                                                                                                   \
-  }
+  // Filter-slice staging, prefetch distance TWO steps (a step = one tap of one channel chunk): the global
+  // loads of step s+2 are issued into one of two register sets before the MFMAs of step s and written to the
+  // LDS buffer of step s+2 one step later, after the MFMAs of step s+1 -- two MFMA blocks (>= 1000 cycles) of
+  // cover for an L2 round trip, against one barrier per step.
+  u32x4 wregA[WPT], wregB[WPT];
+  const int nsteps = nchunks * a.ntaps;
+  auto wload = [&](u32x4 (&wr)[WPT], int step) {
+    const int c = step / a.ntaps, t = step - c * a.ntaps;
+    const T* base = wpk + ((size_t)(tap_code(a, t) >> 4) * a.CoutPad + (size_t)nb * BN) * a.Cin + c * KC;
+#pragma unroll
+    for (int i = 0; i < WPT; ++i) {
+      const int u = tid + i * 256;
+      u32x4 v = (u32x4){0u, 0u, 0u, 0u};
+      if ((BN * UNITS) % 256 == 0 || u < BN * UNITS)
+        v = *(const u32x4*)(base + (unsigned)((u / UNITS) * a.Cin + (u % UNITS) * EPB));
+      wr[i] = v;
+    }
+  };
+  auto wstore = [&](const u32x4 (&wr)[WPT], int buf) {
+#pragma unroll
+    for (int i = 0; i < WPT; ++i) {
+      const int u = tid + i * 256;
+      if ((BN * UNITS) % 256 == 0 || u < BN * UNITS)
+        *(u32x4*)(wl + ((size_t)buf * BN + (u / UNITS)) * PITCHW + (u % UNITS) * EPB) = wr[i];
+    }
+  };
 
   f32x4 acc[MT][NT];
 #pragma unroll
@@ -173,49 +179,58 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvKArgs a) {
 #pragma unroll
   for (int n = 0; n < NT; ++n) wbase[n] = ((wn * NT + n) * 16 + l15) * PITCHW + lg * EPB;
 
-  halo_issue(0);
-  halo_commit();
-  FSR_WLOAD(0, 0)
-  FSR_WSTORE(0)
-  __syncthreads();
-
-  int cur = 0;
-  for (int c = 0; c < nchunks; ++c) {
-    if (c + 1 < nchunks) halo_issue(c + 1);
-    for (int t = 0; t < a.ntaps; ++t) {
-      const bool last_tap = (t + 1 == a.ntaps);
-      const bool has_next = !(last_tap && c + 1 == nchunks);
-      if (has_next) FSR_WLOAD(last_tap ? 0 : t + 1, last_tap ? c + 1 : c)
-
-      const T* wcur = wl + (size_t)cur * BN * PITCHW;
-      const unsigned tc = tap_code(a, t);
-      const int toff = ((int)(tc & 3u) * HW + (int)((tc >> 2) & 3u)) * PITCHX;
+  // One step.  P = step parity: LDS buffer P holds this step's filter slice; register set `mine` receives the
+  // loads of step s+2 (same parity), register set `other` holds step s+1's slice, loaded during step s-1.
+  auto step_body = [&](auto parity, int s, int c, int t, u32x4 (&mine)[WPT], u32x4 (&other)[WPT]) {
+    constexpr int P = decltype(parity)::value;
+    if (s + 2 < nsteps) wload(mine, s + 2);
+    if (t == 0 && c + 1 < nchunks) halo_issue(c + 1);
+    const T* wcur = wl + (size_t)P * BN * PITCHW;
+    const unsigned tc = tap_code(a, t);
+    const int toff = ((int)(tc & 3u) * HW + (int)((tc >> 2) & 3u)) * PITCHX;
 #pragma unroll
-      for (int ks = 0; ks < KC / KSTEP; ++ks) {
-        frag_t wf[NT], xf[MT];
+    for (int ks = 0; ks < KC / KSTEP; ++ks) {
+      frag_t wf[NT], xf[MT];
 #pragma unroll
-        for (int n = 0; n < NT; ++n) wf[n] = *(const frag_t*)(wcur + wbase[n] + ks * KSTEP);
+      for (int n = 0; n < NT; ++n) wf[n] = *(const frag_t*)(wcur + wbase[n] + ks * KSTEP);
 #pragma unroll
-        for (int m = 0; m < MT; ++m) xf[m] = *(const frag_t*)(halo + pixbase[m] + toff + ks * KSTEP);
+      for (int m = 0; m < MT; ++m) xf[m] = *(const frag_t*)(halo + pixbase[m] + toff + ks * KSTEP);
 #pragma unroll
-        for (int m = 0; m < MT; ++m)
+      for (int m = 0; m < MT; ++m)
 #pragma unroll
-          for (int n = 0; n < NT; ++n) {
-            if constexpr (sizeof(T) == 2) {
-              acc[m][n] = mfma_bf16_16x16x32(wf[n], xf[m], acc[m][n]);
-            } else {
+        for (int n = 0; n < NT; ++n) {
+          if constexpr (sizeof(T) == 2) {
+            acc[m][n] = mfma_bf16_16x16x32(wf[n], xf[m], acc[m][n]);
+          } else {
 #pragma unroll
-              for (int j = 0; j < 4; ++j) acc[m][n] = mfma_f32_16x16x4(wf[n][j], xf[m][j], acc[m][n]);
-            }
+            for (int j = 0; j < 4; ++j) acc[m][n] = mfma_f32_16x16x4(wf[n][j], xf[m][j], acc[m][n]);
           }
-      }
-      if (has_next) FSR_WSTORE(cur ^ 1)
-      __syncthreads();
-      cur ^= 1;
+        }
     }
-    if (c + 1 < nchunks) {
+    if (s + 1 < nsteps) wstore(other, P ^ 1);
+    __syncthreads();
+    if (t + 1 == a.ntaps && c + 1 < nchunks) {
       halo_commit();
       __syncthreads();
+    }
+  };
+
+  halo_issue(0);
+  halo_commit();
+  wload(wregA, 0);
+  wstore(wregA, 0);
+  if (nsteps > 1) wload(wregB, 1);
+  __syncthreads();
+
+  {
+    int c = 0, t = 0;
+    for (int s = 0; s < nsteps; s += 2) {
+      step_body(std::integral_constant<int, 0>{}, s, c, t, wregA, wregB);
+      if (++t == a.ntaps) { t = 0; ++c; }
+      if (s + 1 < nsteps) {
+        step_body(std::integral_constant<int, 1>{}, s + 1, c, t, wregB, wregA);
+        if (++t == a.ntaps) { t = 0; ++c; }
+      }
     }
   }
 
@@ -337,9 +352,6 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvKArgs a) {
     }
   }
 }
-
-#undef FSR_WLOAD
-#undef FSR_WSTORE
 
 // ---------------------------------------------------------------------------- host side
 template <typename T, int TH, int BN, int WM, int WN, int KC, int S>
