@@ -10,7 +10,7 @@
 // and, with other tap tables, the data-gradients (dgrad) of all of the above.
 //
 // Work decomposition
-//   workgroup (256 threads = 4 waves) -> TH x 16 output pixels of one image x BN output channels
+//   workgroup (WM x WN waves: 4 or 8) -> TH x 16 output pixels of one image x BN output channels
 //   wave                              -> MT pixel rows (16 px each) x NT 16-wide channel tiles
 //   K loop                            -> input-channel chunks of KC; inside a chunk one step per tap
 // LDS images
@@ -61,8 +61,9 @@ __device__ __forceinline__ void store_vec4(T* p, f32x4 v) {
 }
 
 template <typename T, int TH, int BN, int WM, int WN, int KC, int S>
-__global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvKArgs a) {
-  static_assert(WM * WN == 4, "4 waves per workgroup");
+__global__ __launch_bounds__(WM * WN * 64, 2) void conv_igemm_kernel(const ConvKArgs a) {
+  static_assert(WM * WN == 4 || WM * WN == 8, "4 or 8 waves per workgroup");
+  constexpr int NTHR = WM * WN * 64;
   constexpr int MT = TH / WM;
   constexpr int NT = BN / 16 / WN;
   constexpr int EPB = 16 / (int)sizeof(T);  // elements per 16-byte unit
@@ -74,7 +75,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvKArgs a) {
   constexpr int PITCHX = KC + (S == 2 ? 1 : 2) * EPB;
   constexpr int UNITS = KC / EPB;
   constexpr int KSTEP = (sizeof(T) == 2) ? 32 : 16;  // channels consumed per operand vector pair
-  constexpr int WPT = (BN * UNITS + 255) / 256;
+  constexpr int WPT = (BN * UNITS + NTHR - 1) / NTHR;
   typedef typename Frag<T>::type frag_t;
 
   HIP_DYNAMIC_SHARED(char, smem)
@@ -104,12 +105,12 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvKArgs a) {
   // registers at the start of chunk c and written to LDS after its last tap, so their latency hides
   // under a whole chunk of MFMAs instead of stalling every workgroup once per chunk.
   constexpr int halo_total = HH * HW * UNITS;
-  constexpr int HPT = (halo_total + 255) / 256;  // 16-byte units per thread
+  constexpr int HPT = (halo_total + NTHR - 1) / NTHR;  // 16-byte units per thread
   u32x4 hreg[HPT];
   auto halo_issue = [&](int c) {
 #pragma unroll
     for (int i = 0; i < HPT; ++i) {
-      const int u = tid + i * 256;
+      const int u = tid + i * NTHR;
       u32x4 v = (u32x4){0u, 0u, 0u, 0u};
       if (u < halo_total) {
         const int unit = u % UNITS;
@@ -135,7 +136,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvKArgs a) {
   auto halo_commit = [&]() {
 #pragma unroll
     for (int i = 0; i < HPT; ++i) {
-      const int u = tid + i * 256;
+      const int u = tid + i * NTHR;
       if (u < halo_total) *(u32x4*)(halo + (size_t)(u / UNITS) * PITCHX + (u % UNITS) * EPB) = hreg[i];
     }
   };
@@ -151,9 +152,9 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvKArgs a) {
     const T* base = wpk + ((size_t)(tap_code(a, t) >> 4) * a.CoutPad + (size_t)nb * BN) * a.Cin + c * KC;
 #pragma unroll
     for (int i = 0; i < WPT; ++i) {
-      const int u = tid + i * 256;
+      const int u = tid + i * NTHR;
       u32x4 v = (u32x4){0u, 0u, 0u, 0u};
-      if ((BN * UNITS) % 256 == 0 || u < BN * UNITS)
+      if ((BN * UNITS) % NTHR == 0 || u < BN * UNITS)
         v = *(const u32x4*)(base + (unsigned)((u / UNITS) * a.Cin + (u % UNITS) * EPB));
       wr[i] = v;
     }
@@ -161,8 +162,8 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvKArgs a) {
   auto wstore = [&](const u32x4 (&wr)[WPT], int buf) {
 #pragma unroll
     for (int i = 0; i < WPT; ++i) {
-      const int u = tid + i * 256;
-      if ((BN * UNITS) % 256 == 0 || u < BN * UNITS)
+      const int u = tid + i * NTHR;
+      if ((BN * UNITS) % NTHR == 0 || u < BN * UNITS)
         *(u32x4*)(wl + ((size_t)buf * BN + (u / UNITS)) * PITCHW + (u % UNITS) * EPB) = wr[i];
     }
   };
@@ -240,7 +241,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvKArgs a) {
   if (a.act == FSR_ACT_RELU) slope = 0.f;
   float* sred = (float*)smem;  // [BN][2] statistics of this workgroup (reuses the halo image)
   if (a.stats) {               // the main loop ended on a barrier: every wave is done with LDS
-    for (int i = tid; i < 2 * BN; i += 256) sred[i] = 0.f;
+    for (int i = tid; i < 2 * BN; i += NTHR) sred[i] = 0.f;
     __syncthreads();
   }
   const int gx = gx0 + l15;
@@ -346,7 +347,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvKArgs a) {
   });
   if (a.stats) {
     __syncthreads();
-    for (int i = tid; i < 2 * BN; i += 256) {
+    for (int i = tid; i < 2 * BN; i += NTHR) {
       const int co = nb * BN + (i >> 1);
       if (co < a.Cout) atomicAdd(a.stats + ((size_t)img * a.Cout + co) * 2 + (i & 1), sred[i]);
     }
@@ -382,14 +383,14 @@ static int launch_cfg(ConvKArgs& a, hipStream_t stream) {
   auto kern = conv_igemm_kernel<T, TH, BN, WM, WN, KC, S>;
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+    (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
     attr_set = true;
   }
   if ((long long)a.N * a.IH * a.IW * a.Cin >= (1LL << 31) || (long long)a.N * a.FOH * a.FOW * a.Cout >= (1LL << 31))
     return fsr_fail(-2, "conv3x3: tensors with 2^31 or more elements are not supported");
   const long long nwg = (long long)a.tiles_x * a.tiles_y * a.N * a.nblk_n;
   if (nwg <= 0 || nwg > 0x7fffffffLL) return fsr_fail(-2, "conv3x3: bad grid");
-  hipLaunchKernelGGL(kern, dim3((unsigned)nwg), dim3(256), lds, stream, a);
+  hipLaunchKernelGGL(kern, dim3((unsigned)nwg), dim3(WM * WN * 64), lds, stream, a);
   return fsr_check_launch("conv_igemm_kernel");
 }
 
@@ -402,12 +403,15 @@ static int dispatch_T(ConvKArgs& a, int S, hipStream_t stream) {
   const bool wide = (a.Cin % KCW == 0);
   if (a.CoutPad % 128 == 0) {
     if (S == 2) return launch_cfg<T, 8, 128, 2, 2, KCN, 2>(a, stream);
-    if (wide) return launch_cfg<T, 8, 128, 2, 2, KCW, 1>(a, stream);
+    // 8 waves share one filter slice over 16x16 pixels: half the filter traffic (L2 -> LDS) per FLOP of two
+    // 4-wave workgroups, same occupancy (one workgroup per CU instead of two)
+    if (wide) return th8 ? launch_cfg<T, 8, 128, 2, 2, KCW, 1>(a, stream) : launch_cfg<T, 16, 128, 4, 2, KCW, 1>(a, stream);
     return launch_cfg<T, 8, 128, 2, 2, KCN, 1>(a, stream);
   }
   if (a.CoutPad % 64 == 0) {
     if (S == 2) return launch_cfg<T, 8, 64, 2, 2, KCN, 2>(a, stream);
     if (th8) return wide ? launch_cfg<T, 8, 64, 2, 2, KCW, 1>(a, stream) : launch_cfg<T, 8, 64, 2, 2, KCN, 1>(a, stream);
+    if (wide && ((a.GH + 31) / 32) * 32 - a.GH < 8) return launch_cfg<T, 32, 64, 8, 1, KCW, 1>(a, stream);  // 8 waves, 32x16 pixels
     if (wide) return launch_cfg<T, 16, 64, 4, 1, KCW, 1>(a, stream);
     return launch_cfg<T, 16, 64, 4, 1, KCN, 1>(a, stream);
   }
