@@ -33,6 +33,9 @@ sys.path.insert(0, ROOT)
 
 MFMA_PEAK_TFLOPS = {"bf16": 2500.0, "f32": 157.3}   # /opt/skills/guides/MI355X_MICROARCH.md, dense
 STEP_GFLOP_PER_IMAGE = 686.71                         # BASELINE.md section 2, as the reference graph executes it
+# HBM bytes per conv launch (forward + data-gradient calls of one iteration, batch 32, bf16) from the PMC counters:
+# 168 kernel launches per iteration x (2 x 81344 KB FETCH_SIZE + 137348 KB WRITE_SIZE) / 132 API-level launches
+CONV_HBM_BYTES_PER_LAUNCH = 3.91e8
 
 
 def ns(**k):
@@ -48,7 +51,7 @@ def make_config(batch, dtype, device):
 
 def conv_profile(ops, fn):
     """Runs fn() with every conv3x3 forward/dgrad launch bracketed by HIP events on the launch stream.
-    Returns (launches, total_ms, total_flops)."""
+    Returns (launches, total_ms, total_flops, total_algorithmic_bytes)."""
     rec = []
     ops.PROFILE_CONV = rec
     try:
@@ -56,8 +59,8 @@ def conv_profile(ops, fn):
         torch.cuda.synchronize()
     finally:
         ops.PROFILE_CONV = None
-    ms = sum(s.elapsed_time(e) for s, e, _ in rec)
-    return len(rec), ms, sum(f for _, _, f in rec)
+    ms = sum(r[0].elapsed_time(r[1]) for r in rec)
+    return len(rec), ms, sum(r[2] for r in rec), sum(r[3] for r in rec)
 
 
 def cpu_baseline():
@@ -158,12 +161,15 @@ def main():
     value = world * B * args.steps / elapsed
 
     # ---- roofline of the dominant kernel: one instrumented iteration (outside the timed region)
-    launches, conv_ms, conv_flops = conv_profile(ops, lambda: trainer.train_step(lr, hr))
+    launches, conv_ms, conv_flops, conv_bytes = conv_profile(ops, lambda: trainer.train_step(lr, hr))
     achieved = conv_flops / (conv_ms * 1e-3) / 1e12 if conv_ms > 0 else 0.0
     peak = MFMA_PEAK_TFLOPS[args.dtype]
     roofline = {"bound": "mfma", "kernel": "conv_igemm_kernel (3x3 conv forward + data-gradient launches)",
                 "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(achieved / peak, 4),
-                "traffic": None, "launches_per_step": launches,
+                "traffic": CONV_HBM_BYTES_PER_LAUNCH if (args.dtype == "bf16" and B == 32) else None,
+                "traffic_source": "rocprofv3 --pmc FETCH_SIZE (x2, gfx950 correction) + WRITE_SIZE over one iteration, "
+                                  "profiles/r01_pmc_*_train_step.csv",
+                "algorithmic_bytes_per_launch": round(conv_bytes / max(launches, 1)), "launches_per_step": launches,
                 "avg_launch_us": round(conv_ms * 1e3 / max(launches, 1), 2),
                 "algorithmic_gflop_per_launch": round(conv_flops / max(launches, 1) / 1e9, 3),
                 "share_of_step_time": round(conv_ms / ms_per_step, 3)}

@@ -403,15 +403,14 @@ static int dispatch_T(ConvKArgs& a, int S, hipStream_t stream) {
   const bool wide = (a.Cin % KCW == 0);
   if (a.CoutPad % 128 == 0) {
     if (S == 2) return launch_cfg<T, 8, 128, 2, 2, KCN, 2>(a, stream);
-    // 8 waves share one filter slice over 16x16 pixels: half the filter traffic (L2 -> LDS) per FLOP of two
-    // 4-wave workgroups, same occupancy (one workgroup per CU instead of two)
-    if (wide) return th8 ? launch_cfg<T, 8, 128, 2, 2, KCW, 1>(a, stream) : launch_cfg<T, 16, 128, 4, 2, KCW, 1>(a, stream);
+    // (8-wave variants <16,128,4,2> / <32,64,8,1> halve the filter traffic per FLOP but measured 5-10 % slower:
+    // one workgroup per CU means every wave waits at the same barriers; two independent 4-wave workgroups overlap)
+    if (wide) return launch_cfg<T, 8, 128, 2, 2, KCW, 1>(a, stream);
     return launch_cfg<T, 8, 128, 2, 2, KCN, 1>(a, stream);
   }
   if (a.CoutPad % 64 == 0) {
     if (S == 2) return launch_cfg<T, 8, 64, 2, 2, KCN, 2>(a, stream);
     if (th8) return wide ? launch_cfg<T, 8, 64, 2, 2, KCW, 1>(a, stream) : launch_cfg<T, 8, 64, 2, 2, KCN, 1>(a, stream);
-    if (wide && ((a.GH + 31) / 32) * 32 - a.GH < 8) return launch_cfg<T, 32, 64, 8, 1, KCW, 1>(a, stream);  // 8 waves, 32x16 pixels
     if (wide) return launch_cfg<T, 16, 64, 4, 1, KCW, 1>(a, stream);
     return launch_cfg<T, 16, 64, 4, 1, KCN, 1>(a, stream);
   }

@@ -84,7 +84,7 @@ def _const_vec(values, device):
         _const[key] = t
     return t
 
-# bench.py sets this to a list to collect (start_event, end_event, algorithmic_flops) per conv launch
+# bench.py sets this to a list to collect (start_event, end_event, algorithmic_flops, algorithmic_bytes) per conv launch
 PROFILE_CONV = None
 
 
@@ -128,7 +128,8 @@ def conv3x3_raw(cd, x, wpk, cout, *, mode=L.CONV_FWD, out_hw=None, stride=1, bia
         ev1.record()
         k = cin if alg_k is None else alg_k
         pix = oh * ow if mode == L.CONV_FWD else ih * iw      # dgrad: one MAC per forward MAC
-        prof.append((ev0, ev1, 2.0 * n * pix * cout * k * 9))
+        nbytes = x.numel() * x.element_size() + out.numel() * out.element_size() + wpk.numel() * wpk.element_size()
+        prof.append((ev0, ev1, 2.0 * n * pix * cout * k * 9, nbytes))
     return out, pre, stats
 
 

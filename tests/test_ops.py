@@ -239,19 +239,3 @@ def test_losses_and_adamw(dev):
         L.check(L.lib().fsr_adamw_step(pd.data_ptr(), g.to(dev).data_ptr(), m.data_ptr(), v.data_ptr(), n, 1e-4, 0.9, 0.999,
                                        1e-8, 0.01, step_dev.data_ptr(), 1.0, ops._stream()))
     assert (pd.cpu() - ref.detach()).abs().max() < 1e-6
-
-
-@pytest.mark.parametrize("cdn", ["f32", "bf16"])
-@pytest.mark.parametrize("cin,cout,h,w", [(64, 128, 16, 16), (64, 64, 32, 16)])
-def test_conv_8wave_configs(dev, cdn, cin, cout, h, w):
-    """Shapes that select the 8-wave workgroup configurations (16x16 px x 128 co, 32x16 px x 64 co)."""
-    cd = ops.Compute(cdn)
-    torch.manual_seed(8)
-    n = 2 if _big(dev) else 1
-    x = _q(torch.randn(n, cin, h, w), cd)
-    wt = _q(torch.randn(cout, cin, 3, 3) * 0.1, cd)
-    wpk = ops.packed_filter(cd, wt.to(dev), L.PACK_FWD, cin)
-    y, _, stats = ops.conv3x3_raw(cd, _nhwc(x, cd, dev), wpk, cout, want_stats=True)
-    ref = F.conv2d(x, wt, None, 1, 1)
-    assert relerr(_nchw(y), ref) < tol(cdn, 1e-5, 1e-2)
-    assert relerr(stats.cpu()[..., 1], (ref * ref).sum((2, 3))) < tol(cdn, 1e-4, 1e-3)
