@@ -57,6 +57,19 @@ __device__ __forceinline__ float act_dz(float z, int act, float slope) {
   return z > 0.f ? 1.f : slope;
 }
 
+// blocks along x for a (blocks, images) grid: about 2048 workgroups in total, each thread doing >= 1 unit
+inline int image_blocks(long long units_per_image, int n) {
+  long long b = (units_per_image + 255) / 256;
+  const long long cap = (2048 + n - 1) / n;
+  if (b > cap) b = cap;
+  return b < 1 ? 1 : (int)b;
+}
+
+inline int row_blocks(int units_per_row) {
+  int b = (units_per_row + 255) / 256;
+  return b < 1 ? 1 : (b > 64 ? 64 : b);
+}
+
 inline int capped_blocks(long long work_items, int per_block) {
   long long b = (work_items + per_block - 1) / per_block;
   if (b > 256 * 8) b = 256 * 8;  // 8 workgroups of 256 threads per CU, grid-stride the rest
@@ -65,30 +78,41 @@ inline int capped_blocks(long long work_items, int per_block) {
 }
 
 // ------------------------------------------------------------------ InstanceNorm apply
+// Grid = (pixel blocks, images).  256 % (c / E) == 0 (host checked), so a thread keeps ONE channel unit for its
+// whole grid-stride walk: mean / rstd of its E channels are computed once, and the loop body is two 16-byte
+// loads, E fmas and one 16-byte store -- no integer division, no per-element rsqrt.
 template <typename T>
 __global__ __launch_bounds__(256) void instnorm_act_fwd_kernel(const T* __restrict__ x, const float* __restrict__ stats,
                                                                const T* __restrict__ res, int act, float slope_in,
                                                                const float* __restrict__ prelu, T* __restrict__ out,
-                                                               long long units, int hw, int c) {
+                                                               int hw, int c) {
   constexpr int E = V16<T>::N;
   const int cu = c / E;
-  const float slope = (act == FSR_ACT_PRELU) ? prelu[0] : slope_in;
+  const int n = blockIdx.y;
+  const float slope = (act == FSR_ACT_PRELU) ? prelu[0] : (act == FSR_ACT_NONE ? 1.f : (act == FSR_ACT_RELU ? 0.f : slope_in));
   const float inv = 1.f / (float)hw;
-  for (long long u = (long long)blockIdx.x * 256 + threadIdx.x; u < units; u += (long long)gridDim.x * 256) {
-    const int c0 = (int)(u % cu) * E;
-    const int n = (int)(u / ((long long)cu * hw));
-    const float* st = stats + ((size_t)n * c + c0) * 2;
-    float v[E], r[E];
-    V16<T>::ld(x + u * E, v);
-    if (res) V16<T>::ld(res + u * E, r);
+  const int unit = threadIdx.x % cu;
+  float mean[E], rstd[E];
+  {
+    const float* st = stats + ((size_t)n * c + unit * E) * 2;
 #pragma unroll
     for (int i = 0; i < E; ++i) {
-      const float mean = st[2 * i] * inv;
-      const float var = fmaxf(st[2 * i + 1] * inv - mean * mean, 0.f);
-      const float z = (v[i] - mean) * rsqrtf(var + kEps);
-      v[i] = act_fwd(z, act, slope) + (res ? r[i] : 0.f);
+      mean[i] = st[2 * i] * inv;
+      rstd[i] = rsqrtf(fmaxf(st[2 * i + 1] * inv - mean[i] * mean[i], 0.f) + kEps);
     }
-    V16<T>::st(out + u * E, v);
+  }
+  const unsigned units = (unsigned)hw * cu;          // per image
+  const size_t img = (size_t)n * units * E;
+  for (unsigned u = blockIdx.x * 256 + threadIdx.x; u < units; u += gridDim.x * 256) {
+    float v[E], r[E];
+    V16<T>::ld(x + img + (size_t)u * E, v);
+    if (res) V16<T>::ld(res + img + (size_t)u * E, r);
+#pragma unroll
+    for (int i = 0; i < E; ++i) {
+      const float z = (v[i] - mean[i]) * rstd[i];
+      v[i] = fmaxf(z, 0.f) + slope * fminf(z, 0.f) + (res ? r[i] : 0.f);
+    }
+    V16<T>::st(out + img + (size_t)u * E, v);
   }
 }
 
@@ -164,28 +188,38 @@ __global__ __launch_bounds__(256) void instnorm_act_bwd_apply_kernel(const T* __
                                                                      const float* __restrict__ stats,
                                                                      const float* __restrict__ sums, int act,
                                                                      float slope_in, const float* __restrict__ prelu,
-                                                                     T* __restrict__ dx, long long units, int hw, int c) {
+                                                                     T* __restrict__ dx, int hw, int c) {
   constexpr int E = V16<T>::N;
   const int cu = c / E;
-  const float slope = (act == FSR_ACT_PRELU) ? prelu[0] : slope_in;
+  const int n = blockIdx.y;
+  const float slope = (act == FSR_ACT_PRELU) ? prelu[0] : (act == FSR_ACT_NONE ? 1.f : (act == FSR_ACT_RELU ? 0.f : slope_in));
   const float inv = 1.f / (float)hw;
-  for (long long u = (long long)blockIdx.x * 256 + threadIdx.x; u < units; u += (long long)gridDim.x * 256) {
-    const int c0 = (int)(u % cu) * E;
-    const int n = (int)(u / ((long long)cu * hw));
-    const float* st = stats + ((size_t)n * c + c0) * 2;
-    const float* sm = sums + ((size_t)n * c + c0) * 2;
-    float gv[E], xv[E];
-    V16<T>::ld(g + u * E, gv);
-    V16<T>::ld(x + u * E, xv);
+  const int unit = threadIdx.x % cu;
+  float mean[E], rstd[E], m1[E], m2[E];
+  {
+    const float* st = stats + ((size_t)n * c + unit * E) * 2;
+    const float* sm = sums + ((size_t)n * c + unit * E) * 2;
 #pragma unroll
     for (int i = 0; i < E; ++i) {
-      const float mean = st[2 * i] * inv;
-      const float rstd = rsqrtf(fmaxf(st[2 * i + 1] * inv - mean * mean, 0.f) + kEps);
-      const float xh = (xv[i] - mean) * rstd;
-      const float gz = gv[i] * act_dz(xh, act, slope);
-      xv[i] = rstd * (gz - sm[2 * i] * inv - xh * sm[2 * i + 1] * inv);
+      mean[i] = st[2 * i] * inv;
+      rstd[i] = rsqrtf(fmaxf(st[2 * i + 1] * inv - mean[i] * mean[i], 0.f) + kEps);
+      m1[i] = sm[2 * i] * inv;
+      m2[i] = sm[2 * i + 1] * inv;
     }
-    V16<T>::st(dx + u * E, xv);
+  }
+  const unsigned units = (unsigned)hw * cu;
+  const size_t img = (size_t)n * units * E;
+  for (unsigned u = blockIdx.x * 256 + threadIdx.x; u < units; u += gridDim.x * 256) {
+    float gv[E], xv[E];
+    V16<T>::ld(g + img + (size_t)u * E, gv);
+    V16<T>::ld(x + img + (size_t)u * E, xv);
+#pragma unroll
+    for (int i = 0; i < E; ++i) {
+      const float xh = (xv[i] - mean[i]) * rstd[i];
+      const float gz = gv[i] * (xh > 0.f ? 1.f : slope);
+      xv[i] = rstd[i] * (gz - m1[i] - xh * m2[i]);
+    }
+    V16<T>::st(dx + img + (size_t)u * E, xv);
   }
 }
 
@@ -264,53 +298,57 @@ __global__ __launch_bounds__(256) void act_bwd_kernel(const T* __restrict__ g, c
 }
 
 // ------------------------------------------------------------------ 3-channel images <-> padded NHWC
+// Grid = (image rows n*h, column blocks): all index arithmetic is 32-bit and per row.
 template <typename T>
 __global__ __launch_bounds__(256) void image_to_nhwc_kernel(const float* __restrict__ img, long long sn, long long sc,
                                                             long long sh, long long sw, int h, int w, float a0, float a1,
                                                             float a2, float b0, float b1, float b2, T* __restrict__ out,
-                                                            int cpad, long long npix) {
+                                                            int cpad) {
   constexpr int E = V16<T>::N;
   const int upp = cpad / E;  // 16-byte units per pixel
-  for (long long u = (long long)blockIdx.x * 256 + threadIdx.x; u < npix * upp; u += (long long)gridDim.x * 256) {
-    const long long p = u / upp;
-    const int un = (int)(u % upp);
+  const int row = blockIdx.x;
+  const int n = row / h, y = row - n * h;
+  const float* src = img + n * sn + y * sh;
+  T* dst = out + (size_t)row * w * cpad;
+  const unsigned units = (unsigned)w * upp;
+  for (unsigned u = blockIdx.y * 256 + threadIdx.x; u < units; u += gridDim.y * 256) {
+    const unsigned x = u / upp, un = u - x * upp;
     float v[E];
 #pragma unroll
     for (int i = 0; i < E; ++i) v[i] = 0.f;
     if (un == 0) {
-      const int x = (int)(p % w);
-      const int y = (int)((p / w) % h);
-      const long long n = p / ((long long)w * h);
-      const float* s = img + n * sn + y * sh + x * sw;
+      const float* s = src + x * sw;
       v[0] = s[0] * a0 + b0;
       v[1] = s[sc] * a1 + b1;
       v[2] = s[2 * sc] * a2 + b2;
     }
-    V16<T>::st(out + u * E, v);
+    V16<T>::st(dst + (size_t)u * E, v);
   }
 }
 
 template <typename T>
 __global__ __launch_bounds__(256) void tanh_bwd_to_nhwc_kernel(const float* __restrict__ g, long long sn, long long sc,
                                                                long long sh, long long sw, const float* __restrict__ y,
-                                                               int h, int w, T* __restrict__ dz, int cpad, long long npix,
+                                                               int h, int w, T* __restrict__ dz, int cpad,
                                                                float* __restrict__ dbias) {
   constexpr int E = V16<T>::N;
   __shared__ float red[3][4];
   const int upp = cpad / E;
+  const int row = blockIdx.x;
+  const int n = row / h, yy = row - n * h;
+  const float* src = g + n * sn + yy * sh;
+  const float* ty = y + (size_t)row * w * 3;
+  T* dst = dz + (size_t)row * w * cpad;
+  const unsigned units = (unsigned)w * upp;
   float b0 = 0.f, b1 = 0.f, b2 = 0.f;
-  for (long long u = (long long)blockIdx.x * 256 + threadIdx.x; u < npix * upp; u += (long long)gridDim.x * 256) {
-    const long long p = u / upp;
-    const int un = (int)(u % upp);
+  for (unsigned u = blockIdx.y * 256 + threadIdx.x; u < units; u += gridDim.y * 256) {
+    const unsigned x = u / upp, un = u - x * upp;
     float v[E];
 #pragma unroll
     for (int i = 0; i < E; ++i) v[i] = 0.f;
     if (un == 0) {
-      const int x = (int)(p % w);
-      const int yy = (int)((p / w) % h);
-      const long long n = p / ((long long)w * h);
-      const float* s = g + n * sn + yy * sh + x * sw;
-      const float* t = y + p * 3;
+      const float* s = src + x * sw;
+      const float* t = ty + x * 3;
       v[0] = s[0] * (1.f - t[0] * t[0]);
       v[1] = s[sc] * (1.f - t[1] * t[1]);
       v[2] = s[2 * sc] * (1.f - t[2] * t[2]);
@@ -318,7 +356,7 @@ __global__ __launch_bounds__(256) void tanh_bwd_to_nhwc_kernel(const float* __re
       b1 += v[1];
       b2 += v[2];
     }
-    V16<T>::st(dz + u * E, v);
+    V16<T>::st(dst + (size_t)u * E, v);
   }
   if (dbias) {
     b0 = wave_sum(b0);
@@ -335,65 +373,63 @@ __global__ __launch_bounds__(256) void tanh_bwd_to_nhwc_kernel(const float* __re
 }
 
 // ------------------------------------------------------------------ MaxPool2d(2,2)
+// Grid = (output rows n*oh, column blocks); 32-bit index arithmetic per row.
 template <typename T>
-__global__ __launch_bounds__(256) void maxpool2_fwd_kernel(const T* __restrict__ x, T* __restrict__ y, int h, int w, int c,
-                                                           long long units) {
+__global__ __launch_bounds__(256) void maxpool2_fwd_kernel(const T* __restrict__ x, T* __restrict__ y, int h, int w, int c) {
   constexpr int E = V16<T>::N;
   const int cu = c / E, oh = h / 2, ow = w / 2;
-  for (long long u = (long long)blockIdx.x * 256 + threadIdx.x; u < units; u += (long long)gridDim.x * 256) {
-    const int un = (int)(u % cu);
-    long long p = u / cu;
-    const int ox = (int)(p % ow);
-    p /= ow;
-    const int oy = (int)(p % oh);
-    const long long n = p / oh;
-    const T* s = x + ((n * h + 2 * oy) * w + 2 * ox) * (long long)c + un * E;
-    float a[E], b[E];
+  const int row = blockIdx.x;
+  const int n = row / oh, oy = row - n * oh;
+  const T* src = x + ((size_t)n * h + 2 * oy) * w * c;
+  T* dst = y + (size_t)row * ow * c;
+  const unsigned units = (unsigned)ow * cu;
+  const size_t rs = (size_t)w * c;
+  for (unsigned u = blockIdx.y * 256 + threadIdx.x; u < units; u += gridDim.y * 256) {
+    const unsigned ox = u / cu, un = u - ox * cu;
+    const T* s = src + (size_t)(2 * ox) * c + un * E;
+    float a[E], b[E], d[E], e[E];
     V16<T>::ld(s, a);
     V16<T>::ld(s + c, b);
+    V16<T>::ld(s + rs, d);
+    V16<T>::ld(s + rs + c, e);
 #pragma unroll
-    for (int i = 0; i < E; ++i) a[i] = fmaxf(a[i], b[i]);
-    V16<T>::ld(s + (long long)w * c, b);
-#pragma unroll
-    for (int i = 0; i < E; ++i) a[i] = fmaxf(a[i], b[i]);
-    V16<T>::ld(s + (long long)w * c + c, b);
-#pragma unroll
-    for (int i = 0; i < E; ++i) a[i] = fmaxf(a[i], b[i]);
-    V16<T>::st(y + u * E, a);
+    for (int i = 0; i < E; ++i) a[i] = fmaxf(fmaxf(a[i], b[i]), fmaxf(d[i], e[i]));
+    V16<T>::st(dst + (size_t)u * E, a);
   }
 }
 
 template <typename T>
 __global__ __launch_bounds__(256) void maxpool2_bwd_kernel(const T* __restrict__ g, const T* __restrict__ x,
                                                            const T* __restrict__ y, T* __restrict__ dx, int h, int w, int c,
-                                                           long long units, int relu_mask) {
+                                                           int relu_mask) {
   constexpr int E = V16<T>::N;
   const int cu = c / E, oh = h / 2, ow = w / 2;
-  for (long long u = (long long)blockIdx.x * 256 + threadIdx.x; u < units; u += (long long)gridDim.x * 256) {
-    const int un = (int)(u % cu);
-    long long p = u / cu;
-    const int ox = (int)(p % ow);
-    p /= ow;
-    const int oy = (int)(p % oh);
-    const long long n = p / oh;
-    const long long base = ((n * h + 2 * oy) * w + 2 * ox) * (long long)c + un * E;
-    float gv[E], yv[E], xv[E], o[E];
+  const int row = blockIdx.x;
+  const int n = row / oh, oy = row - n * oh;
+  const size_t in0 = ((size_t)n * h + 2 * oy) * w * c;
+  const size_t out0 = (size_t)row * ow * c;
+  const unsigned units = (unsigned)ow * cu;
+  const size_t rs = (size_t)w * c;
+  for (unsigned u = blockIdx.y * 256 + threadIdx.x; u < units; u += gridDim.y * 256) {
+    const unsigned ox = u / cu, un = u - ox * cu;
+    const size_t base = in0 + (size_t)(2 * ox) * c + un * E;
+    float gv[E], yv[E], xv[4][E], o[E];
     bool taken[E];
-    V16<T>::ld(g + u * E, gv);
-    V16<T>::ld(y + u * E, yv);
+    V16<T>::ld(g + out0 + (size_t)u * E, gv);
+    V16<T>::ld(y + out0 + (size_t)u * E, yv);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) V16<T>::ld(x + base + (size_t)(k >> 1) * rs + (k & 1) * c, xv[k]);
 #pragma unroll
     for (int i = 0; i < E; ++i) taken[i] = false;
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-      const long long off = base + (long long)(k >> 1) * w * c + (k & 1) * c;
-      V16<T>::ld(x + off, xv);
 #pragma unroll
       for (int i = 0; i < E; ++i) {
-        const bool hit = !taken[i] && xv[i] == yv[i];
-        o[i] = (hit && !(relu_mask && xv[i] <= 0.f)) ? gv[i] : 0.f;
+        const bool hit = !taken[i] && xv[k][i] == yv[i];
+        o[i] = (hit && !(relu_mask && xv[k][i] <= 0.f)) ? gv[i] : 0.f;
         taken[i] = taken[i] || hit;
       }
-      V16<T>::st(dx + off, o);
+      V16<T>::st(dx + base + (size_t)(k >> 1) * rs + (k & 1) * c, o);
     }
   }
 }
@@ -438,11 +474,11 @@ extern "C" int fsr_instnorm_act_fwd(int dtype, const void* x, const float* stats
   hipStream_t stream = (hipStream_t)stream_;
   if (!x || !stats || !out) return fsr_fail(-1, "fsr_instnorm_act_fwd: null argument");
   if (act == FSR_ACT_PRELU && !prelu_weight) return fsr_fail(-1, "fsr_instnorm_act_fwd: PReLU needs its weight");
-  if (int rc = check_c("fsr_instnorm_act_fwd", dtype, c)) return rc;
-  const long long units = (long long)n * hw * (c / (dtype == FSR_BF16 ? 8 : 4));
-  FSR_DISPATCH_T(dtype, hipLaunchKernelGGL(instnorm_act_fwd_kernel<T>, dim3(capped_blocks(units, 256)), dim3(256), 0,
-                                           stream, P<T>(x), stats, P<T>(res), act, slope, prelu_weight, P<T>(out), units,
-                                           hw, c);)
+  if (int rc = check_reduce_c("fsr_instnorm_act_fwd", dtype, c)) return rc;
+  const long long units = (long long)hw * (c / (dtype == FSR_BF16 ? 8 : 4));   // per image
+  if (units >= (1LL << 31)) return fsr_fail(-2, "fsr_instnorm_act_fwd: image too large");
+  FSR_DISPATCH_T(dtype, hipLaunchKernelGGL(instnorm_act_fwd_kernel<T>, dim3(image_blocks(units, n), n), dim3(256), 0,
+                                           stream, P<T>(x), stats, P<T>(res), act, slope, prelu_weight, P<T>(out), hw, c);)
   return fsr_check_launch("instnorm_act_fwd_kernel");
 }
 
@@ -465,11 +501,11 @@ extern "C" int fsr_instnorm_act_bwd_apply(int dtype, const void* g, const void* 
   hipStream_t stream = (hipStream_t)stream_;
   if (!g || !x || !stats || !sums || !dx) return fsr_fail(-1, "fsr_instnorm_act_bwd_apply: null argument");
   if (act == FSR_ACT_PRELU && !prelu_weight) return fsr_fail(-1, "fsr_instnorm_act_bwd_apply: PReLU needs its weight");
-  if (int rc = check_c("fsr_instnorm_act_bwd_apply", dtype, c)) return rc;
-  const long long units = (long long)n * hw * (c / (dtype == FSR_BF16 ? 8 : 4));
-  FSR_DISPATCH_T(dtype, hipLaunchKernelGGL(instnorm_act_bwd_apply_kernel<T>, dim3(capped_blocks(units, 256)), dim3(256), 0,
-                                           stream, P<T>(g), P<T>(x), stats, sums, act, slope, prelu_weight, P<T>(dx), units,
-                                           hw, c);)
+  if (int rc = check_reduce_c("fsr_instnorm_act_bwd_apply", dtype, c)) return rc;
+  const long long units = (long long)hw * (c / (dtype == FSR_BF16 ? 8 : 4));
+  if (units >= (1LL << 31)) return fsr_fail(-2, "fsr_instnorm_act_bwd_apply: image too large");
+  FSR_DISPATCH_T(dtype, hipLaunchKernelGGL(instnorm_act_bwd_apply_kernel<T>, dim3(image_blocks(units, n), n), dim3(256), 0,
+                                           stream, P<T>(g), P<T>(x), stats, sums, act, slope, prelu_weight, P<T>(dx), hw, c);)
   return fsr_check_launch("instnorm_act_bwd_apply_kernel");
 }
 
@@ -498,11 +534,10 @@ extern "C" int fsr_image_to_nhwc(int dtype, const float* img, long long sn, long
   hipStream_t stream = (hipStream_t)stream_;
   if (!img || !out) return fsr_fail(-1, "fsr_image_to_nhwc: null argument");
   if (int rc = check_c("fsr_image_to_nhwc", dtype, cpad)) return rc;
-  const long long npix = (long long)n * h * w;
-  const long long units = npix * (cpad / (dtype == FSR_BF16 ? 8 : 4));
-  FSR_DISPATCH_T(dtype, hipLaunchKernelGGL(image_to_nhwc_kernel<T>, dim3(capped_blocks(units, 256)), dim3(256), 0, stream,
+  const int rowunits = w * (cpad / (dtype == FSR_BF16 ? 8 : 4));
+  FSR_DISPATCH_T(dtype, hipLaunchKernelGGL(image_to_nhwc_kernel<T>, dim3(n * h, row_blocks(rowunits)), dim3(256), 0, stream,
                                            img, sn, sc, sh, sw, h, w, scale0, scale1, scale2, shift0, shift1, shift2,
-                                           P<T>(out), cpad, npix);)
+                                           P<T>(out), cpad);)
   return fsr_check_launch("image_to_nhwc_kernel");
 }
 
@@ -512,10 +547,9 @@ extern "C" int fsr_tanh_bwd_to_nhwc(int dtype, const float* g, long long sn, lon
   hipStream_t stream = (hipStream_t)stream_;
   if (!g || !y_nhwc3 || !dz) return fsr_fail(-1, "fsr_tanh_bwd_to_nhwc: null argument");
   if (int rc = check_c("fsr_tanh_bwd_to_nhwc", dtype, cpad)) return rc;
-  const long long npix = (long long)n * h * w;
-  const long long units = npix * (cpad / (dtype == FSR_BF16 ? 8 : 4));
-  FSR_DISPATCH_T(dtype, hipLaunchKernelGGL(tanh_bwd_to_nhwc_kernel<T>, dim3(capped_blocks(units, 256)), dim3(256), 0,
-                                           stream, g, sn, sc, sh, sw, y_nhwc3, h, w, P<T>(dz), cpad, npix, dbias);)
+  const int rowunits = w * (cpad / (dtype == FSR_BF16 ? 8 : 4));
+  FSR_DISPATCH_T(dtype, hipLaunchKernelGGL(tanh_bwd_to_nhwc_kernel<T>, dim3(n * h, row_blocks(rowunits)), dim3(256), 0,
+                                           stream, g, sn, sc, sh, sw, y_nhwc3, h, w, P<T>(dz), cpad, dbias);)
   return fsr_check_launch("tanh_bwd_to_nhwc_kernel");
 }
 
@@ -524,9 +558,9 @@ extern "C" int fsr_maxpool2_fwd(int dtype, const void* x, void* y, int n, int h,
   if (!x || !y) return fsr_fail(-1, "fsr_maxpool2_fwd: null argument");
   if (int rc = check_c("fsr_maxpool2_fwd", dtype, c)) return rc;
   if ((h | w) & 1) return fsr_fail(-2, "fsr_maxpool2_fwd: odd extent %dx%d", h, w);
-  const long long units = (long long)n * (h / 2) * (w / 2) * (c / (dtype == FSR_BF16 ? 8 : 4));
-  FSR_DISPATCH_T(dtype, hipLaunchKernelGGL(maxpool2_fwd_kernel<T>, dim3(capped_blocks(units, 256)), dim3(256), 0, stream,
-                                           P<T>(x), P<T>(y), h, w, c, units);)
+  const int rowunits = (w / 2) * (c / (dtype == FSR_BF16 ? 8 : 4));
+  FSR_DISPATCH_T(dtype, hipLaunchKernelGGL(maxpool2_fwd_kernel<T>, dim3(n * (h / 2), row_blocks(rowunits)), dim3(256), 0,
+                                           stream, P<T>(x), P<T>(y), h, w, c);)
   return fsr_check_launch("maxpool2_fwd_kernel");
 }
 
@@ -536,8 +570,8 @@ extern "C" int fsr_maxpool2_bwd(int dtype, const void* g, const void* x, const v
   if (!g || !x || !y || !dx) return fsr_fail(-1, "fsr_maxpool2_bwd: null argument");
   if (int rc = check_c("fsr_maxpool2_bwd", dtype, c)) return rc;
   if ((h | w) & 1) return fsr_fail(-2, "fsr_maxpool2_bwd: odd extent %dx%d", h, w);
-  const long long units = (long long)n * (h / 2) * (w / 2) * (c / (dtype == FSR_BF16 ? 8 : 4));
-  FSR_DISPATCH_T(dtype, hipLaunchKernelGGL(maxpool2_bwd_kernel<T>, dim3(capped_blocks(units, 256)), dim3(256), 0, stream,
-                                           P<T>(g), P<T>(x), P<T>(y), P<T>(dx), h, w, c, units, relu_mask);)
+  const int rowunits = (w / 2) * (c / (dtype == FSR_BF16 ? 8 : 4));
+  FSR_DISPATCH_T(dtype, hipLaunchKernelGGL(maxpool2_bwd_kernel<T>, dim3(n * (h / 2), row_blocks(rowunits)), dim3(256), 0,
+                                           stream, P<T>(g), P<T>(x), P<T>(y), P<T>(dx), h, w, c, relu_mask);)
   return fsr_check_launch("maxpool2_bwd_kernel");
 }

@@ -75,6 +75,53 @@ _ws = {}
 _const = {}
 
 
+class ZeroPool:
+    """Per-iteration arena of zero-initialised float32 scratch (InstanceNorm statistics, reduction outputs, bias /
+    PReLU gradients, loss accumulators): ONE memset per iteration instead of ~160 tiny fill kernels.  `reset()` at the
+    start of an iteration re-zeroes the arena and rewinds it; tensors carved from it live until the next reset."""
+
+    def __init__(self, device, nfloats=4 << 20):
+        self.buf = torch.zeros(nfloats, dtype=torch.float32, device=device)
+        self.off = 0
+
+    def reset(self):
+        if self.off:
+            self.buf[:self.off].zero_()
+        self.off = 0
+
+    def take(self, shape):
+        n = 1
+        for d in shape:
+            n *= d
+        n4 = (n + 3) // 4 * 4          # keep 16-byte alignment for vector loads
+        if self.off + n4 > self.buf.numel():
+            return None
+        t = self.buf[self.off:self.off + n].view(shape)
+        self.off += n4
+        return t
+
+
+_zero_pool = {}
+
+
+def zero_pool_reset(device):
+    """Called by the Trainer at the start of every iteration (creates the arena on first use)."""
+    key = str(device)
+    pool = _zero_pool.get(key)
+    if pool is None:
+        pool = _zero_pool[key] = ZeroPool(device)
+    pool.reset()
+
+
+def _zeros(shape, device):
+    pool = _zero_pool.get(str(device))
+    if pool is not None:
+        t = pool.take(tuple(shape))
+        if t is not None:
+            return t
+    return torch.zeros(shape, dtype=torch.float32, device=device)
+
+
 def _const_vec(values, device):
     """Small float constant vector on `device`, uploaded once (no host-to-device copies inside captured steps)."""
     key = (tuple(values), str(device))
@@ -115,7 +162,7 @@ def conv3x3_raw(cd, x, wpk, cout, *, mode=L.CONV_FWD, out_hw=None, stride=1, bia
     oshape = (n, 2 * oh, 2 * ow, cout // 4) if pixel_shuffle else (n, oh, ow, cout)
     out = torch.empty(oshape, dtype=odt, device=x.device)
     pre = torch.empty(oshape, dtype=odt, device=x.device) if want_preact else None
-    stats = torch.zeros((n, cout, 2), dtype=torch.float32, device=x.device) if want_stats else None
+    stats = _zeros((n, cout, 2), x.device) if want_stats else None
     d = L.ConvDesc(cd.code, mode, n, ih, iw, cin, oh, ow, cout, stride, act, float(slope), int(pixel_shuffle),
                    int(in_pixel_shuffled), int(out_f32))
     prof = PROFILE_CONV
@@ -231,7 +278,7 @@ class Conv3x3Fn(torch.autograd.Function):
         cout, cin, xshape = ctx.dims
         n, ih, iw, cin_pad = xshape
         lib, st = L.lib(), _stream()
-        dbias = torch.zeros(cout, dtype=torch.float32, device=xin.device) if ctx.has_bias else None
+        dbias = _zeros((cout,), xin.device) if ctx.has_bias else None
         dprelu = None
         act = L.ACT_TANH if cfg.tanh_head else cfg.act
         if cfg.tanh_head:
@@ -251,7 +298,7 @@ class Conv3x3Fn(torch.autograd.Function):
                 dz = g
             elif act != L.ACT_NONE or ctx.has_bias:
                 if act == L.ACT_PRELU:
-                    dprelu = torch.zeros(1, dtype=torch.float32, device=xin.device)
+                    dprelu = _zeros((1,), xin.device)
                 dz = torch.empty_like(g)
                 _, h, w, c = g.shape
                 L.check(lib.fsr_act_bwd(cd.code, _p(g), _p(saved), act, float(cfg.slope), _p(prelu), _p(dz), _p(dbias),
@@ -312,8 +359,8 @@ class InstNormActFn(torch.autograd.Function):
         n, h, w, c = x.shape
         g = g if g.is_contiguous() else g.contiguous()
         lib, st = L.lib(), _stream()
-        sums = torch.zeros((n, c, 2), dtype=torch.float32, device=x.device)
-        dprelu = torch.zeros(1, dtype=torch.float32, device=x.device) if act == L.ACT_PRELU else None
+        sums = _zeros((n, c, 2), x.device)
+        dprelu = _zeros((1,), x.device) if act == L.ACT_PRELU else None
         L.check(lib.fsr_instnorm_act_bwd_reduce(cd.code, _p(g), _p(x), _p(stats), act, float(slope), _p(prelu), _p(sums),
                                                 _p(dprelu), n, h * w, c, st), "fsr_instnorm_act_bwd_reduce")
         dx = torch.empty_like(x)
@@ -378,8 +425,8 @@ class Conv1x1ToLogitsFn(torch.autograd.Function):
         n, h, w, c = x.shape
         g = g.contiguous().float()
         dx = torch.empty_like(x) if ctx.needs_input_grad[0] else None
-        dw = torch.zeros(weight.shape, dtype=torch.float32, device=x.device)
-        db = torch.zeros(1, dtype=torch.float32, device=x.device)
+        dw = _zeros(tuple(weight.shape), x.device)
+        db = _zeros((1,), x.device)
         L.check(L.lib().fsr_conv1x1_c1_bwd(ctx.cd.code, _p(g), _p(x), _p(weight.detach().reshape(-1)), _p(dx), _p(dw), _p(db),
                                            n * h * w, c, _stream()), "fsr_conv1x1_c1_bwd")
         return dx, dw, db, None
@@ -398,7 +445,7 @@ class BCEWithLogitsFn(torch.autograd.Function):
         _check_dev(x, t)
         x = x.contiguous().float()
         t = t.contiguous().float()
-        loss = torch.zeros((), dtype=torch.float32, device=x.device)
+        loss = _zeros((1,), x.device).view(())
         L.check(L.lib().fsr_bce_logits_fwd(_p(x), _p(t), _p(loss), x.numel(), _stream()), "fsr_bce_logits_fwd")
         ctx.save_for_backward(x, t)
         return loss
@@ -436,7 +483,7 @@ class SmoothL1Fn(torch.autograd.Function):
         code = L.FSR_BF16 if a.dtype == torch.bfloat16 else L.FSR_F32
         if code == L.FSR_F32 and a.dtype != torch.float32:
             raise L.FsrError("SmoothL1: unsupported dtype %s" % a.dtype)
-        loss = torch.zeros((), dtype=torch.float32, device=a.device)
+        loss = _zeros((1,), a.device).view(())
         L.check(L.lib().fsr_smooth_l1_fwd(code, _p(a), _p(b), _p(loss), a.numel(), _stream()), "fsr_smooth_l1_fwd")
         ctx.code = code
         ctx.save_for_backward(a, b)

@@ -75,6 +75,7 @@ class Trainer:
     def train_step(self, lr_images, hr_images, noise=None):
         """noise: optional (n0, n1, n2) replacing the torch.rand_like draws of trainer.py:175,176,187."""
         G, Dm, V = self.generator, self.discriminator, self.perceptual_network
+        ops.zero_pool_reset(lr_images.device)   # one memset for all statistics / reduction scratch of the iteration
         # ---- discriminator step
         self.optim_discriminator.zero_grad()                                    # :171
         y_real = Dm(hr_images)                                                  # :172
@@ -110,8 +111,9 @@ class Trainer:
         self._sync_g.start()
         self._sync_g.wait()
         self.optim_generator.step()                                             # :196
-        return {"loss_real": loss_real.detach(), "loss_fake": loss_fake.detach(),
-                "adv_loss": adv_loss.detach(), "content_loss": content_loss.detach()}
+        # the loss scalars live in the per-iteration scratch arena: copy them out (one launch) so they survive the next reset
+        vals = torch.stack([loss_real.detach(), loss_fake.detach(), adv_loss.detach(), content_loss.detach()])
+        return dict(zip(("loss_real", "loss_fake", "adv_loss", "content_loss"), vals.unbind(0)))
 
     # ------------------------------------------------------------------ hipGraph replay of the whole iteration
     def capture_train_step(self, lr_images, hr_images, warmup=2):
@@ -142,6 +144,7 @@ class Trainer:
 
     def pretrain_step(self, lr_images, hr_images):
         """trainer.py:107-111."""
+        ops.zero_pool_reset(lr_images.device)
         self.optim_generator.zero_grad()
         fake_hr_images = self.generator(lr_images)
         gen_loss = self.l1_loss(fake_hr_images, hr_images)
@@ -149,7 +152,7 @@ class Trainer:
         self._sync_g.start()
         self._sync_g.wait()
         self.optim_generator.step()
-        return gen_loss.detach()
+        return gen_loss.detach().clone()
 
     # ------------------------------------------------------------------ cold paths
     @torch.no_grad()
