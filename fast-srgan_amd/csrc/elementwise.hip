@@ -329,34 +329,35 @@ __global__ __launch_bounds__(256) void image_to_nhwc_kernel(const float* __restr
 template <typename T>
 __global__ __launch_bounds__(256) void tanh_bwd_to_nhwc_kernel(const float* __restrict__ g, long long sn, long long sc,
                                                                long long sh, long long sw, const float* __restrict__ y,
-                                                               int h, int w, T* __restrict__ dz, int cpad,
+                                                               int h, int w, T* __restrict__ dz, int cpad, int nrows,
                                                                float* __restrict__ dbias) {
   constexpr int E = V16<T>::N;
   __shared__ float red[3][4];
   const int upp = cpad / E;
-  const int row = blockIdx.x;
-  const int n = row / h, yy = row - n * h;
-  const float* src = g + n * sn + yy * sh;
-  const float* ty = y + (size_t)row * w * 3;
-  T* dst = dz + (size_t)row * w * cpad;
-  const unsigned units = (unsigned)w * upp;
   float b0 = 0.f, b1 = 0.f, b2 = 0.f;
-  for (unsigned u = blockIdx.y * 256 + threadIdx.x; u < units; u += gridDim.y * 256) {
-    const unsigned x = u / upp, un = u - x * upp;
-    float v[E];
+  const unsigned units = (unsigned)w * upp;
+  for (int row = blockIdx.x; row < nrows; row += gridDim.x) {   // few workgroups: the bias sums end in 3 atomics each
+    const int n = row / h, yy = row - n * h;
+    const float* src = g + n * sn + yy * sh;
+    const float* ty = y + (size_t)row * w * 3;
+    T* dst = dz + (size_t)row * w * cpad;
+    for (unsigned u = blockIdx.y * 256 + threadIdx.x; u < units; u += gridDim.y * 256) {
+      const unsigned x = u / upp, un = u - x * upp;
+      float v[E];
 #pragma unroll
-    for (int i = 0; i < E; ++i) v[i] = 0.f;
-    if (un == 0) {
-      const float* s = src + x * sw;
-      const float* t = ty + x * 3;
-      v[0] = s[0] * (1.f - t[0] * t[0]);
-      v[1] = s[sc] * (1.f - t[1] * t[1]);
-      v[2] = s[2 * sc] * (1.f - t[2] * t[2]);
-      b0 += v[0];
-      b1 += v[1];
-      b2 += v[2];
+      for (int i = 0; i < E; ++i) v[i] = 0.f;
+      if (un == 0) {
+        const float* s = src + x * sw;
+        const float* t = ty + x * 3;
+        v[0] = s[0] * (1.f - t[0] * t[0]);
+        v[1] = s[sc] * (1.f - t[1] * t[1]);
+        v[2] = s[2 * sc] * (1.f - t[2] * t[2]);
+        b0 += v[0];
+        b1 += v[1];
+        b2 += v[2];
+      }
+      V16<T>::st(dst + (size_t)u * E, v);
     }
-    V16<T>::st(dst + (size_t)u * E, v);
   }
   if (dbias) {
     b0 = wave_sum(b0);
@@ -548,8 +549,8 @@ extern "C" int fsr_tanh_bwd_to_nhwc(int dtype, const float* g, long long sn, lon
   if (!g || !y_nhwc3 || !dz) return fsr_fail(-1, "fsr_tanh_bwd_to_nhwc: null argument");
   if (int rc = check_c("fsr_tanh_bwd_to_nhwc", dtype, cpad)) return rc;
   const int rowunits = w * (cpad / (dtype == FSR_BF16 ? 8 : 4));
-  FSR_DISPATCH_T(dtype, hipLaunchKernelGGL(tanh_bwd_to_nhwc_kernel<T>, dim3(n * h, row_blocks(rowunits)), dim3(256), 0,
-                                           stream, g, sn, sc, sh, sw, y_nhwc3, h, w, P<T>(dz), cpad, dbias);)
+  FSR_DISPATCH_T(dtype, hipLaunchKernelGGL(tanh_bwd_to_nhwc_kernel<T>, dim3(n * h < 512 ? n * h : 512, row_blocks(rowunits)), dim3(256), 0,
+                                           stream, g, sn, sc, sh, sw, y_nhwc3, h, w, P<T>(dz), cpad, n * h, dbias);)
   return fsr_check_launch("tanh_bwd_to_nhwc_kernel");
 }
 
