@@ -146,16 +146,22 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv_igemm_kernel(const ConvK
   // LDS buffer of step s+2 one step later, after the MFMAs of step s+1 -- two MFMA blocks (>= 1000 cycles) of
   // cover for an L2 round trip, against one barrier per step.
   u32x4 wregA[WPT], wregB[WPT];
-  const int nsteps = nchunks * a.ntaps;
-  auto wload = [&](u32x4 (&wr)[WPT], int step) {
-    const int c = step / a.ntaps, t = step - c * a.ntaps;
-    const T* base = wpk + ((size_t)(tap_code(a, t) >> 4) * a.CoutPad + (size_t)nb * BN) * a.Cin + c * KC;
+  // per-thread element offsets inside a filter slice (loop invariant), and the slice geometry in 32 bits
+  unsigned woff[WPT];
+#pragma unroll
+  for (int i = 0; i < WPT; ++i) {
+    const int u = tid + i * NTHR;
+    woff[i] = (unsigned)((u / UNITS) * a.Cin + (u % UNITS) * EPB);
+  }
+  const unsigned slice_stride = (unsigned)(a.CoutPad * a.Cin);   // elements per tap slice (< 2^31: host checked)
+  const T* wnb = wpk + (size_t)nb * BN * a.Cin;
+  auto wload = [&](u32x4 (&wr)[WPT], int c, int t) {
+    const T* base = wnb + ((tap_code(a, t) >> 4) * slice_stride + (unsigned)(c * KC));
 #pragma unroll
     for (int i = 0; i < WPT; ++i) {
       const int u = tid + i * NTHR;
       u32x4 v = (u32x4){0u, 0u, 0u, 0u};
-      if ((BN * UNITS) % NTHR == 0 || u < BN * UNITS)
-        v = *(const u32x4*)(base + (unsigned)((u / UNITS) * a.Cin + (u % UNITS) * EPB));
+      if ((BN * UNITS) % NTHR == 0 || u < BN * UNITS) v = *(const u32x4*)(base + woff[i]);
       wr[i] = v;
     }
   };
@@ -181,10 +187,11 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv_igemm_kernel(const ConvK
   for (int n = 0; n < NT; ++n) wbase[n] = ((wn * NT + n) * 16 + l15) * PITCHW + lg * EPB;
 
   // One step.  P = step parity: LDS buffer P holds this step's filter slice; register set `mine` receives the
-  // loads of step s+2 (same parity), register set `other` holds step s+1's slice, loaded during step s-1.
-  auto step_body = [&](auto parity, int s, int c, int t, u32x4 (&mine)[WPT], u32x4 (&other)[WPT]) {
+  // loads of the step two ahead (same parity: chunk c2, tap t2), register set `other` holds the next step's slice,
+  // loaded one step ago.  All step bookkeeping is incremental scalar arithmetic (no division in the loop).
+  auto step_body = [&](auto parity, int c, int t, bool has1, bool has2, int c2, int t2, u32x4 (&mine)[WPT], u32x4 (&other)[WPT]) {
     constexpr int P = decltype(parity)::value;
-    if (s + 2 < nsteps) wload(mine, s + 2);
+    if (has2) wload(mine, c2, t2);
     if (t == 0 && c + 1 < nchunks) halo_issue(c + 1);
     const T* wcur = wl + (size_t)P * BN * PITCHW;
     const unsigned tc = tap_code(a, t);
@@ -208,7 +215,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv_igemm_kernel(const ConvK
           }
         }
     }
-    if (s + 1 < nsteps) wstore(other, P ^ 1);
+    if (has1) wstore(other, P ^ 1);
     __syncthreads();
     if (t + 1 == a.ntaps && c + 1 < nchunks) {
       halo_commit();
@@ -216,21 +223,26 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv_igemm_kernel(const ConvK
     }
   };
 
+  const int nsteps = nchunks * a.ntaps;
   halo_issue(0);
   halo_commit();
-  wload(wregA, 0);
+  wload(wregA, 0, 0);
   wstore(wregA, 0);
-  if (nsteps > 1) wload(wregB, 1);
+  if (nsteps > 1) wload(wregB, a.ntaps > 1 ? 0 : 1, a.ntaps > 1 ? 1 : 0);
   __syncthreads();
 
   {
-    int c = 0, t = 0;
+    int c = 0, t = 0;            // current step
+    int c2 = 0, t2 = 2;          // the step two ahead
+    while (t2 >= a.ntaps) { t2 -= a.ntaps; ++c2; }
     for (int s = 0; s < nsteps; s += 2) {
-      step_body(std::integral_constant<int, 0>{}, s, c, t, wregA, wregB);
+      step_body(std::integral_constant<int, 0>{}, c, t, s + 1 < nsteps, s + 2 < nsteps, c2, t2, wregA, wregB);
       if (++t == a.ntaps) { t = 0; ++c; }
+      if (++t2 == a.ntaps) { t2 = 0; ++c2; }
       if (s + 1 < nsteps) {
-        step_body(std::integral_constant<int, 1>{}, s + 1, c, t, wregB, wregA);
+        step_body(std::integral_constant<int, 1>{}, c, t, s + 2 < nsteps, s + 3 < nsteps, c2, t2, wregB, wregA);
         if (++t == a.ntaps) { t = 0; ++c; }
+        if (++t2 == a.ntaps) { t2 = 0; ++c2; }
       }
     }
   }
