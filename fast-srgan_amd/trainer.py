@@ -155,21 +155,39 @@ class Trainer:
         return gen_loss.detach().clone()
 
     # ------------------------------------------------------------------ cold paths
+    @staticmethod
+    def _ssim(a, b, data_range=1.0):
+        """torchmetrics StructuralSimilarityIndexMeasure defaults (trainer.py:46-48): gaussian 11x11, sigma 1.5,
+        k1 0.01, k2 0.03, per-image mean over the valid (unpadded) region.  Eval-only cold path: plain torch ops."""
+        k = torch.arange(11, dtype=torch.float32, device=a.device) - 5
+        g = torch.exp(-(k ** 2) / (2 * 1.5 ** 2))
+        g = (g / g.sum()).outer(g / g.sum())
+        w = g.expand(a.shape[1], 1, 11, 11).contiguous()
+        c1, c2 = (0.01 * data_range) ** 2, (0.03 * data_range) ** 2
+        pad = lambda t: torch.nn.functional.pad(t, (5, 5, 5, 5), mode="reflect")          # torchmetrics pads, then crops
+        f = lambda t: torch.nn.functional.conv2d(pad(t), w, groups=a.shape[1])
+        mu_a, mu_b = f(a), f(b)
+        s_aa, s_bb, s_ab = f(a * a) - mu_a ** 2, f(b * b) - mu_b ** 2, f(a * b) - mu_a * mu_b
+        ssim = ((2 * mu_a * mu_b + c1) * (2 * s_ab + c2)) / ((mu_a ** 2 + mu_b ** 2 + c1) * (s_aa + s_bb + c2))
+        return ssim[..., 5:-5, 5:-5].reshape(a.shape[0], -1).mean(-1)
+
     @torch.no_grad()
     def _calculate_metrics_over_dataset(self, dataloader, phase, step):
-        """PSNR over the loader (data_range 1.0), trainer.py:53-69.  SSIM (torchmetrics) is outside the hot
-        path and not reproduced."""
+        """SSIM and PSNR over the loader (data_range 1.0), trainer.py:53-69 (torchmetrics restated; eval-only)."""
         self.generator.eval()
-        total, count = 0.0, 0
+        psnr, ssim, count = 0.0, 0.0, 0
         for lr_images, hr_images in dataloader:
             lr_images = lr_images.to(self.config.training.device, non_blocking=True)
             hr_images = hr_images.to(self.config.training.device, non_blocking=True)
-            sr = (1.0 + self.generator(lr_images)) / 2.0
-            mse = ((sr - (1.0 + hr_images) / 2.0) ** 2).mean(dim=(1, 2, 3))
-            total += float((10.0 * torch.log10(1.0 / mse)).sum())
+            sr = ((1.0 + self.generator(lr_images)) / 2.0).contiguous()
+            hr = (1.0 + hr_images) / 2.0
+            mse = ((sr - hr) ** 2).mean(dim=(1, 2, 3))
+            psnr += float((10.0 * torch.log10(1.0 / mse)).sum())
+            ssim += float(self._ssim(sr, hr).sum())
             count += mse.numel()
         if count:
-            self.writer.add_scalar(f"{phase}/PSNR", total / count, global_step=step)
+            self.writer.add_scalar(f"{phase}/SSIM", ssim / count, global_step=step)
+            self.writer.add_scalar(f"{phase}/PSNR", psnr / count, global_step=step)
         self.writer.flush()
 
     @classmethod

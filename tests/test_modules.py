@@ -144,3 +144,18 @@ def test_full_size_modules_vs_oracle_gpu(pkg, cdn):
             if p.numel() < 1000 and cdn == "bf16":
                 continue   # PReLU slopes, biases: a few cancelling sums, their relative error says nothing in bf16
             assert relerr2(p.grad, ref[(tag, k)]) < t_grad, (tag, k, relerr2(p.grad, ref[(tag, k)]))
+
+
+@pytest.mark.gpu
+def test_generator_8x_extension_gpu(pkg):
+    """BASELINE cfg #5 shape: n_upsample=3 (three pixel-shuffle stages) against the oracle, f32 mode."""
+    dev = select("hip")
+    torch.manual_seed(4)
+    G = pkg.Generator(ns(n_filters=64, n_layers=2, n_upsample=3), compute_dtype="f32")
+    sd = {k: v.clone() for k, v in G.state_dict().items()}
+    assert "upsampling.2.conv.weight" in sd
+    x = torch.rand(1, 3, 16, 24) * 2 - 1
+    with torch.no_grad():
+        y = G.to(dev)(x.to(dev))
+    assert y.shape == (1, 3, 128, 192)
+    assert relerr(y, O.generator_forward(sd, x)) < 1e-3
