@@ -107,29 +107,36 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv_igemm_kernel(const ConvK
   constexpr int halo_total = HH * HW * UNITS;
   constexpr int HPT = (halo_total + NTHR - 1) / NTHR;  // 16-byte units per thread
   u32x4 hreg[HPT];
+  // Per-thread element offset of each of its halo units for chunk 0 (loop invariant: pixel, bounds test and
+  // channel unit depend only on the thread), ~0u outside the image (zero padding).  A chunk adds a scalar.
+  unsigned hoff[HPT];
+#pragma unroll
+  for (int i = 0; i < HPT; ++i) {
+    const int u = tid + i * NTHR;
+    unsigned o = ~0u;
+    if (u < halo_total) {
+      const int unit = u % UNITS;
+      const int p = u / UNITS;
+      const int hx = p % HW, hy = p / HW;
+      const int iy = iy0 + hy, ix = ix0 + hx;
+      if (iy >= 0 && iy < a.IH && ix >= 0 && ix < a.IW) {
+        if (!a.in_ps) o = (unsigned)((img * a.IH + iy) * a.IW + ix) * (unsigned)a.Cin + (unsigned)(unit * EPB);
+        else o = (unsigned)((img * 2 * a.IH + 2 * iy) * (2 * a.IW) + 2 * ix) * (unsigned)(a.Cin >> 2) + (unsigned)(unit * EPB);
+      }
+    }
+    hoff[i] = o;
+  }
   auto halo_issue = [&](int c) {
+    unsigned add = (unsigned)(c * KC);
+    if (a.in_ps) {  // depth-to-space input: a chunk lies inside one quadrant (host checked: (Cin/4) % KC == 0)
+      const int cps = a.Cin >> 2;
+      const int q = (c * KC) / cps;
+      add = (unsigned)(((q >> 1) * 2 * a.IW + (q & 1)) * cps + (c * KC - q * cps));
+    }
 #pragma unroll
     for (int i = 0; i < HPT; ++i) {
-      const int u = tid + i * NTHR;
       u32x4 v = (u32x4){0u, 0u, 0u, 0u};
-      if (u < halo_total) {
-        const int unit = u % UNITS;
-        const int p = u / UNITS;
-        const int hx = p % HW, hy = p / HW;
-        const int iy = iy0 + hy, ix = ix0 + hx;
-        if (iy >= 0 && iy < a.IH && ix >= 0 && ix < a.IW) {
-          const int ch = c * KC + unit * EPB;
-          unsigned eoff;  // 32-bit element offset (host guarantees the tensor has < 2^31 elements)
-          if (!a.in_ps) {
-            eoff = (unsigned)((img * a.IH + iy) * a.IW + ix) * (unsigned)a.Cin + (unsigned)ch;
-          } else {
-            const int cps = a.Cin >> 2;
-            const int q = ch / cps, cc = ch - q * cps;
-            eoff = (unsigned)((img * 2 * a.IH + 2 * iy + (q >> 1)) * (2 * a.IW) + 2 * ix + (q & 1)) * (unsigned)cps + (unsigned)cc;
-          }
-          v = *(const u32x4*)(in + eoff);
-        }
-      }
+      if (hoff[i] != ~0u) v = *(const u32x4*)(in + (hoff[i] + add));
       hreg[i] = v;
     }
   };
@@ -372,6 +379,8 @@ static int launch_cfg(ConvKArgs& a, hipStream_t stream) {
   constexpr int EPB = 16 / (int)sizeof(T);
   constexpr int PITCHW = KC + 2 * EPB, PITCHX = KC + (S == 2 ? 1 : 2) * EPB;
   if (a.Cin % KC != 0) return fsr_fail(-2, "conv3x3: Cin=%d is not a multiple of the chunk %d", a.Cin, KC);
+  if (a.in_ps && (a.Cin / 4) % KC != 0)
+    return fsr_fail(-2, "conv3x3: pixel-shuffled input needs (Cin/4)=%d to be a multiple of the chunk %d", a.Cin / 4, KC);
   if (a.CoutPad % BN != 0) return fsr_fail(-2, "conv3x3: padded Cout=%d is not a multiple of %d", a.CoutPad, BN);
   a.tiles_x = (a.GW + 15) / 16;
   a.tiles_y = (a.GH + TH - 1) / TH;
@@ -412,7 +421,7 @@ static int dispatch_T(ConvKArgs& a, int S, hipStream_t stream) {
   // stride 1 (half the barriers and halo passes per FLOP); KCN: narrow chunk (stride 2 halos are 4x larger)
   const int w16 = ((a.GH + 15) / 16) * 16 - a.GH, w8 = ((a.GH + 7) / 8) * 8 - a.GH;
   const bool th8 = (w16 - w8 >= 8);
-  const bool wide = (a.Cin % KCW == 0);
+  const bool wide = (a.Cin % KCW == 0) && (!a.in_ps || (a.Cin / 4) % KCW == 0);
   if (a.CoutPad % 128 == 0) {
     if (S == 2) return launch_cfg<T, 8, 128, 2, 2, KCN, 2>(a, stream);
     // (8-wave variants <16,128,4,2> / <32,64,8,1> halve the filter traffic per FLOP but measured 5-10 % slower:

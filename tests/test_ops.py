@@ -35,7 +35,7 @@ def _big(dev):
 
 
 @pytest.mark.parametrize("cdn", ["f32", "bf16"])
-@pytest.mark.parametrize("stride,cin,cout,ps", [(1, 32, 64, False), (2, 64, 64, False), (1, 32, 64, True), (1, 64, 3, False)])
+@pytest.mark.parametrize("stride,cin,cout,ps", [(1, 32, 64, False), (2, 64, 64, False), (1, 32, 128, True), (1, 64, 3, False)])
 def test_conv_fwd_dgrad_wgrad(dev, cdn, stride, cin, cout, ps):
     cd = ops.Compute(cdn)
     torch.manual_seed(1)
