@@ -17,7 +17,9 @@
 //   workgroup -> BM output channels x BN input channels x all 9 taps, for a slab of pixel tiles
 //                (TPH x 16 output pixels each); the dy tile and the x halo of a pixel tile are
 //                staged in LDS once and reused by all 9 taps (x) / all taps and channel tiles (dy);
-//   wave      -> one 16-row co tile x TPW 16-wide ci tiles x 9 taps of accumulators in registers;
+//   wave      -> one 16-row co tile x TPW 16-wide ci tiles x 9 taps of accumulators in registers; the
+//                64x64 block runs with 8 waves (TPW = 2, 72 accumulator registers) so that two waves share
+//                each SIMD and cover each other's transposing-read latency;
 //   split-K   -> slabs write f32 partials [slab][9][cout_pad][cin_pad] to the workspace; a second
 //                kernel sums the slabs and adds the result into the OIHW float gradient.
 #include "fsr_common.h"
@@ -35,13 +37,15 @@ struct WgradKArgs {
 };
 
 template <typename T, int BM, int BN, int S, int TPH>
-__global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradKArgs a) {
+__global__ __launch_bounds__((BM == 64 && BN == 64) ? 512 : 256) void conv_wgrad_kernel(const WgradKArgs a) {
+  constexpr int NW = (BM == 64 && BN == 64) ? 8 : 4;   // waves per workgroup
+  constexpr int NTHR = NW * 64;
   constexpr int EPB = 16 / (int)sizeof(T);
   constexpr int PAD = 16;
   constexpr int PA = BM + PAD, PB = BN + PAD;  // LDS pixel pitches (elements)
   constexpr int HH = (TPH - 1) * S + 3, HW = 15 * S + 3;
   constexpr int NPAIR = (BM / 16) * (BN / 16);
-  constexpr int TPW = (NPAIR + 3) / 4;  // (co tile, ci tile) pairs per wave; all share one co tile
+  constexpr int TPW = (NPAIR + NW - 1) / NW;  // (co tile, ci tile) pairs per wave; all share one co tile
   constexpr int NBT = BN / 16;
   static_assert(TPW <= NBT, "a wave's pairs must share its co tile");
   constexpr int TPIX = TPH * 16;
@@ -75,7 +79,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradKArgs a) {
   // Staging is split (issue early / commit late): the global loads of tile i+1 are issued into registers
   // before the MFMAs of tile i and written to LDS after them, so HBM/L2 latency hides under a tile of math.
   constexpr int DUNITS = TPIX * (BM / EPB), HUNITS = HH * HW * (BN / EPB);
-  constexpr int DPT = (DUNITS + 255) / 256, HPT = (HUNITS + 255) / 256;
+  constexpr int DPT = (DUNITS + NTHR - 1) / NTHR, HPT = (HUNITS + NTHR - 1) / NTHR;
   u32x4 dreg[DPT], hreg[HPT];
   auto stage_issue = [&](int tile) {
     const int tx = tile % a.tiles_x;
@@ -84,9 +88,9 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradKArgs a) {
     const int oy0 = ty * TPH, ox0 = tx * 16;
 #pragma unroll
     for (int i = 0; i < DPT; ++i) {   // dy tile: [TPIX][BM]
-      const int u = tid + i * 256;
+      const int u = tid + i * NTHR;
       u32x4 v = (u32x4){0u, 0u, 0u, 0u};
-      if (DUNITS % 256 == 0 || u < DUNITS) {
+      if (DUNITS % NTHR == 0 || u < DUNITS) {
         const int unit = u % (BM / EPB), p = u / (BM / EPB);
         const int oy = oy0 + p / 16, ox = ox0 + (p & 15);
         if (oy < a.OH && ox < a.OW) {
@@ -107,9 +111,9 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradKArgs a) {
     const int iy0 = oy0 * S - 1, ix0 = ox0 * S - 1;
 #pragma unroll
     for (int i = 0; i < HPT; ++i) {   // x halo: [HH][HW][BN]
-      const int u = tid + i * 256;
+      const int u = tid + i * NTHR;
       u32x4 v = (u32x4){0u, 0u, 0u, 0u};
-      if (HUNITS % 256 == 0 || u < HUNITS) {
+      if (HUNITS % NTHR == 0 || u < HUNITS) {
         const int unit = u % (BN / EPB), p = u / (BN / EPB);
         const int iy = iy0 + p / HW, ix = ix0 + p % HW;
         if (iy >= 0 && iy < a.IH && ix >= 0 && ix < a.IW)
@@ -121,13 +125,13 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradKArgs a) {
   auto stage_commit = [&]() {
 #pragma unroll
     for (int i = 0; i < DPT; ++i) {
-      const int u = tid + i * 256;
-      if (DUNITS % 256 == 0 || u < DUNITS) *(u32x4*)(dyt + (u / (BM / EPB)) * PA + (u % (BM / EPB)) * EPB) = dreg[i];
+      const int u = tid + i * NTHR;
+      if (DUNITS % NTHR == 0 || u < DUNITS) *(u32x4*)(dyt + (u / (BM / EPB)) * PA + (u % (BM / EPB)) * EPB) = dreg[i];
     }
 #pragma unroll
     for (int i = 0; i < HPT; ++i) {
-      const int u = tid + i * 256;
-      if (HUNITS % 256 == 0 || u < HUNITS) *(u32x4*)(halo + (u / (BN / EPB)) * PB + (u % (BN / EPB)) * EPB) = hreg[i];
+      const int u = tid + i * NTHR;
+      if (HUNITS % NTHR == 0 || u < HUNITS) *(u32x4*)(halo + (u / (BN / EPB)) * PB + (u % (BN / EPB)) * EPB) = hreg[i];
     }
   };
 
@@ -285,7 +289,7 @@ int launch_wgrad(const WgradKArgs& a, size_t lds, hipStream_t stream) {
     (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
     attr_set = true;
   }
-  hipLaunchKernelGGL(kern, dim3((unsigned)(a.nslab * a.nbm * a.nbn)), dim3(256), lds, stream, a);
+  hipLaunchKernelGGL(kern, dim3((unsigned)(a.nslab * a.nbm * a.nbn)), dim3((BM == 64 && BN == 64) ? 512 : 256), lds, stream, a);
   return fsr_check_launch("conv_wgrad_kernel");
 }
 
