@@ -14,7 +14,7 @@ LIB_PATH = os.path.join(_HERE, "libfsr_hip.so")
 FSR_F32, FSR_BF16 = 0, 1
 ACT_NONE, ACT_RELU, ACT_LEAKY, ACT_PRELU, ACT_TANH = 0, 1, 2, 3, 4
 CONV_FWD, CONV_DGRAD = 0, 1
-PACK_FWD, PACK_FWD_PS, PACK_DGRAD, PACK_DGRAD_PS, PACK_DGRAD_S2 = 0, 1, 2, 3, 4
+PACK_FWD, PACK_FWD_PS, PACK_DGRAD, PACK_DGRAD_PS = 0, 1, 2, 3
 ABI_VERSION = 3
 
 c_int, c_float, c_void_p, c_size_t, c_ll = ctypes.c_int, ctypes.c_float, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_longlong

@@ -115,29 +115,7 @@ extern "C" int fsr_conv3x3(const fsr_conv_desc* d, const void* in, const void* p
     a.ooy = a.oox = 0;
     return fsr_conv_igemm_dispatch(d->dtype, a, 1, stream);
   }
-  if (d->oh % 2 == 0 && d->ow % 2 == 0 && d->cout % 4 == 0 && !a.in_ps) {
-    // stride 2, even extents: ONE stride-1 launch over the (i, j) = (y/2, x/2) grid producing all four output
-    // parities as 4*cout "channels" stored depth-to-space (filters packed FSR_PACK_DGRAD_S2)
-    a.GH = d->oh / 2;
-    a.GW = d->ow / 2;
-    a.FOH = a.GH;
-    a.FOW = a.GW;
-    a.org_y = a.org_x = 0;
-    a.ntaps = 4;
-    for (int t = 0; t < 4; ++t) {
-      a.tdy[t] = t >> 1;
-      a.tdx[t] = t & 1;
-      a.tw[t] = t;
-    }
-    a.osy = a.osx = 1;
-    a.ooy = a.oox = 0;
-    a.Cout = 4 * d->cout;
-    a.CoutPad = a.Cout;
-    a.ps = 1;
-    if (a.Cout % 16 != 0) return fsr_fail(-2, "fsr_conv3x3: stride-2 data gradient needs cout %% 4 == 0");
-    return fsr_conv_igemm_dispatch(d->dtype, a, 1, stream);
-  }
-  // stride 2, odd extents: split dx into its four parity classes.  For dx row y = 2i+py the contributing
+  // stride 2: split dx into its four parity classes.  For dx row y = 2i+py the contributing
   // filter rows are ky = 1 (py = 0; dy row i) or ky in {0, 2} (py = 1; dy rows i+1, i).
   for (int py = 0; py < 2; ++py)
     for (int px = 0; px < 2; ++px) {

@@ -3,24 +3,6 @@
 #include "fsr_common.h"
 #include "fsr_host.h"
 
-// FSR_PACK_DGRAD_S2: [4 slices (a,b)][4*cin rows (q, ci)][k_pad]
-template <typename T>
-__global__ void pack_dgrad_s2_kernel(const float* __restrict__ w, T* __restrict__ out, int cout, int cin, int K) {
-  const long long total = 4LL * 4 * cin * K;
-  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
-       i += (long long)gridDim.x * blockDim.x) {
-    const int k = (int)(i % K);
-    const int row = (int)((i / K) % (4 * cin));
-    const int t = (int)(i / ((long long)K * 4 * cin));
-    const int a = t >> 1, b = t & 1;
-    const int q = row / cin, ci = row - q * cin;
-    const int ky = (q >> 1) + 1 - 2 * a, kx = (q & 1) + 1 - 2 * b;
-    float v = 0.f;
-    if (k < cout && ky >= 0 && ky <= 2 && kx >= 0 && kx <= 2) v = w[((size_t)k * cin + ci) * 9 + ky * 3 + kx];
-    ElemIO<T>::st(out + i, v);
-  }
-}
-
 template <typename T>
 __global__ void pack_conv3x3_kernel(const float* __restrict__ w, T* __restrict__ out, int cout, int cin, int mode,
                                     int rows, int rows_pad, int K, int Kreal) {
@@ -58,19 +40,6 @@ extern "C" int fsr_pack_conv3x3(int dtype, int mode, const float* w_oihw, int co
                                 fsr_stream_t stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   if (!w_oihw || !packed) return fsr_fail(-1, "fsr_pack_conv3x3: null argument");
-  if (mode == FSR_PACK_DGRAD_S2) {
-    if (cin % 4 != 0 || k_pad < cout) return fsr_fail(-2, "fsr_pack_conv3x3: DGRAD_S2 needs cin %% 4 == 0 and k_pad >= cout");
-    const long long total = 16LL * cin * k_pad;
-    int blocks = (int)((total + 255) / 256);
-    if (blocks > 4096) blocks = 4096;
-    if (dtype == FSR_BF16)
-      hipLaunchKernelGGL(pack_dgrad_s2_kernel<bf16_t>, dim3(blocks), dim3(256), 0, stream, w_oihw, (bf16_t*)packed, cout, cin, k_pad);
-    else if (dtype == FSR_F32)
-      hipLaunchKernelGGL(pack_dgrad_s2_kernel<float>, dim3(blocks), dim3(256), 0, stream, w_oihw, (float*)packed, cout, cin, k_pad);
-    else
-      return fsr_fail(-2, "fsr_pack_conv3x3: unknown dtype %d", dtype);
-    return fsr_check_launch("pack_dgrad_s2_kernel");
-  }
   if (mode < FSR_PACK_FWD || mode > FSR_PACK_DGRAD_PS) return fsr_fail(-2, "fsr_pack_conv3x3: bad mode %d", mode);
   if ((mode == FSR_PACK_FWD_PS || mode == FSR_PACK_DGRAD_PS) && cout % 4 != 0)
     return fsr_fail(-2, "fsr_pack_conv3x3: pixel-shuffle packing needs cout %% 4 == 0");

@@ -59,14 +59,11 @@ def packed_filter(cd, weight, mode, k_pad):
     fwd = mode in (L.PACK_FWD, L.PACK_FWD_PS)
     rows = cout if fwd else cin
     rows_pad = (rows + 15) // 16 * 16
-    nslices = 9
-    if mode == L.PACK_DGRAD_S2:
-        rows_pad, nslices = 4 * cin, 4
     w = weight.detach()
     if w.dtype != torch.float32 or not w.is_contiguous():
         w = w.float().contiguous()
     _check_dev(w)
-    out = torch.empty(nslices * rows_pad * k_pad, dtype=cd.torch_dtype, device=w.device)
+    out = torch.empty(9 * rows_pad * k_pad, dtype=cd.torch_dtype, device=w.device)
     L.check(L.lib().fsr_pack_conv3x3(cd.code, mode, _p(w), cout, cin, k_pad, _p(out), _stream()), "fsr_pack_conv3x3")
     _pack_cache[key] = (ver, out, weight.data_ptr())
     if len(_pack_cache) > 4096:
@@ -318,10 +315,7 @@ class Conv3x3Fn(torch.autograd.Function):
                 dx = dx.permute(0, 3, 1, 2)
             else:
                 kpad = dz.shape[3] * (4 if cfg.pixel_shuffle else 1)
-                pmode = L.PACK_DGRAD_PS if cfg.pixel_shuffle else L.PACK_DGRAD
-                if cfg.stride == 2 and ih % 2 == 0 and iw % 2 == 0 and not cfg.pixel_shuffle:
-                    pmode = L.PACK_DGRAD_S2      # one launch for all four output parities
-                wpk = packed_filter(cd, weight, pmode, kpad)
+                wpk = packed_filter(cd, weight, L.PACK_DGRAD_PS if cfg.pixel_shuffle else L.PACK_DGRAD, kpad)
                 mask = xin if cfg.input_act_bwd is not None else None
                 dx, _, _ = conv3x3_raw(cd, dz, wpk, cin_pad, mode=L.CONV_DGRAD, out_hw=(ih, iw), stride=cfg.stride,
                                        in_pixel_shuffled=cfg.pixel_shuffle, alg_k=cout, dact_mask=mask,

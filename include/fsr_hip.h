@@ -36,7 +36,7 @@ extern "C" {
 enum { FSR_F32 = 0, FSR_BF16 = 1 };
 enum { FSR_ACT_NONE = 0, FSR_ACT_RELU = 1, FSR_ACT_LEAKY = 2, FSR_ACT_PRELU = 3, FSR_ACT_TANH = 4 };
 enum { FSR_CONV_FWD = 0, FSR_CONV_DGRAD = 1 };
-enum { FSR_PACK_FWD = 0, FSR_PACK_FWD_PS = 1, FSR_PACK_DGRAD = 2, FSR_PACK_DGRAD_PS = 3, FSR_PACK_DGRAD_S2 = 4 };
+enum { FSR_PACK_FWD = 0, FSR_PACK_FWD_PS = 1, FSR_PACK_DGRAD = 2, FSR_PACK_DGRAD_PS = 3 };
 
 typedef void* fsr_stream_t; /* hipStream_t */
 
@@ -53,13 +53,9 @@ int fsr_device_info(char* buf, size_t buflen);
  *                      the PixelShuffle(2) convs (model.py:36,40) stores contiguous channels
  *   FSR_PACK_DGRAD     rows = cin,  K = cout                 (transposed filter for dL/dx)
  *   FSR_PACK_DGRAD_PS  as DGRAD with K permuted like FWD_PS rows
- *   FSR_PACK_DGRAD_S2  data gradient of a STRIDE-2 conv as one stride-1 launch: 4 slices (a,b in {0,1}: dy pixel
- *                      (i+a, j+b)), rows = 4*cin ordered [parity q = 2*py+px][ci] (output pixel (2i+py, 2j+px)),
- *                      K = cout; entry = w[co][ci][py+1-2a][px+1-2b] where that tap exists, else 0 (7 of 16 blocks are
- *                      zero: 16/9 of the minimal MACs, but one launch with 4x the GEMM-N instead of four thin ones)
  * rows_pad = rows rounded up to 16 (head conv, model.py:103-108; first-layer data gradients:
  * 3 -> 16); K_pad = `k_pad` >= K (3-channel inputs: K zero-padded to FSR_CPAD).  Padding is zero
- * filled.  `packed` holds 9*rows_pad*k_pad elements (FSR_PACK_DGRAD_S2: 4*(4*cin)*k_pad; cin % 4 == 0). */
+ * filled.  `packed` holds 9*rows_pad*k_pad elements. */
 int fsr_pack_conv3x3(int dtype, int mode, const float* w_oihw, int cout, int cin, int k_pad, void* packed,
                      fsr_stream_t stream);
 
@@ -73,9 +69,7 @@ int fsr_pack_conv3x3(int dtype, int mode, const float* w_oihw, int cout, int cin
  *   mode FSR_CONV_FWD  : in [n,ih,iw,cin] -> out [n,oh,ow,cout], oh = (ih-1)/stride+1
  *   mode FSR_CONV_DGRAD: in = dL/dy [n,ih,iw,cin], out = dL/dx [n,oh,ow,cout] where
  *                        (ih,iw,cin) are the forward OUTPUT dims and (oh,ow,cout) the forward
- *                        INPUT dims; stride is the forward stride.  Stride 2 with even (oh, ow) takes filters
- *                        packed FSR_PACK_DGRAD_S2 (one launch); odd extents take FSR_PACK_DGRAD (four
- *                        parity-class launches).
+ *                        INPUT dims; stride is the forward stride.
  * cin is the (padded) channel count of `in` and the K_pad of the packed filter.
  * pixel_shuffle (FWD): out is [n,2oh,2ow,cout/4]; filters packed FSR_PACK_FWD_PS.
  * in_pixel_shuffled (DGRAD): in is [n,2ih,2iw,cin/4]; filters packed FSR_PACK_DGRAD_PS.

@@ -78,7 +78,7 @@ def main():
         else:
             res += [0, 0]
         if "dgrad" in only:
-            wpd = ops.packed_filter(cd, wt, L.PACK_DGRAD_PS if ps else (L.PACK_DGRAD_S2 if stride == 2 else L.PACK_DGRAD), cout_pad)
+            wpd = ops.packed_filter(cd, wt, L.PACK_DGRAD_PS if ps else L.PACK_DGRAD, cout_pad)
             t = timeit(lambda: ops.conv3x3_raw(cd, dy, wpd, cin_pad if cin > 3 else 3, mode=L.CONV_DGRAD, out_hw=(h, w),
                                                stride=stride, in_pixel_shuffled=ps, out_f32=(cin == 3)))
             res += [t * 1e3, gflop / t]
