@@ -191,15 +191,21 @@ def main():
             for name, (h, w) in (("90x160", (90, 160)), ("180x320", (180, 320))):
                 for bsz in (1, 32):
                     x = torch.rand(bsz, 3, h, w, device=device) * 2 - 1
+                    run = G
+                    try:   # one hipGraph launch per frame/batch (batch-1 eager inference is host-launch bound)
+                        run = pkg.GraphedGenerator(G, x)
+                    except Exception as exc:  # noqa: BLE001
+                        print("bench: inference graph capture failed (%s); eager" % exc, file=sys.stderr)
                     for _ in range(3):
-                        G(x)
+                        run(x)
                     torch.cuda.synchronize()
-                    iters = 20 if bsz == 1 else 5
+                    iters = 100 if bsz == 1 else 8
                     t0 = time.perf_counter()
                     for _ in range(iters):
-                        G(x)
+                        run(x)
                     torch.cuda.synchronize()
                     inf["fps_%s_b%d" % (name, bsz)] = round(bsz * iters / (time.perf_counter() - t0), 2)
+            inf["launch"] = "hipGraph replay" if run is not G else "eager"
         out["inference"] = inf
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline()
