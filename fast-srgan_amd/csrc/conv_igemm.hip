@@ -420,7 +420,10 @@ static int dispatch_T(ConvKArgs& a, int S, hipStream_t stream) {
   // KCW: wide input-channel chunk (bf16: 64 channels = 128 B per pixel) used whenever Cin allows it at
   // stride 1 (half the barriers and halo passes per FLOP); KCN: narrow chunk (stride 2 halos are 4x larger)
   const int w16 = ((a.GH + 15) / 16) * 16 - a.GH, w8 = ((a.GH + 7) / 8) * 8 - a.GH;
-  const bool th8 = (w16 - w8 >= 8);
+  // 8-row tiles when 16-row tiles would waste half a tile, or when there are too few of them to give every CU
+  // two workgroups (batch-1 inference: a 180x320 frame is only 240 tiles of 16x16 pixels)
+  const long long tiles16 = (long long)a.N * ((a.GH + 15) / 16) * ((a.GW + 15) / 16) * (a.CoutPad / 64 > 0 ? a.CoutPad / 64 : 1);
+  const bool th8 = (w16 - w8 >= 8) || tiles16 < 1024;
   const bool wide = (a.Cin % KCW == 0) && (!a.in_ps || (a.Cin / 4) % KCW == 0);
   if (a.CoutPad % 128 == 0) {
     if (S == 2) return launch_cfg<T, 8, 128, 2, 2, KCN, 2>(a, stream);

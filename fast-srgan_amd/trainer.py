@@ -68,14 +68,41 @@ class Trainer:
         D.broadcast_parameters(self.optim_discriminator)
         self._sync_g = D.GradSync(self.optim_generator)
         self._sync_d = D.GradSync(self.optim_discriminator)
+        self._streams = {}
+        self.use_side_stream = os.environ.get("FSR_SIDE_STREAM", "1") != "0"
         self.loss_fn = ops.bce_with_logits      # torch.nn.BCEWithLogitsLoss(), trainer.py:41
         self.l1_loss = ops.smooth_l1            # torch.nn.SmoothL1Loss(), trainer.py:43
+
+    def _side_stream(self, device):
+        st = self._streams.get(str(device))
+        if st is None:
+            st = self._streams[str(device)] = torch.cuda.Stream(device=device)
+        return st
 
     # ------------------------------------------------------------------ one GAN iteration, trainer.py:171-196
     def train_step(self, lr_images, hr_images, noise=None):
         """noise: optional (n0, n1, n2) replacing the torch.rand_like draws of trainer.py:175,176,187."""
         G, Dm, V = self.generator, self.discriminator, self.perceptual_network
         ops.zero_pool_reset(lr_images.device)   # one memset for all statistics / reduction scratch of the iteration
+        # The frozen perceptual branch (VGG(hr), VGG(sr) and its backward: ~45 % of the kernel time) runs on a second
+        # HIP stream: it only meets the rest of the iteration at `sr_images` and at the loss sum, so its kernels
+        # fill the gaps the discriminator / generator kernels leave (tails, 1-workgroup-per-CU weight gradients,
+        # bandwidth-bound elementwise passes).  Captured hipGraphs keep the two branches as parallel graph paths.
+        main = torch.cuda.current_stream() if lr_images.is_cuda else None
+        side = self._side_stream(lr_images.device) if (main is not None and self.use_side_stream) else None
+
+        def on_side(fn):
+            if side is None:
+                return fn()
+            side.wait_stream(main)
+            with torch.cuda.stream(side):
+                return fn()
+
+        def features_no_grad():
+            with torch.no_grad():                                               # :191 (no gradient needed: target)
+                return V.features_nhwc(hr_images)
+
+        real_features = on_side(features_no_grad)
         # ---- discriminator step
         self.optim_discriminator.zero_grad()                                    # :171
         y_real = Dm(hr_images)                                                  # :172
@@ -90,8 +117,8 @@ class Trainer:
         discriminator_loss = 0.5 * loss_real + 0.5 * loss_fake                  # :179
         discriminator_loss.backward()                                           # :180
         self._sync_d.start()
-        with torch.no_grad():                                                   # :191 (no gradient needed: target)
-            real_features = V.features_nhwc(hr_images)                          #   runs under the D all-reduce
+        # content branch of the generator step (:190, :192) starts as soon as sr_images exists
+        content_loss = on_side(lambda: self.l1_loss(V.features_nhwc(sr_images), real_features))
         self._sync_d.wait()
         self.optim_discriminator.step()                                         # :181
         # ---- generator step
@@ -102,8 +129,8 @@ class Trainer:
         n2 = torch.rand_like(y_fake) if noise is None else noise[2]
         real_labels = 0.3 * n2 + 0.7                                            # :187
         adv_loss = 1e-1 * self.loss_fn(y_fake, real_labels)                     # :188
-        fake_features = V.features_nhwc(sr_images)                              # :190
-        content_loss = self.l1_loss(fake_features, real_features)               # :192
+        if side is not None:
+            main.wait_stream(side)
         generator_loss = 0.5 * adv_loss + 0.5 * content_loss                    # :194
         generator_loss.backward()                                               # :195
         for p in Dm.parameters():
