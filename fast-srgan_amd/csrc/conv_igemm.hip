@@ -10,15 +10,19 @@
 // and, with other tap tables, the data-gradients (dgrad) of all of the above.
 //
 // Work decomposition
-//   workgroup (WM x WN waves: 4 or 8) -> TH x 16 output pixels of one image x BN output channels
+//   workgroup (WM x WN waves: 4; 8 also compiles) -> TH x 16 output pixels of one image x BN output channels
 //   wave                              -> MT pixel rows (16 px each) x NT 16-wide channel tiles
-//   K loop                            -> input-channel chunks of KC; inside a chunk one step per tap
+//   K loop                            -> steps = (input-channel chunk of KC) x (tap); one barrier per step
 // LDS images
-//   halo : [(TH-1)*S+3][15*S+3][KC] input pixels of the current chunk, loaded ONCE per chunk and
-//          re-read by every tap (9x reuse out of LDS instead of L2), pixel pitch KC+16B so that the
-//          16 pixel rows of a fragment spread over the bank row;
-//   wl   : [2][BN][KC] filter slice of the current / next tap (double buffered: the global loads of
-//          tap t+1 are issued before the MFMAs of tap t and written after them - one barrier/tap).
+//   halo : [(TH-1)*S+3][15*S+3][KC] input pixels of the current chunk, loaded ONCE per chunk and re-read by every
+//          tap (9x reuse out of LDS instead of L2).  The loads of chunk c+1 are issued into registers at the start
+//          of chunk c (per-thread offsets are loop invariant) and committed to LDS after its last tap;
+//   wl   : [2][BN][KC] filter slices of the current / next step.  Prefetch distance is two steps: the global loads
+//          of step s+2 go into one of two register sets before the MFMAs of step s and reach LDS after the MFMAs of
+//          step s+1;
+//   pitches are conflict-free for ds_read_b128 (see PITCHW / PITCHX below).
+// Two independent 4-wave workgroups per CU overlap each other's barriers and staging (8-wave workgroups and a
+// single-launch stride-2 data gradient were measured and lost 5-10 %).
 // MFMA mapping: D[row = output channel][col = pixel] = W[cout][k] * X[k][pixel], so each lane ends
 // up with 4 consecutive output channels of one pixel and the NHWC store is a 8/16-byte vector.
 // K index permutation inside a chunk is free as long as both operands agree; both operands are
@@ -443,8 +447,9 @@ static int dispatch_T(ConvKArgs& a, int S, hipStream_t stream) {
   }
   if (a.CoutPad % 16 == 0) {  // thin outputs (head conv, image gradients) and small test networks
     if (S == 2) return launch_cfg<T, 8, 16, 4, 1, KCN, 2>(a, stream);
-    if (wide) return launch_cfg<T, 16, 16, 4, 1, KCW, 1>(a, stream);
-    return launch_cfg<T, 16, 16, 4, 1, KCN, 1>(a, stream);
+    // bandwidth/latency-bound: small 8x16 tiles keep 4-5 workgroups per CU in flight
+    if (wide) return launch_cfg<T, 8, 16, 4, 1, KCW, 1>(a, stream);
+    return launch_cfg<T, 8, 16, 4, 1, KCN, 1>(a, stream);
   }
   return fsr_fail(-2, "conv3x3: unsupported padded Cout=%d (need a multiple of 16)", a.CoutPad);
 }
