@@ -51,7 +51,7 @@ def relerr(a, b):
 def relerr2(a, b):
     """Relative L2 error.  Gradients of (Leaky/P)ReLU networks are discontinuous in the activations' signs: a 1e-6
     perturbation of the weights already moves single elements of the fp32 ORACLE's own gradients by ~1% of the
-    tensor maximum (measured: tools/grad_sensitivity.py), so element-wise max-norm bounds are not meaningful for
+    tensor maximum (measured: tests/grad_sensitivity.py), so element-wise max-norm bounds are not meaningful for
     them; the L2 norm is."""
     a, b = a.detach().double().cpu(), b.detach().double().cpu()
     return float((a - b).norm() / b.norm().clamp_min(1e-30))

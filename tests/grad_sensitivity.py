@@ -1,7 +1,7 @@
 """Shows that the fp32 ORACLE gradients of G+D move by ~1% (max-norm) under a 1e-6 relative weight perturbation:
 activation-sign flips make element-wise gradient comparisons ill-conditioned (see tests/backend.py relerr2)."""
 import sys, types, torch, importlib
-sys.path.insert(0, __import__('os').path.dirname(__import__('os').path.dirname(__import__('os').path.abspath(__file__))))
+sys.path.insert(0, __import__('os').path.dirname(__import__('os').path.dirname(__import__('os').path.abspath(__file__))))  # repo root
 from oracle import srgan_cpu as O
 pkg = importlib.import_module("fast-srgan_amd")
 ns=types.SimpleNamespace
