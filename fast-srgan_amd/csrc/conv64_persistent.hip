@@ -1,0 +1,239 @@
+// 64 -> 64 channel 3x3 convolution (stride 1) with the WHOLE filter resident in LDS: a persistent kernel.
+//
+// The 64-channel layers -- ResidualBlock conv1/conv2 and the bottleneck of the Generator
+// (/root/reference/model.py:47-64, 86-93: 17 layers forward + 17 data gradients per iteration) and vgg19
+// conv1_2 (model.py:8) -- have only K = 9*64 = 576: in the generic implicit-GEMM kernel a workgroup spends more
+// time fetching nine 8 KB filter slices from L2 (one barrier each) and in its prologue/epilogue than in its 288
+// MFMAs.  gfx950 has 160 KB of LDS per CU, and the complete bf16 filter is 72 KB:
+//
+//   LDS   : filter [9 taps][64 co][64 ci] (pitch 160 B, conflict-free)  92,160 B   loaded ONCE per workgroup
+//           halo   [18][18][64 ci]        (pitch 160 B)                51,840 B   one 16x16-pixel tile at a time
+//   grid  : one workgroup (8 waves = 2 per SIMD) per CU, walking tiles bid, bid + grid, ...
+//   wave  : 2 pixel rows x all 64 output channels (8 accumulator tiles); a tile is 144 back-to-back MFMAs per
+//           wave with NO barrier inside (nothing is restaged during a tile);
+//   tiles : the halo of the next tile is loaded into registers before the MFMAs of the current one and committed
+//           to LDS after its epilogue -- two barriers per tile instead of ten.
+// Same operand mapping, tap table, epilogue semantics (bias, ReLU/LeakyReLU/identity, InstanceNorm statistics,
+// fused activation-backward mask) and therefore the same results as conv_igemm_kernel.  bf16 only: the f32
+// filter (144 KB + pads) does not fit next to a halo, the parity mode stays on the generic kernel.
+#include "fsr_common.h"
+#include "fsr_conv_args.h"
+#include "fsr_host.h"
+
+namespace {
+
+constexpr int P64 = 80;          // LDS pitch in bf16 elements (160 B = 10 slots of 16 B: P = 2 mod 4)
+constexpr int HT = 18;           // halo extent of a 16x16 tile, 3x3 footprint
+constexpr int NTHR64 = 512;
+constexpr int W_BYTES = 9 * 64 * P64 * 2;
+constexpr int H_BYTES = HT * HT * P64 * 2;
+constexpr int LDS64 = W_BYTES + H_BYTES + 128 * 4;
+
+__device__ __forceinline__ unsigned tap64(const ConvKArgs& a, int t) {
+  return (t < 8) ? (unsigned)((a.taps_lo >> (8 * t)) & 0xffull) : a.taps_hi;
+}
+
+__global__ __launch_bounds__(NTHR64, 2) void conv64_persistent_kernel(const ConvKArgs a) {
+  typedef bf16_t T;
+  constexpr int HUNITS = HT * HT * 8;                   // 16-byte units of one halo
+  constexpr int HPT = (HUNITS + NTHR64 - 1) / NTHR64;   // 6
+  HIP_DYNAMIC_SHARED(char, smem)
+  T* wl = (T*)smem;
+  T* halo = (T*)(smem + W_BYTES);
+  float* sred = (float*)(smem + W_BYTES + H_BYTES);     // [64][2]
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int l15 = lane & 15, lg = lane >> 4;
+  const T* in = (const T*)a.in;
+  const int tiles_per_img = a.tiles_x * a.tiles_y;
+  const int ntiles = tiles_per_img * a.N;
+
+  // ---- the whole packed filter [9][64][64] -> LDS (4608 units, 9 per thread), once
+  {
+    const T* wpk = (const T*)a.wpk;
+#pragma unroll
+    for (int i = 0; i < 9; ++i) {
+      const int u = tid + i * NTHR64;                   // (slice*64 + row)*8 + unit
+      const u32x4 v = *(const u32x4*)(wpk + (size_t)u * 8);
+      *(u32x4*)(wl + (u >> 3) * P64 + (u & 7) * 8) = v;
+    }
+    if (tid < 128) sred[tid] = 0.f;
+  }
+
+  u32x4 hreg[HPT];
+  auto halo_issue = [&](int tile) {
+    const int img = tile / tiles_per_img;
+    const int rem = tile - img * tiles_per_img;
+    const int ty = rem / a.tiles_x, tx = rem - ty * a.tiles_x;
+    const int iy0 = ty * 16 + a.org_y, ix0 = tx * 16 + a.org_x;
+#pragma unroll
+    for (int i = 0; i < HPT; ++i) {
+      const int u = tid + i * NTHR64;
+      u32x4 v = (u32x4){0u, 0u, 0u, 0u};
+      if (u < HUNITS) {
+        const int unit = u & 7, p = u >> 3;
+        const int hy = p / HT, hx = p - hy * HT;
+        const int iy = iy0 + hy, ix = ix0 + hx;
+        if (iy >= 0 && iy < a.IH && ix >= 0 && ix < a.IW)
+          v = *(const u32x4*)(in + ((unsigned)((img * a.IH + iy) * a.IW + ix) * 64u + (unsigned)(unit * 8)));
+      }
+      hreg[i] = v;
+    }
+  };
+  auto halo_commit = [&]() {
+#pragma unroll
+    for (int i = 0; i < HPT; ++i) {
+      const int u = tid + i * NTHR64;
+      if (u < HUNITS) *(u32x4*)(halo + (u >> 3) * P64 + (u & 7) * 8) = hreg[i];
+    }
+  };
+
+  float slope = (a.act == FSR_ACT_PRELU) ? a.prelu[0] : a.slope;
+  if (a.act == FSR_ACT_NONE) slope = 1.f;
+  if (a.act == FSR_ACT_RELU) slope = 0.f;
+  const bool want_stats = a.stats != nullptr;
+  T* outp = (T*)a.out;
+  const T* maskp = (const T*)a.dmask;
+
+  int pixbase[2], wbase[4];
+#pragma unroll
+  for (int m = 0; m < 2; ++m) pixbase[m] = ((wave * 2 + m) * HT + l15) * P64 + lg * 8;
+#pragma unroll
+  for (int n = 0; n < 4; ++n) wbase[n] = (n * 16 + l15) * P64 + lg * 8;
+  f32x4 bias[4];
+#pragma unroll
+  for (int n = 0; n < 4; ++n) bias[n] = a.bias ? *(const f32x4*)(a.bias + n * 16 + lg * 4) : (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  int tile = (int)blockIdx.x;
+  if (tile < ntiles) halo_issue(tile);
+  __syncthreads();                 // filter + zeroed statistics visible
+  if (tile < ntiles) halo_commit();
+  __syncthreads();
+
+  for (; tile < ntiles; tile += (int)gridDim.x) {
+    const int next = tile + (int)gridDim.x;
+    if (next < ntiles) halo_issue(next);
+
+    f32x4 acc[2][4];
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+      for (int n = 0; n < 4; ++n) acc[m][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+      const unsigned tc = tap64(a, t);
+      const int toff = ((int)(tc & 3u) * HT + (int)((tc >> 2) & 3u)) * P64;
+      const T* wsl = wl + (int)(tc >> 4) * 64 * P64;
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        s16x8 wf[4], xf[2];
+#pragma unroll
+        for (int n = 0; n < 4; ++n) wf[n] = *(const s16x8*)(wsl + wbase[n] + ks * 32);
+#pragma unroll
+        for (int m = 0; m < 2; ++m) xf[m] = *(const s16x8*)(halo + pixbase[m] + toff + ks * 32);
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
+#pragma unroll
+          for (int n = 0; n < 4; ++n) acc[m][n] = mfma_bf16_16x16x32(wf[n], xf[m], acc[m][n]);
+      }
+    }
+
+    // ---- epilogue of this tile
+    const int img = tile / tiles_per_img;
+    const int rem = tile - img * tiles_per_img;
+    const int ty = rem / a.tiles_x, tx = rem - ty * a.tiles_x;
+    const int gx = tx * 16 + l15, gyb = ty * 16 + wave * 2;
+    const bool col_ok = gx < a.GW;
+    const unsigned rstride = (unsigned)(a.FOW * 64);
+    const unsigned base0 = (unsigned)((img * a.FOH + gyb) * a.FOW + gx) * 64u + (unsigned)(lg * 4);
+    static_for<0, 4>([&](auto nc) {
+      constexpr int n = decltype(nc)::value;
+      f32x4 s1 = (f32x4){0.f, 0.f, 0.f, 0.f}, s2 = (f32x4){0.f, 0.f, 0.f, 0.f};
+      static_for<0, 2>([&](auto mc) {
+        constexpr int m = decltype(mc)::value;
+        if (col_ok && gyb + m < a.GH) {
+          const unsigned off = base0 + m * rstride + n * 16;
+          f32x4 v = acc[m][n] + bias[n];
+          if (maskp) {
+            const u32x2 t = *(const u32x2*)(maskp + off);
+            const float mk[4] = {__uint_as_float(t.x << 16), __uint_as_float(t.x & 0xffff0000u),
+                                 __uint_as_float(t.y << 16), __uint_as_float(t.y & 0xffff0000u)};
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] = mk[r] > 0.f ? v[r] : v[r] * a.dmask_slope;
+          }
+          if (want_stats) {
+            s1 += v;
+            s2 += v * v;
+          }
+#pragma unroll
+          for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f) + slope * fminf(v[r], 0.f);
+          u32x2 pk;
+          pk.x = pack_bf16x2(v[0], v[1]);
+          pk.y = pack_bf16x2(v[2], v[3]);
+          *(u32x2*)(outp + off) = pk;
+        }
+      });
+      if (want_stats) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          float x1 = s1[r], x2 = s2[r];
+#pragma unroll
+          for (int o = 8; o >= 1; o >>= 1) {
+            x1 += __shfl_xor(x1, o, 64);
+            x2 += __shfl_xor(x2, o, 64);
+          }
+          if (l15 == 0) {
+            const int cl = n * 16 + lg * 4 + r;
+            atomicAdd(sred + 2 * cl, x1);
+            atomicAdd(sred + 2 * cl + 1, x2);
+          }
+        }
+      }
+    });
+    __syncthreads();   // every wave is done with the halo (and with its statistics contributions)
+    if (want_stats && tid < 128) {
+      atomicAdd(a.stats + ((size_t)img * 64 + (tid >> 1)) * 2 + (tid & 1), sred[tid]);
+      sred[tid] = 0.f;
+    }
+    if (next < ntiles) halo_commit();
+    __syncthreads();
+  }
+}
+
+}  // namespace
+
+// Returns 1 if the launch was taken, 0 if the shape is not this kernel's, < 0 on error.
+int fsr_conv64_persistent_try(int dtype, ConvKArgs& a, int S, hipStream_t stream) {
+  if (dtype != FSR_BF16 || S != 1 || a.Cin != 64 || a.Cout != 64 || a.CoutPad != 64 || a.ntaps != 9) return 0;
+  if (a.ps || a.in_ps || a.out_f32 || a.preact || a.oscale) return 0;
+  if (a.osy != 1 || a.osx != 1 || a.ooy != 0 || a.oox != 0) return 0;
+  if ((long long)a.N * a.IH * a.IW * 64 >= (1LL << 31)) return 0;
+  a.tiles_x = (a.GW + 15) / 16;
+  a.tiles_y = (a.GH + 15) / 16;
+  a.taps_lo = 0;
+  a.taps_hi = 0;
+  for (int t = 0; t < 9; ++t) {
+    if (a.tdy[t] > 2 || a.tdx[t] > 2) return 0;
+    const unsigned code = (unsigned)a.tdy[t] | ((unsigned)a.tdx[t] << 2) | ((unsigned)a.tw[t] << 4);
+    if (t < 8) a.taps_lo |= (unsigned long long)code << (8 * t);
+    else a.taps_hi = code;
+  }
+  const long long ntiles = (long long)a.tiles_x * a.tiles_y * a.N;
+  if (ntiles <= 0 || ntiles > 0x7fffffffLL) return 0;
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute((const void*)conv64_persistent_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS64);
+    attr_set = true;
+  }
+  static int cus = 0;    // one persistent workgroup per CU (LDS admits exactly one)
+  if (cus == 0) {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    cus = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
+              ? prop.multiProcessorCount : 256;
+  }
+  const int grid = (int)(ntiles < cus ? ntiles : cus);
+  hipLaunchKernelGGL(conv64_persistent_kernel, dim3(grid), dim3(NTHR64), LDS64, stream, a);
+  int rc = fsr_check_launch("conv64_persistent_kernel");
+  return rc ? rc : 1;
+}

@@ -455,6 +455,8 @@ static int dispatch_T(ConvKArgs& a, int S, hipStream_t stream) {
 }
 
 int fsr_conv_igemm_dispatch(int dtype, ConvKArgs& a, int S, hipStream_t stream) {
+  // 64 -> 64 channel stride-1 layers: persistent kernel with the whole filter resident in LDS (conv64_persistent.hip)
+  if (const int rc = fsr_conv64_persistent_try(dtype, a, S, stream)) return rc < 0 ? rc : 0;
   if (dtype == FSR_BF16) return dispatch_T<bf16_t, 64, 32>(a, S, stream);
   if (dtype == FSR_F32) return dispatch_T<float, 16, 16>(a, S, stream);
   return fsr_fail(-2, "conv3x3: unknown dtype %d", dtype);

@@ -12,3 +12,5 @@ int fsr_fail(int code, const char* fmt, ...);
 int fsr_check_launch(const char* what);
 
 int fsr_conv_igemm_dispatch(int dtype, ConvKArgs& a, int S, hipStream_t stream);
+// 1 = launched, 0 = shape not handled by the LDS-resident-filter kernel, < 0 = error
+int fsr_conv64_persistent_try(int dtype, ConvKArgs& a, int S, hipStream_t stream);

@@ -35,7 +35,7 @@ def _big(dev):
 
 
 @pytest.mark.parametrize("cdn", ["f32", "bf16"])
-@pytest.mark.parametrize("stride,cin,cout,ps", [(1, 32, 64, False), (2, 64, 64, False), (1, 32, 128, True), (1, 64, 3, False)])
+@pytest.mark.parametrize("stride,cin,cout,ps", [(1, 32, 64, False), (1, 64, 64, False), (2, 64, 64, False), (1, 32, 128, True), (1, 64, 3, False)])
 def test_conv_fwd_dgrad_wgrad(dev, cdn, stride, cin, cout, ps):
     cd = ops.Compute(cdn)
     torch.manual_seed(1)
@@ -239,3 +239,23 @@ def test_losses_and_adamw(dev):
         L.check(L.lib().fsr_adamw_step(pd.data_ptr(), g.to(dev).data_ptr(), m.data_ptr(), v.data_ptr(), n, 1e-4, 0.9, 0.999,
                                        1e-8, 0.01, step_dev.data_ptr(), 1.0, ops._stream()))
     assert (pd.cpu() - ref.detach()).abs().max() < 1e-6
+
+
+@pytest.mark.parametrize("cdn", ["f32", "bf16"])
+@pytest.mark.parametrize("cin,cout", [(64, 64), (64, 128)])
+def test_dgrad_with_fused_activation_mask(dev, cdn, cin, cout):
+    """Data gradient fused with the producer's ReLU / LeakyReLU backward (mask = saved forward input)."""
+    cd = ops.Compute(cdn)
+    torch.manual_seed(9)
+    n, h, w = (2, 33, 40) if _big(dev) else (1, 6, 18)
+    x = _q(torch.randn(n, cin, h, w), cd)                 # forward input = output of the producing activation
+    wt = _q(torch.randn(cout, cin, 3, 3) * 0.1, cd)
+    g = _q(torch.randn(n, cout, h, w), cd)
+    xr = x.clone().requires_grad_(True)
+    F.conv2d(xr, wt, None, 1, 1).backward(g)
+    for slope in (0.0, 0.2):
+        want = xr.grad * torch.where(x > 0, torch.ones(()), torch.tensor(slope))
+        wpk = ops.packed_filter(cd, wt.to(dev), L.PACK_DGRAD, cout)
+        xd = _nhwc(x, cd, dev)
+        dx, _, _ = ops.conv3x3_raw(cd, _nhwc(g, cd, dev), wpk, cin, mode=L.CONV_DGRAD, out_hw=(h, w), dact_mask=xd, dact_slope=slope)
+        assert relerr(_nchw(dx), want) < tol(cdn, 1e-5, 1e-2)
