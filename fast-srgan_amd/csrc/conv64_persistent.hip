@@ -104,15 +104,23 @@ __global__ __launch_bounds__(NTHR64, 2) void conv64_persistent_kernel(const Conv
 #pragma unroll
   for (int n = 0; n < 4; ++n) bias[n] = a.bias ? *(const f32x4*)(a.bias + n * 16 + lg * 4) : (f32x4){0.f, 0.f, 0.f, 0.f};
 
-  int tile = (int)blockIdx.x;
-  if (tile < ntiles) halo_issue(tile);
+  // a workgroup walks a CONTIGUOUS range of tiles (mostly one image): InstanceNorm statistics stay in registers
+  // across tiles and are flushed (lane shuffle -> LDS -> 128 global atomics) only when the image changes
+  const int tile_begin = (int)blockIdx.x * a.nblk_n;   // nblk_n = tiles per workgroup (set by the host)
+  const int tile_end = (tile_begin + a.nblk_n < ntiles) ? tile_begin + a.nblk_n : ntiles;
+  f32x4 s1acc[4], s2acc[4];
+#pragma unroll
+  for (int n = 0; n < 4; ++n) s1acc[n] = s2acc[n] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  int tile = tile_begin;
+  if (tile < tile_end) halo_issue(tile);
   __syncthreads();                 // filter + zeroed statistics visible
-  if (tile < ntiles) halo_commit();
+  if (tile < tile_end) halo_commit();
   __syncthreads();
 
-  for (; tile < ntiles; tile += (int)gridDim.x) {
-    const int next = tile + (int)gridDim.x;
-    if (next < ntiles) halo_issue(next);
+  for (; tile < tile_end; ++tile) {
+    const int next = tile + 1;
+    if (next < tile_end) halo_issue(next);
 
     f32x4 acc[2][4];
 #pragma unroll
@@ -146,9 +154,9 @@ __global__ __launch_bounds__(NTHR64, 2) void conv64_persistent_kernel(const Conv
     const bool col_ok = gx < a.GW;
     const unsigned rstride = (unsigned)(a.FOW * 64);
     const unsigned base0 = (unsigned)((img * a.FOH + gyb) * a.FOW + gx) * 64u + (unsigned)(lg * 4);
+    const bool flush = want_stats && (next >= tile_end || next / tiles_per_img != img);
     static_for<0, 4>([&](auto nc) {
       constexpr int n = decltype(nc)::value;
-      f32x4 s1 = (f32x4){0.f, 0.f, 0.f, 0.f}, s2 = (f32x4){0.f, 0.f, 0.f, 0.f};
       static_for<0, 2>([&](auto mc) {
         constexpr int m = decltype(mc)::value;
         if (col_ok && gyb + m < a.GH) {
@@ -162,8 +170,8 @@ __global__ __launch_bounds__(NTHR64, 2) void conv64_persistent_kernel(const Conv
             for (int r = 0; r < 4; ++r) v[r] = mk[r] > 0.f ? v[r] : v[r] * a.dmask_slope;
           }
           if (want_stats) {
-            s1 += v;
-            s2 += v * v;
+            s1acc[n] += v;
+            s2acc[n] += v * v;
           }
 #pragma unroll
           for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f) + slope * fminf(v[r], 0.f);
@@ -173,10 +181,10 @@ __global__ __launch_bounds__(NTHR64, 2) void conv64_persistent_kernel(const Conv
           *(u32x2*)(outp + off) = pk;
         }
       });
-      if (want_stats) {
+      if (flush) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          float x1 = s1[r], x2 = s2[r];
+          float x1 = s1acc[n][r], x2 = s2acc[n][r];
 #pragma unroll
           for (int o = 8; o >= 1; o >>= 1) {
             x1 += __shfl_xor(x1, o, 64);
@@ -188,14 +196,15 @@ __global__ __launch_bounds__(NTHR64, 2) void conv64_persistent_kernel(const Conv
             atomicAdd(sred + 2 * cl + 1, x2);
           }
         }
+        s1acc[n] = s2acc[n] = (f32x4){0.f, 0.f, 0.f, 0.f};
       }
     });
     __syncthreads();   // every wave is done with the halo (and with its statistics contributions)
-    if (want_stats && tid < 128) {
+    if (flush && tid < 128) {
       atomicAdd(a.stats + ((size_t)img * 64 + (tid >> 1)) * 2 + (tid & 1), sred[tid]);
       sred[tid] = 0.f;
     }
-    if (next < ntiles) halo_commit();
+    if (next < tile_end) halo_commit();
     __syncthreads();
   }
 }
@@ -232,7 +241,9 @@ int fsr_conv64_persistent_try(int dtype, ConvKArgs& a, int S, hipStream_t stream
     cus = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
               ? prop.multiProcessorCount : 256;
   }
-  const int grid = (int)(ntiles < cus ? ntiles : cus);
+  const int per = (int)((ntiles + cus - 1) / cus);          // contiguous tiles per workgroup
+  a.nblk_n = per;
+  const int grid = (int)((ntiles + per - 1) / per);
   hipLaunchKernelGGL(conv64_persistent_kernel, dim3(grid), dim3(NTHR64), LDS64, stream, a);
   int rc = fsr_check_launch("conv64_persistent_kernel");
   return rc ? rc : 1;

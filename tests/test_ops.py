@@ -40,6 +40,8 @@ def test_conv_fwd_dgrad_wgrad(dev, cdn, stride, cin, cout, ps):
     cd = ops.Compute(cdn)
     torch.manual_seed(1)
     n, h, w = (3, 37, 45) if _big(dev) else (1, 7, 19)
+    if (cin, cout, stride) == (64, 64, 1) and not _big(dev):
+        n = 2                  # the persistent 64-channel kernel: one (emulated) CU walks both images' tiles
     x = _q(torch.randn(n, cin, h, w), cd)
     wt = _q(torch.randn(cout, cin, 3, 3) * 0.1, cd)
     bias = torch.randn(cout) * 0.1

@@ -51,7 +51,8 @@ def test_two_train_steps_match_reference_trainer_f32(pkg):
         for k, p in mod.state_dict().items():
             p0, p2 = torch.from_numpy(z[f"{pre}0.{k}"]), torch.from_numpy(z[f"{pre}2.{k}"])
             upd = (p2 - p0).abs().mean()
-            assert (p.cpu() - p2).abs().mean() <= 0.12 * upd, (pre, k)   # see tests/test_oracle.py on Adam's noise gain
+            lim = 0.3 if p.numel() == 1 else 0.12      # a lone scalar has no mean to average Adam's noise gain over
+            assert (p.cpu() - p2).abs().mean() <= lim * upd, (pre, k)   # see tests/test_oracle.py on Adam's noise gain
 
 
 @pytest.mark.gpu
