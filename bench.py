@@ -161,10 +161,16 @@ def main():
     value = world * B * args.steps / elapsed
 
     # ---- roofline of the dominant kernel: one instrumented iteration (outside the timed region)
+    # (single-stream: with the perceptual branch on its second stream, kernels of both streams share the GPU and an
+    # event pair around one launch would also time its neighbours)
+    side = trainer.use_side_stream
+    trainer.use_side_stream = False
+    trainer.train_step(lr, hr)
     launches, conv_ms, conv_flops, conv_bytes = conv_profile(ops, lambda: trainer.train_step(lr, hr))
+    trainer.use_side_stream = side
     achieved = conv_flops / (conv_ms * 1e-3) / 1e12 if conv_ms > 0 else 0.0
     peak = MFMA_PEAK_TFLOPS[args.dtype]
-    roofline = {"bound": "mfma", "kernel": "conv_igemm_kernel (3x3 conv forward + data-gradient launches)",
+    roofline = {"bound": "mfma", "kernel": "conv_igemm_kernel / conv64_persistent_kernel (3x3 conv forward + data-gradient launches)",
                 "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(achieved / peak, 4),
                 "traffic": CONV_HBM_BYTES_PER_LAUNCH if (args.dtype == "bf16" and B == 32) else None,
                 "traffic_source": "rocprofv3 --pmc FETCH_SIZE (x2, gfx950 correction) + WRITE_SIZE over one iteration, "
