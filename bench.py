@@ -213,6 +213,28 @@ def main():
                     inf["fps_%s_b%d" % (name, bsz)] = round(bsz * iters / (time.perf_counter() - t0), 2)
             inf["launch"] = "hipGraph replay" if run is not G else "eager"
         out["inference"] = inf
+    if rank == 0 and not args.no_inference:
+        # device crop pipeline (dataloader.py:24-38 replacement): 96 -> 384 crops cut from a resident uint8 pool
+        import numpy as np
+        import tempfile
+        with tempfile.TemporaryDirectory() as td:
+            rng = np.random.default_rng(0)
+            paths = []
+            for i in range(4):
+                path = os.path.join(td, "img%d.npy" % i)
+                np.save(path, rng.integers(0, 256, size=(3, 1356 + 8 * i, 2040), dtype=np.uint8))   # DIV2K-sized
+                paths.append(path)
+            ds = pkg.NumpyImagesDataset(paths, lr_image_size=96, scale_factor=4, device=device)
+            for _ in pkg.DeviceBatchLoader(ds, B, 2, seed=1):
+                pass
+            torch.cuda.synchronize()
+            iters = 20
+            t0 = time.perf_counter()
+            for _ in pkg.DeviceBatchLoader(ds, B, iters, seed=2):
+                pass
+            torch.cuda.synchronize()
+            out["data_pipeline"] = {"crops_per_s": round(B * iters / (time.perf_counter() - t0), 1),
+                                    "what": "NumpyImagesDataset + DeviceBatchLoader: uint8 pool resident in HBM -> (lr, hr) float batches"}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline()
     if world > 1:

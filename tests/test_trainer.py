@@ -159,3 +159,27 @@ def test_arena_adamw_matches_torch(pkg):
         assert (p.detach() - r.detach()).abs().max() < 1e-6
     sd = opt.state_dict()
     assert set(sd["state"][0]) == {"step", "exp_avg", "exp_avg_sq"} and sd["state"][0]["exp_avg"].shape == (5, 4, 3, 3)
+
+
+@pytest.mark.gpu
+def test_device_crop_pipeline_full_size_gpu(pkg, tmp_path):
+    """NumpyImagesDataset at the bench geometry (96 -> 384 crops of 2K-wide images) on the HIP kernels vs the oracle's
+    restatement of dataloader.py:24-38, same python RNG stream."""
+    dev = select("hip")
+    rng = np.random.default_rng(3)
+    paths = []
+    for i in range(2):
+        p = str(tmp_path / f"img{i}.npy")
+        np.save(p, rng.integers(0, 256, size=(3, 500 + 40 * i, 700), dtype=np.uint8))
+        paths.append(p)
+    ds = pkg.NumpyImagesDataset(paths, lr_image_size=96, scale_factor=4, device=dev)
+    for idx in (0, 1, 0):
+        random.seed(100 + idx)
+        lr, hr = ds[idx]
+        random.seed(100 + idx)
+        lr_ref, hr_ref, _ = O.dataset_item(np.load(paths[idx]), 96, 4)
+        assert lr.shape == (3, 96, 96) and hr.shape == (3, 384, 384)
+        assert torch.equal(hr.cpu(), hr_ref)
+        assert (lr.cpu() - lr_ref).abs().max() < 1e-5
+    lr_b, hr_b = next(iter(pkg.DeviceBatchLoader(ds, batch_size=8, iterations=1, seed=5)))
+    assert lr_b.shape == (8, 3, 96, 96) and hr_b.shape == (8, 3, 384, 384) and lr_b.is_cuda
