@@ -183,3 +183,33 @@ def test_device_crop_pipeline_full_size_gpu(pkg, tmp_path):
         assert (lr.cpu() - lr_ref).abs().max() < 1e-5
     lr_b, hr_b = next(iter(pkg.DeviceBatchLoader(ds, batch_size=8, iterations=1, seed=5)))
     assert lr_b.shape == (8, 3, 96, 96) and hr_b.shape == (8, 3, 384, 384) and lr_b.is_cuda
+
+
+@pytest.mark.gpu
+def test_graph_replay_of_iteration_and_inference(pkg):
+    """hipGraph paths: a captured training iteration keeps stepping the optimizers (device-side step counters,
+    fresh label noise per replay), and GraphedGenerator reproduces eager inference bit for bit."""
+    dev = select("hip")
+    torch.manual_seed(11)
+    T = _trainer(pkg, dev, "bf16", nf=32, n_layers=1, width_div=2)
+    lr, hr = (torch.rand(2, 3, 16, 16) * 2 - 1).to(dev), (torch.rand(2, 3, 64, 64) * 2 - 1).to(dev)
+    T.capture_train_step(lr, hr, warmup=2)                # 2 warm-up iterations + 1 captured
+    base = float(T.optim_generator.step_dev)
+    p0 = T.optim_generator.flat_param.clone()
+    outs = []
+    for _ in range(3):
+        out = T.graphed_train_step(lr, hr)
+        outs.append(float(out["loss_fake"]))
+    torch.cuda.synchronize()
+    assert float(T.optim_generator.step_dev) == base + 3 and float(T.optim_discriminator.step_dev) == base + 3
+    assert torch.isfinite(T.optim_generator.flat_param).all() and not torch.equal(T.optim_generator.flat_param, p0)
+    assert len(set(outs)) == 3                             # new noise (and new weights) every replay
+    G = T.generator.eval()
+    x = (torch.rand(1, 3, 20, 24) * 2 - 1).to(dev)
+    with torch.no_grad():
+        want = G(x).clone()
+    gg = pkg.GraphedGenerator(G, x)
+    assert torch.equal(gg(x), want)
+    x2 = (torch.rand(1, 3, 20, 24) * 2 - 1).to(dev)
+    with torch.no_grad():
+        assert torch.equal(gg(x2), G(x2))
