@@ -83,6 +83,7 @@ class ZeroPool:
     def __init__(self, device, nfloats=4 << 20):
         self.buf = torch.zeros(nfloats, dtype=torch.float32, device=device)
         self.off = 0
+        self.active = False
 
     def reset(self):
         if self.off:
@@ -111,11 +112,20 @@ def zero_pool_reset(device):
     if pool is None:
         pool = _zero_pool[key] = ZeroPool(device)
     pool.reset()
+    pool.active = True
+
+
+def zero_pool_end(device):
+    """End of the iteration: later allocations (inference, metrics, captured inference graphs) must get their own
+    zero-filled memory -- the arena is only re-zeroed by the next `zero_pool_reset`."""
+    pool = _zero_pool.get(str(device))
+    if pool is not None:
+        pool.active = False
 
 
 def _zeros(shape, device):
     pool = _zero_pool.get(str(device))
-    if pool is not None:
+    if pool is not None and pool.active:
         t = pool.take(tuple(shape))
         if t is not None:
             return t

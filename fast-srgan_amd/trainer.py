@@ -140,6 +140,7 @@ class Trainer:
         self.optim_generator.step()                                             # :196
         # the loss scalars live in the per-iteration scratch arena: copy them out (one launch) so they survive the next reset
         vals = torch.stack([loss_real.detach(), loss_fake.detach(), adv_loss.detach(), content_loss.detach()])
+        ops.zero_pool_end(lr_images.device)
         return dict(zip(("loss_real", "loss_fake", "adv_loss", "content_loss"), vals.unbind(0)))
 
     # ------------------------------------------------------------------ hipGraph replay of the whole iteration
@@ -179,7 +180,9 @@ class Trainer:
         self._sync_g.start()
         self._sync_g.wait()
         self.optim_generator.step()
-        return gen_loss.detach().clone()
+        out = gen_loss.detach().clone()
+        ops.zero_pool_end(lr_images.device)
+        return out
 
     # ------------------------------------------------------------------ cold paths
     @staticmethod
