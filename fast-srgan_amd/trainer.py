@@ -82,8 +82,14 @@ class Trainer:
     # ------------------------------------------------------------------ one GAN iteration, trainer.py:171-196
     def train_step(self, lr_images, hr_images, noise=None):
         """noise: optional (n0, n1, n2) replacing the torch.rand_like draws of trainer.py:175,176,187."""
-        G, Dm, V = self.generator, self.discriminator, self.perceptual_network
         ops.zero_pool_reset(lr_images.device)   # one memset for all statistics / reduction scratch of the iteration
+        try:
+            return self._train_step(lr_images, hr_images, noise)
+        finally:
+            ops.zero_pool_end(lr_images.device)
+
+    def _train_step(self, lr_images, hr_images, noise):
+        G, Dm, V = self.generator, self.discriminator, self.perceptual_network
         # The frozen perceptual branch (VGG(hr), VGG(sr) and its backward: ~45 % of the kernel time) runs on a second
         # HIP stream: it only meets the rest of the iteration at `sr_images` and at the loss sum, so its kernels
         # fill the gaps the discriminator / generator kernels leave (tails, 1-workgroup-per-CU weight gradients,
@@ -140,7 +146,6 @@ class Trainer:
         self.optim_generator.step()                                             # :196
         # the loss scalars live in the per-iteration scratch arena: copy them out (one launch) so they survive the next reset
         vals = torch.stack([loss_real.detach(), loss_fake.detach(), adv_loss.detach(), content_loss.detach()])
-        ops.zero_pool_end(lr_images.device)
         return dict(zip(("loss_real", "loss_fake", "adv_loss", "content_loss"), vals.unbind(0)))
 
     # ------------------------------------------------------------------ hipGraph replay of the whole iteration
@@ -173,16 +178,17 @@ class Trainer:
     def pretrain_step(self, lr_images, hr_images):
         """trainer.py:107-111."""
         ops.zero_pool_reset(lr_images.device)
-        self.optim_generator.zero_grad()
-        fake_hr_images = self.generator(lr_images)
-        gen_loss = self.l1_loss(fake_hr_images, hr_images)
-        gen_loss.backward()
-        self._sync_g.start()
-        self._sync_g.wait()
-        self.optim_generator.step()
-        out = gen_loss.detach().clone()
-        ops.zero_pool_end(lr_images.device)
-        return out
+        try:
+            self.optim_generator.zero_grad()
+            fake_hr_images = self.generator(lr_images)
+            gen_loss = self.l1_loss(fake_hr_images, hr_images)
+            gen_loss.backward()
+            self._sync_g.start()
+            self._sync_g.wait()
+            self.optim_generator.step()
+            return gen_loss.detach().clone()
+        finally:
+            ops.zero_pool_end(lr_images.device)
 
     # ------------------------------------------------------------------ cold paths
     @staticmethod
