@@ -45,11 +45,6 @@ template <> struct V16<bf16_t> {
   }
 };
 
-__device__ __forceinline__ float act_fwd(float z, int act, float slope) {
-  if (act == FSR_ACT_NONE) return z;
-  if (act == FSR_ACT_RELU) return z > 0.f ? z : 0.f;
-  return z > 0.f ? z : z * slope;
-}
 // derivative with respect to the pre-activation, evaluated from the pre-activation
 __device__ __forceinline__ float act_dz(float z, int act, float slope) {
   if (act == FSR_ACT_NONE) return 1.f;
@@ -68,13 +63,6 @@ inline int image_blocks(long long units_per_image, int n) {
 inline int row_blocks(int units_per_row) {
   int b = (units_per_row + 255) / 256;
   return b < 1 ? 1 : (b > 64 ? 64 : b);
-}
-
-inline int capped_blocks(long long work_items, int per_block) {
-  long long b = (work_items + per_block - 1) / per_block;
-  if (b > 256 * 8) b = 256 * 8;  // 8 workgroups of 256 threads per CU, grid-stride the rest
-  if (b < 1) b = 1;
-  return (int)b;
 }
 
 // ------------------------------------------------------------------ InstanceNorm apply
