@@ -17,12 +17,15 @@ CLANG = "/opt/rocm/lib/llvm/bin/clang++"
 def build_emu(force=False):
     os.makedirs(OUT, exist_ok=True)
     srcs = sorted(f for f in os.listdir(CSRC) if f.endswith(".hip"))
+    runtime_src, runtime_obj = os.path.join(HERE, "emu_runtime.cpp"), os.path.join(OUT, "emu_runtime.o")
     hdrs = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
     hdrs += [os.path.join(ROOT, "include", "fsr_hip.h"), os.path.join(HERE, "include", "hip", "hip_runtime.h")]
     hdr_t = max(os.path.getmtime(h) for h in hdrs)
     flags = ["-x", "c++", "-std=c++17", "-O2", "-fPIC", "-pthread", "-Wno-unused-value",
              "-I", os.path.join(HERE, "include"), "-I", os.path.join(ROOT, "include"), "-I", CSRC]
     todo = []
+    if force or not os.path.exists(runtime_obj) or os.path.getmtime(runtime_obj) < max(os.path.getmtime(runtime_src), hdr_t):
+        todo.append((runtime_src, runtime_obj))
     for s in srcs:
         src = os.path.join(CSRC, s)
         obj = os.path.join(OUT, s[:-4] + ".o")
@@ -38,7 +41,7 @@ def build_emu(force=False):
     if todo:
         with concurrent.futures.ThreadPoolExecutor(max_workers=8) as ex:
             list(ex.map(cc, todo))
-    objs = [os.path.join(OUT, s[:-4] + ".o") for s in srcs]
+    objs = [os.path.join(OUT, s[:-4] + ".o") for s in srcs] + [runtime_obj]
     if todo or not os.path.exists(LIB):
         r = subprocess.run([CLANG, "-shared", "-fPIC", "-pthread", "-o", LIB] + objs, capture_output=True, text=True)
         if r.returncode != 0:

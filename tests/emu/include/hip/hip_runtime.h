@@ -9,7 +9,6 @@
 // kernels can be debugged without a GPU (`pytest -m "not gpu"`); the shipped library is built
 // by hipcc for gfx950 only and nothing in the package can load the emulated build.
 #pragma once
-#include <pthread.h>
 #include <stdint.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -17,7 +16,6 @@
 
 #include <cmath>
 #include <functional>
-#include <thread>
 #include <vector>
 
 #define FSR_EMU_BUILD 1
@@ -77,8 +75,15 @@ inline hipError_t hipGetDeviceProperties(hipDeviceProp_t* p, int) {
 
 namespace emu {
 
+// Execution model: the lanes of a workgroup are FIBERS on one OS thread (a 30-line x86-64 context switch in
+// emu_runtime.cpp), scheduled round-robin; wave / workgroup barriers are generation counters that yield until every
+// member has arrived.  (One OS thread per lane with pthread barriers spent > 95 % of its time in futex calls.)
+struct Barrier {
+  int count = 0, total = 0;
+  unsigned gen = 0;
+};
 struct WaveState {
-  pthread_barrier_t bar;
+  Barrier bar;
   float fa[64][8];
   float fb[64][8];
   uint64_t u64[64];
@@ -86,7 +91,7 @@ struct WaveState {
   int i32[64];
 };
 struct BlockState {
-  pthread_barrier_t bar;
+  Barrier bar;
   int nthreads;
   std::vector<WaveState*> waves;
   char* dyn_smem;
@@ -97,56 +102,47 @@ struct ThreadCtx {
   BlockState* blk;
   WaveState* w;
 };
-inline thread_local ThreadCtx ctx;
+struct Fiber {
+  void* sp = nullptr;      // saved stack pointer while the fiber is switched out
+  char* stack = nullptr;
+  bool done = false;
+  ThreadCtx c;
+};
+struct Sched {
+  std::vector<Fiber> fibers;
+  int cur = 0, live = 0;
+  void* main_sp = nullptr;
+  const std::function<void()>* body = nullptr;
+  dim3 grid;
+};
+extern "C" void fsr_emu_switch(void** save_sp, void* load_sp);   // emu_runtime.cpp
+Sched& sched();                                                   // emu_runtime.cpp (one per OS thread)
+void fiber_yield();                                               // run the next live fiber of the workgroup
+void run_workgroups(dim3 grid, dim3 block, const std::function<void()>& body);
 
-inline void wave_sync() { pthread_barrier_wait(&ctx.w->bar); }
-inline void block_sync() { pthread_barrier_wait(&ctx.blk->bar); }
+inline ThreadCtx& cur_ctx() { Sched& s = sched(); return s.fibers[s.cur].c; }
+#define ctx (::emu::cur_ctx())
+
+inline void barrier_wait(Barrier& b) {
+  const unsigned g = b.gen;
+  if (++b.count == b.total) {
+    b.count = 0;
+    ++b.gen;
+    return;
+  }
+  while (b.gen == g) fiber_yield();
+}
+inline void wave_sync() { barrier_wait(ctx.w->bar); }
+inline void block_sync() { barrier_wait(ctx.blk->bar); }
 
 inline void launch(dim3 grid, dim3 block, size_t smem, const std::function<void()>& body) {
+  (void)smem;
   const int nthreads = (int)(block.x * block.y * block.z);
   if (nthreads % 64 != 0) {
     fprintf(stderr, "emu: block size must be a multiple of 64\n");
     abort();
   }
-  BlockState blk;
-  blk.nthreads = nthreads;
-  pthread_barrier_init(&blk.bar, nullptr, nthreads);
-  blk.dyn_smem = (char*)aligned_alloc(256, 160 * 1024);
-  (void)smem;
-  const int nwaves = nthreads / 64;
-  for (int w = 0; w < nwaves; ++w) {
-    WaveState* ws = new WaveState();
-    pthread_barrier_init(&ws->bar, nullptr, 64);
-    blk.waves.push_back(ws);
-  }
-  std::vector<std::thread> threads;
-  threads.reserve(nthreads);
-  for (int t = 0; t < nthreads; ++t) {
-    threads.emplace_back([&, t]() {
-      ctx.blk = &blk;
-      ctx.lin = t;
-      ctx.lane = t & 63;
-      ctx.wave = t >> 6;
-      ctx.w = blk.waves[t >> 6];
-      ctx.bdim = block;
-      ctx.gdim = grid;
-      ctx.tid = dim3(t % block.x, (t / block.x) % block.y, t / (block.x * block.y));
-      for (unsigned bz = 0; bz < grid.z; ++bz)
-        for (unsigned by = 0; by < grid.y; ++by)
-          for (unsigned bx = 0; bx < grid.x; ++bx) {
-            ctx.bid = dim3(bx, by, bz);
-            body();
-            block_sync();  // the next workgroup reuses the static LDS images
-          }
-    });
-  }
-  for (auto& th : threads) th.join();
-  for (auto* ws : blk.waves) {
-    pthread_barrier_destroy(&ws->bar);
-    delete ws;
-  }
-  pthread_barrier_destroy(&blk.bar);
-  free(blk.dyn_smem);
+  run_workgroups(grid, block, body);
 }
 
 // ---- wave collectives ------------------------------------------------------------------
@@ -247,24 +243,25 @@ inline float atomic_add_f32(float* addr, float v) {
   }
 }
 
+#undef ctx
 }  // namespace emu
 
-#define threadIdx (emu::ctx.tid)
-#define blockIdx (emu::ctx.bid)
-#define blockDim (emu::ctx.bdim)
-#define gridDim (emu::ctx.gdim)
+#define threadIdx (emu::cur_ctx().tid)
+#define blockIdx (emu::cur_ctx().bid)
+#define blockDim (emu::cur_ctx().bdim)
+#define gridDim (emu::cur_ctx().gdim)
 #define warpSize 64
 
-#define HIP_DYNAMIC_SHARED(type, var) type* var = (type*)emu::ctx.blk->dyn_smem;
+#define HIP_DYNAMIC_SHARED(type, var) type* var = (type*)emu::cur_ctx().blk->dyn_smem;
 
 #define hipLaunchKernelGGL(kern, grid, block, smem, stream, ...) \
   emu::launch((grid), (block), (smem), [&]() { kern(__VA_ARGS__); })
 
 inline void __syncthreads() { emu::block_sync(); }
-inline float __shfl_xor(float v, int m, int = 64) { return emu::shfl_idx(v, emu::ctx.lane ^ m); }
-inline int __shfl_xor(int v, int m, int = 64) { return emu::shfl_idx_i(v, emu::ctx.lane ^ m); }
+inline float __shfl_xor(float v, int m, int = 64) { return emu::shfl_idx(v, emu::cur_ctx().lane ^ m); }
+inline int __shfl_xor(int v, int m, int = 64) { return emu::shfl_idx_i(v, emu::cur_ctx().lane ^ m); }
 inline float __shfl_down(float v, int d, int = 64) {
-  return emu::shfl_idx(v, emu::ctx.lane + d < 64 ? emu::ctx.lane + d : emu::ctx.lane);
+  return emu::shfl_idx(v, emu::cur_ctx().lane + d < 64 ? emu::cur_ctx().lane + d : emu::cur_ctx().lane);
 }
 inline float __shfl(float v, int src, int = 64) { return emu::shfl_idx(v, src); }
 inline float atomicAdd(float* a, float v) { return emu::atomic_add_f32(a, v); }

@@ -66,3 +66,72 @@ def test_two_rank_gradient_average_equals_single_process(tmp_path):
         opt.step()
     flat = torch.cat([p.detach().reshape(-1) for p in ref])
     assert (res[0]["end"] - flat).abs().max() < 1e-6
+
+
+# ------------------------------------------------------------------ the whole iteration, batch-sharded over 2 ranks
+def _tiny_trainer(pkg, dev):
+    import types
+    import warnings
+    ns = types.SimpleNamespace
+    cfg = ns(experiment=ns(name="ddp", seed=1234), generator=ns(n_filters=16, n_layers=1),
+             discriminator=ns(n_filters=16, n_layers=7),
+             training=ns(compiled=False, device=str(dev), log_iter=1, checkpoint_iter=10 ** 9, generator_lr=1e-4,
+                         discriminator_lr=1e-4, batch_size=1, compute_dtype="f32"))
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        return pkg.Trainer(cfg, perceptual_network=pkg.VGG19(compute_dtype="f32", width_div=4, seed=1234))
+
+
+def _ddp_data():
+    g = torch.Generator().manual_seed(42)
+    lr = torch.rand(2, 3, 8, 8, generator=g) * 2 - 1
+    hr = torch.rand(2, 3, 32, 32, generator=g) * 2 - 1
+    noise = [torch.rand(2, 1, 2, 2, generator=g) for _ in range(3)]
+    return lr, hr, noise
+
+
+def _step_worker(rank, world, port, out_dir):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port))
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import importlib
+    from backend import select
+    dev = select("emu")
+    pkg = importlib.import_module("fast-srgan_amd")
+    D = importlib.import_module("fast-srgan_amd.distributed")
+    D.init_from_env(backend="gloo")
+    torch.manual_seed(7 + rank)                       # different initialisation per rank; Trainer broadcasts rank 0's
+    T = _tiny_trainer(pkg, dev)
+    init = {"g": T.optim_generator.flat_param.clone(), "d": T.optim_discriminator.flat_param.clone()}
+    lr, hr, noise = _ddp_data()
+    T.train_step(lr[rank:rank + 1], hr[rank:rank + 1], [n[rank:rank + 1] for n in noise])
+    torch.save({"init": init, "g_grad": T.optim_generator.flat_grad / world, "d_grad": T.optim_discriminator.flat_grad / world,
+                "g": T.optim_generator.flat_param.clone(), "d": T.optim_discriminator.flat_param.clone()},
+               os.path.join(out_dir, f"step_rank{rank}.pt"))
+    torch.distributed.barrier()
+    torch.distributed.destroy_process_group()
+
+
+def test_two_rank_iteration_equals_single_process_at_global_batch(tmp_path):
+    """trainer.py:171-196 sharded by batch over 2 ranks (gloo, kernels on the host emulator) vs ONE process at the
+    global batch: per-sample InstanceNorm + mean-reduced losses make the averaged gradients identical."""
+    world, port = 2, _free_port()
+    mp.spawn(_step_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    res = [torch.load(os.path.join(str(tmp_path), f"step_rank{r}.pt")) for r in range(world)]
+    for k in ("g", "d"):
+        assert torch.equal(res[0]["init"][k], res[1]["init"][k])
+        assert torch.equal(res[0][k], res[1][k])                      # replicas stay identical after the iteration
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import importlib
+    from backend import relerr2, select
+    dev = select("emu")
+    pkg = importlib.import_module("fast-srgan_amd")
+    T = _tiny_trainer(pkg, dev)
+    with torch.no_grad():
+        T.optim_generator.flat_param.copy_(res[0]["init"]["g"])
+        T.optim_discriminator.flat_param.copy_(res[0]["init"]["d"])
+    lr, hr, noise = _ddp_data()
+    T.train_step(lr, hr, noise)
+    assert relerr2(res[0]["g_grad"], T.optim_generator.flat_grad) < 1e-3
+    assert relerr2(res[0]["d_grad"], T.optim_discriminator.flat_grad) < 1e-3

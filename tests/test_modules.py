@@ -14,9 +14,6 @@ from oracle import srgan_cpu as O
 
 @pytest.fixture(params=BACKENDS)
 def dev(request):
-    # whole networks on the thread-per-lane emulator take minutes: opt in with FSR_EMU_MODULES=1
-    if request.param == "emu" and os.environ.get("FSR_EMU_MODULES") != "1":
-        pytest.skip("set FSR_EMU_MODULES=1 to run whole modules on the host emulator (about 4 minutes)")
     return select(request.param)
 
 

@@ -8,7 +8,7 @@ import numpy as np
 import pytest
 import torch
 
-from backend import L, ops, relerr, select
+from backend import BACKENDS, L, ops, relerr, select
 from conftest import load_npz, sd_from
 from oracle import srgan_cpu as O
 
@@ -35,11 +35,12 @@ def _trainer(pkg, dev, cdt, z=None, nf=16, n_layers=1, width_div=4):
     return T
 
 
-@pytest.mark.gpu
-def test_two_train_steps_match_reference_trainer_f32(pkg):
+@pytest.mark.parametrize("backend", BACKENDS)
+def test_two_train_steps_match_reference_trainer_f32(pkg, backend):
     """Two iterations of the REFERENCE's Trainer.train (golden, recorded label noise) vs Trainer.train_step on the
-    HIP path in exact-f32 MFMA mode: the four logged losses within 1e-3 relative, parameter updates in the mean."""
-    dev = select("hip")
+    HIP path in exact-f32 MFMA mode: the four logged losses within 1e-3 relative, parameter updates in the mean.
+    (Also runs on the host emulator: the same kernels, lane for lane, in the CPU suite.)"""
+    dev = select(backend)
     z = load_npz("train_steps.npz")
     T = _trainer(pkg, dev, "f32", z, width_div=int(z["vgg_width_div"]))
     for it in range(2):
@@ -81,9 +82,9 @@ def test_full_width_train_step_vs_oracle(pkg, cdt):
                 assert (p.cpu() - sd_ref[k]).abs().mean() <= 0.1 * upd + 1e-12, k
 
 
-@pytest.mark.gpu
-def test_pretrain_step_vs_oracle(pkg):
-    dev = select("hip")
+@pytest.mark.parametrize("backend", BACKENDS)
+def test_pretrain_step_vs_oracle(pkg, backend):
+    dev = select(backend)
     torch.manual_seed(10)
     T = _trainer(pkg, dev, "f32")
     g_sd = {k: v.detach().cpu().clone() for k, v in T.generator.state_dict().items()}
