@@ -261,7 +261,7 @@ __global__ __launch_bounds__(256) void act_bwd_kernel(const T* __restrict__ g, c
         s1[i] += d;
         gv[i] = d;
       }
-      V16<T>::st(dz + off, gv);
+      if (dz) V16<T>::st(dz + off, gv);
     }
   }
   if (dprelu) {
@@ -502,7 +502,8 @@ extern "C" int fsr_act_bwd(int dtype, const void* g, const void* saved, int act,
                            void* dz, float* dbias, float* dprelu, int n, int h, int w, int c, int pixel_shuffled,
                            fsr_stream_t stream_) {
   hipStream_t stream = (hipStream_t)stream_;
-  if (!g || !dz) return fsr_fail(-1, "fsr_act_bwd: null argument");
+  if (!g) return fsr_fail(-1, "fsr_act_bwd: null argument");
+  if (!dz && !dbias && !dprelu) return fsr_fail(-1, "fsr_act_bwd: nothing to compute");
   if (act != FSR_ACT_NONE && !saved) return fsr_fail(-1, "fsr_act_bwd: the activation needs the saved tensor");
   if (act == FSR_ACT_PRELU && !prelu_weight) return fsr_fail(-1, "fsr_act_bwd: PReLU needs its weight");
   if (act == FSR_ACT_TANH) return fsr_fail(-2, "fsr_act_bwd: tanh is handled by fsr_tanh_bwd_to_nhwc");

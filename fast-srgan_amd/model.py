@@ -137,14 +137,17 @@ class Discriminator(torch.nn.Module):
             SimpleBlock(nf * 8, nf * 8, 2),
             torch.nn.Conv2d(nf * 8, 1, kernel_size=1, padding=0, stride=1))
         cd = self.compute
-        self._cfg_neck = ops.ConvCfg(cd, act=L.ACT_LEAKY, slope=0.2, image_in=True)
+        # the neck's LeakyReLU(0.2) backward is applied by stem.0's data-gradient epilogue (mask = the neck output it
+        # saved as its input); the neck then only needs the column sums of that gradient for its bias
+        self._cfg_neck = ops.ConvCfg(cd, act=L.ACT_LEAKY, slope=0.2, image_in=True, act_bwd_by_consumer=True)
         self._cfg_s = {1: ops.ConvCfg(cd, stride=1, stats=True), 2: ops.ConvCfg(cd, stride=2, stats=True)}
+        self._cfg_s0 = ops.ConvCfg(cd, stride=2, stats=True, input_act_bwd=0.2)
 
     def forward(self, x):
         cd = self.compute
         y, _ = ops.conv3x3(x, self.neck[0].weight, self.neck[0].bias, None, self._cfg_neck)
-        for blk in list(self.stem)[:7]:
-            u, st = ops.conv3x3(y, blk.conv.weight, None, None, self._cfg_s[blk.stride])
+        for i, blk in enumerate(list(self.stem)[:7]):
+            u, st = ops.conv3x3(y, blk.conv.weight, None, None, self._cfg_s0 if i == 0 else self._cfg_s[blk.stride])
             y = ops.instnorm_act(u, st, None, None, cd, L.ACT_LEAKY, 0.01)
         return ops.conv1x1_to_logits(y, self.stem[7].weight, self.stem[7].bias, cd)
 

@@ -233,7 +233,8 @@ class ConvCfg:
         #   that produced this conv's input (the mask is the saved input itself), so the tensor it returns is
         #   already the producer's pre-activation gradient;
         # act_bwd_by_consumer: the incoming gradient already went through this conv's own activation backward
-        #   (its consumer -- a conv with input_act_bwd or a pool with relu_mask -- did it); frozen layers only.
+        #   (its consumer -- a conv with input_act_bwd or a pool with relu_mask -- did it); a bias gradient, if
+        #   needed, then costs one read pass (column sums) instead of the three passes of a separate act_bwd.
         self.input_act_bwd, self.act_bwd_by_consumer = input_act_bwd, act_bwd_by_consumer
         self.cd, self.stride, self.act, self.slope = cd, stride, act, slope
         self.pixel_shuffle, self.stats, self.image_in = pixel_shuffle, stats, image_in
@@ -303,9 +304,11 @@ class Conv3x3Fn(torch.autograd.Function):
         else:
             g = g if g.is_contiguous() else g.contiguous()
             if cfg.act_bwd_by_consumer:
-                if ctx.needs_input_grad[2]:
-                    raise L.FsrError("act_bwd_by_consumer is for frozen layers (no bias gradient is produced)")
-                dz = g
+                dz = g          # already multiplied by this layer's act'() in the consumer's data-gradient epilogue
+                if ctx.has_bias and ctx.needs_input_grad[2]:    # bias gradient: column sums of dz, one read pass
+                    _, h, w, c = g.shape
+                    L.check(lib.fsr_act_bwd(cd.code, _p(g), None, L.ACT_NONE, 0.0, None, None, _p(dbias), None, n, h, w, c,
+                                            int(cfg.pixel_shuffle), st), "fsr_act_bwd")
             elif act != L.ACT_NONE or ctx.has_bias:
                 if act == L.ACT_PRELU:
                     dprelu = _zeros((1,), xin.device)

@@ -137,7 +137,8 @@ int fsr_instnorm_act_bwd_apply(int dtype, const void* g, const void* x, const fl
  * ReLU / LeakyReLU(slope > 0) and the saved PRE-activation for PReLU.  Tensors [n,h,w,c] `dtype`.
  * dbias (optional, float [cb]) += per-channel sums of dz; with pixel_shuffled != 0 the tensors are
  * the depth-to-space outputs of a cb = 4c channel conv and dbias index = 4*ch + 2*(y&1) + (x&1).
- * dprelu (optional) += sum g*min(saved,0). */
+ * dprelu (optional) += sum g*min(saved,0).  dz may be null when only the reductions are wanted (bias gradient of a
+ * layer whose activation backward was already applied by its consumer's data-gradient epilogue). */
 int fsr_act_bwd(int dtype, const void* g, const void* saved, int act, float slope, const float* prelu_weight,
                 void* dz, float* dbias, float* dprelu, int n, int h, int w, int c, int pixel_shuffled,
                 fsr_stream_t stream);
