@@ -111,9 +111,11 @@ class Trainer:
         real_features = on_side(features_no_grad)
         # ---- discriminator step
         self.optim_discriminator.zero_grad()                                    # :171
-        y_real = Dm(hr_images)                                                  # :172
         sr_images = G(lr_images)                                                # :173 / :185 (shared)
-        y_fake = Dm(sr_images.detach())                                         # :174
+        # :172 and :174 use the same discriminator weights and every op is per-sample, so real and fake images go
+        # through D as ONE batch of 2B: half the launches, one weight-gradient pass instead of two
+        y_both = Dm(torch.cat([hr_images, sr_images.detach()], dim=0))
+        y_real, y_fake = y_both[:hr_images.shape[0]], y_both[hr_images.shape[0]:]
         n0 = torch.rand_like(y_real) if noise is None else noise[0]
         n1 = torch.rand_like(y_fake) if noise is None else noise[1]
         real_labels = 0.3 * n0 + 0.8                                            # :175
