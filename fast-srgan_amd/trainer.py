@@ -7,6 +7,8 @@ names) and the same arithmetic per iteration as trainer.py:171-196.  Differences
     reference evaluates it twice with identical parameters (trainer.py:173 and :185);
   * the discriminator's weight gradients of the G step, which the reference computes and then discards
     at the next zero_grad (trainer.py:171), are not computed;
+  * D(hr) and D(G(lr).detach()) of the D step (trainer.py:172,174) run as one batch of 2B images (same weights,
+    per-sample ops), and the frozen perceptual branch runs on a second HIP stream;
   * one process per GPU: gradients are averaged across ranks with one RCCL all-reduce per optimizer.
 """
 import os
