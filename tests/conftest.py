@@ -28,3 +28,13 @@ def load_npz(name):
 def sd_from(npz, prefix):
     import torch
     return {k[len(prefix):]: torch.from_numpy(npz[k].copy()) for k in npz.files if k.startswith(prefix)}
+
+
+@pytest.fixture(scope="session", autouse=True)
+def _built_library():
+    """The suite needs libfsr_hip.so (ABI checks here, everything with -m gpu): build it in-tree if it is missing
+    (hipcc cross-compiles gfx950 without a GPU; about a minute).  The package itself never builds implicitly."""
+    lib = os.path.join(ROOT, "fast-srgan_amd", "libfsr_hip.so")
+    if not os.path.exists(lib):
+        importlib.import_module("fast-srgan_amd.build").build_hip(verbose=False)
+    yield
