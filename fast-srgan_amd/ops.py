@@ -7,6 +7,7 @@ enqueued on torch's current stream; nothing here synchronises, allocates pinned 
 back to a torch implementation of the math.
 """
 import ctypes
+import weakref
 
 import torch
 
@@ -45,15 +46,21 @@ def _check_dev(*ts):
 
 
 # ---------------------------------------------------------------------------------- packed filters
-_pack_cache = {}
+_pack_cache = {}   # id(weight) -> (weakref to the weight, {(mode, dtype, k_pad): (version, packed tensor)})
 
 
 def packed_filter(cd, weight, mode, k_pad):
-    """[9][rows_pad][k_pad] image of an OIHW float weight (fsr_pack_conv3x3), cached per weight version."""
-    key = (id(weight), mode, cd.code, k_pad)
-    ver = (weight._version, getattr(weight, "_fsr_epoch", 0))
-    hit = _pack_cache.get(key)
-    if hit is not None and hit[0] == ver and hit[2] == weight.data_ptr():
+    """[9][rows_pad][k_pad] image of an OIHW float weight (fsr_pack_conv3x3), cached per weight OBJECT and version.
+    Entries die with the weight (weak reference), so a recycled id()/address can never serve a stale filter."""
+    ver = (weight._version, getattr(weight, "_fsr_epoch", 0), weight.data_ptr())
+    slot = _pack_cache.get(id(weight))
+    if slot is None or slot[0]() is not weight:
+        wid = id(weight)
+        slot = (weakref.ref(weight, lambda _r, wid=wid: _pack_cache.pop(wid, None)), {})
+        _pack_cache[wid] = slot
+    key = (mode, cd.code, k_pad)
+    hit = slot[1].get(key)
+    if hit is not None and hit[0] == ver:
         return hit[1]
     cout, cin = weight.shape[0], weight.shape[1]
     fwd = mode in (L.PACK_FWD, L.PACK_FWD_PS)
@@ -65,9 +72,7 @@ def packed_filter(cd, weight, mode, k_pad):
     _check_dev(w)
     out = torch.empty(9 * rows_pad * k_pad, dtype=cd.torch_dtype, device=w.device)
     L.check(L.lib().fsr_pack_conv3x3(cd.code, mode, _p(w), cout, cin, k_pad, _p(out), _stream()), "fsr_pack_conv3x3")
-    _pack_cache[key] = (ver, out, weight.data_ptr())
-    if len(_pack_cache) > 4096:
-        _pack_cache.clear()
+    slot[1][key] = (ver, out)
     return out
 
 

@@ -62,6 +62,13 @@ class ArenaAdamW(torch.optim.Optimizer):
         for p in self._params:
             p._fsr_epoch = self._epoch
 
+    def mark_updated(self):
+        """Parameters were modified behind torch's back (a replayed hipGraph ran fsr_adamw_step): invalidate caches
+        keyed on them (ops.packed_filter)."""
+        self._epoch += 1
+        for p in self._params:
+            p._fsr_epoch = self._epoch
+
     def state_dict(self):
         """torch.optim.AdamW-shaped state (per-parameter step / exp_avg / exp_avg_sq), as trainer.py:149-156 saves."""
         state = {}

@@ -177,6 +177,10 @@ class Trainer:
         self._g_lr.copy_(lr_images, non_blocking=True)
         self._g_hr.copy_(hr_images, non_blocking=True)
         self._graph.replay()
+        # the replay stepped both optimizers on the device without running any Python: advance the host-side epochs so
+        # that eager code running afterwards (evaluation, checkpoint-time inference) re-packs the filters it caches
+        for opt in (self.optim_generator, self.optim_discriminator):
+            opt.mark_updated()
         return self._graph_out
 
     def pretrain_step(self, lr_images, hr_images):
