@@ -208,6 +208,11 @@ def test_graph_replay_of_iteration_and_inference(pkg):
     assert len(set(outs)) == 3                             # new noise (and new weights) every replay
     G = T.generator.eval()
     x = (torch.rand(1, 3, 20, 24) * 2 - 1).to(dev)
+    # eager code after replays must see the CURRENT weights (its packed-filter cache was invalidated by the replay)
+    G2 = pkg.Generator(ns(n_filters=32, n_layers=1), compute_dtype="bf16")
+    G2.load_state_dict({k: v.detach().cpu().clone() for k, v in G.state_dict().items()})
+    with torch.no_grad():
+        assert (G(x) - G2.to(dev).eval()(x)).abs().max() < 2e-2
     with torch.no_grad():
         want = G(x).clone()
     gg = pkg.GraphedGenerator(G, x)
