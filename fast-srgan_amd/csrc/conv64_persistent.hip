@@ -214,7 +214,7 @@ __global__ __launch_bounds__(NTHR64, 2) void conv64_persistent_kernel(const Conv
 // Returns 1 if the launch was taken, 0 if the shape is not this kernel's, < 0 on error.
 int fsr_conv64_persistent_try(int dtype, ConvKArgs& a, int S, hipStream_t stream) {
   if (dtype != FSR_BF16 || S != 1 || a.Cin != 64 || a.Cout != 64 || a.CoutPad != 64 || a.ntaps != 9) return 0;
-  if (a.ps || a.in_ps || a.out_f32 || a.preact || a.oscale || a.phase_mode) return 0;
+  if (a.ps || a.in_ps || a.out_f32 || a.preact || a.oscale) return 0;
   if (a.osy != 1 || a.osx != 1 || a.ooy != 0 || a.oox != 0) return 0;
   if ((long long)a.N * a.IH * a.IW * 64 >= (1LL << 31)) return 0;
   a.tiles_x = (a.GW + 15) / 16;

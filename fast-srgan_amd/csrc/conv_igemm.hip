@@ -103,11 +103,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv_igemm_kernel(const ConvK
   const int iy0 = gy0 * S + a.org_y, ix0 = gx0 * S + a.org_x;
   const T* in = (const T*)a.in;
   const T* wpk = (const T*)a.wpk;
-  const int nchunks = a.phase_mode ? 4 * a.cpp : a.Cin / KC;
-  // taps of chunk c (phase mode: the tap list of the chunk's input phase), and the channel chunk inside the tensor
-  auto ntaps_of = [&](int c) { return a.phase_mode ? a.pntaps[c / a.cpp] : a.ntaps; };
-  auto code_of = [&](int c, int t) { return a.phase_mode ? ((a.ptaps[c / a.cpp] >> (8 * t)) & 0xffu) : tap_code(a, t); };
-  auto chan_of = [&](int c) { return a.phase_mode ? (c % a.cpp) * KC : c * KC; };
+  const int nchunks = a.Cin / KC;
 
   // Halo staging is split (issue early / commit late): the global loads of chunk c+1 are issued into
   // registers at the start of chunk c and written to LDS after its last tap, so their latency hides
@@ -127,10 +123,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv_igemm_kernel(const ConvK
       const int p = u / UNITS;
       const int hx = p % HW, hy = p / HW;
       const int iy = iy0 + hy, ix = ix0 + hx;
-      if (a.phase_mode) {   // (iy, ix) index the half-resolution phase grids; phase (0,0) here, a chunk adds its phase
-        if (iy >= 0 && 2 * iy < a.IH && ix >= 0 && 2 * ix < a.IW)
-          o = (unsigned)((img * a.IH + 2 * iy) * a.IW + 2 * ix) * (unsigned)a.Cin + (unsigned)(unit * EPB);
-      } else if (iy >= 0 && iy < a.IH && ix >= 0 && ix < a.IW) {
+      if (iy >= 0 && iy < a.IH && ix >= 0 && ix < a.IW) {
         if (!a.in_ps) o = (unsigned)((img * a.IH + iy) * a.IW + ix) * (unsigned)a.Cin + (unsigned)(unit * EPB);
         else o = (unsigned)((img * 2 * a.IH + 2 * iy) * (2 * a.IW) + 2 * ix) * (unsigned)(a.Cin >> 2) + (unsigned)(unit * EPB);
       }
@@ -139,10 +132,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv_igemm_kernel(const ConvK
   }
   auto halo_issue = [&](int c) {
     unsigned add = (unsigned)(c * KC);
-    if (a.phase_mode) {
-      const int ph = c / a.cpp;
-      add = (unsigned)(((ph >> 1) * a.IW + (ph & 1)) * a.Cin + (c - ph * a.cpp) * KC);
-    } else if (a.in_ps) {  // depth-to-space input: a chunk lies inside one quadrant (host checked: (Cin/4) % KC == 0)
+    if (a.in_ps) {  // depth-to-space input: a chunk lies inside one quadrant (host checked: (Cin/4) % KC == 0)
       const int cps = a.Cin >> 2;
       const int q = (c * KC) / cps;
       add = (unsigned)(((q >> 1) * 2 * a.IW + (q & 1)) * cps + (c * KC - q * cps));
@@ -177,7 +167,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv_igemm_kernel(const ConvK
   const unsigned slice_stride = (unsigned)(a.CoutPad * a.Cin);   // elements per tap slice (< 2^31: host checked)
   const T* wnb = wpk + (size_t)nb * BN * a.Cin;
   auto wload = [&](u32x4 (&wr)[WPT], int c, int t) {
-    const T* base = wnb + ((code_of(c, t) >> 4) * slice_stride + (unsigned)chan_of(c));
+    const T* base = wnb + ((tap_code(a, t) >> 4) * slice_stride + (unsigned)(c * KC));
 #pragma unroll
     for (int i = 0; i < WPT; ++i) {
       const int u = tid + i * NTHR;
@@ -215,7 +205,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv_igemm_kernel(const ConvK
     if (has2) wload(mine, c2, t2);
     if (t == 0 && c + 1 < nchunks) halo_issue(c + 1);
     const T* wcur = wl + (size_t)P * BN * PITCHW;
-    const unsigned tc = code_of(c, t);
+    const unsigned tc = tap_code(a, t);
     const int toff = ((int)(tc & 3u) * HW + (int)((tc >> 2) & 3u)) * PITCHX;
 #pragma unroll
     for (int ks = 0; ks < KC / KSTEP; ++ks) {
@@ -238,37 +228,32 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv_igemm_kernel(const ConvK
     }
     if (has1) wstore(other, P ^ 1);
     __syncthreads();
-    if (t + 1 == ntaps_of(c) && c + 1 < nchunks) {
+    if (t + 1 == a.ntaps && c + 1 < nchunks) {
       halo_commit();
       __syncthreads();
     }
   };
 
-  int nsteps = 0;
-  for (int c = 0; c < nchunks; ++c) nsteps += ntaps_of(c);
+  const int nsteps = nchunks * a.ntaps;
   halo_issue(0);
   halo_commit();
   wload(wregA, 0, 0);
   wstore(wregA, 0);
+  if (nsteps > 1) wload(wregB, a.ntaps > 1 ? 0 : 1, a.ntaps > 1 ? 1 : 0);
+  __syncthreads();
+
   {
     int c = 0, t = 0;            // current step
-    int c1 = 0, t1 = 1;          // the next step
-    if (t1 == ntaps_of(0)) { t1 = 0; c1 = 1; }
-    if (nsteps > 1) wload(wregB, c1, t1);
-    __syncthreads();
-    int c2 = c1, t2 = t1 + 1;    // the step two ahead
-    if (nsteps > 2 && t2 == ntaps_of(c2)) { t2 = 0; ++c2; }
-    auto advance = [&](int& cc, int& tt) {
-      if (++tt == ntaps_of(cc)) { tt = 0; ++cc; }
-    };
+    int c2 = 0, t2 = 2;          // the step two ahead
+    while (t2 >= a.ntaps) { t2 -= a.ntaps; ++c2; }
     for (int s = 0; s < nsteps; s += 2) {
       step_body(std::integral_constant<int, 0>{}, c, t, s + 1 < nsteps, s + 2 < nsteps, c2, t2, wregA, wregB);
-      advance(c, t);
-      if (s + 3 < nsteps) advance(c2, t2);
+      if (++t == a.ntaps) { t = 0; ++c; }
+      if (++t2 == a.ntaps) { t2 = 0; ++c2; }
       if (s + 1 < nsteps) {
         step_body(std::integral_constant<int, 1>{}, c, t, s + 2 < nsteps, s + 3 < nsteps, c2, t2, wregB, wregA);
-        advance(c, t);
-        if (s + 4 < nsteps) advance(c2, t2);
+        if (++t == a.ntaps) { t = 0; ++c; }
+        if (++t2 == a.ntaps) { t2 = 0; ++c2; }
       }
     }
   }
@@ -404,7 +389,6 @@ static int launch_cfg(ConvKArgs& a, hipStream_t stream) {
   a.tiles_x = (a.GW + 15) / 16;
   a.tiles_y = (a.GH + TH - 1) / TH;
   a.nblk_n = a.CoutPad / BN;
-  a.cpp = a.Cin / KC;
   int maxdy = 0, maxdx = 0;
   for (int t = 0; t < a.ntaps; ++t) {
     if (a.tdy[t] > maxdy) maxdy = a.tdy[t];

@@ -82,33 +82,6 @@ extern "C" int fsr_conv3x3(const fsr_conv_desc* d, const void* in, const void* p
     a.GH = d->oh;
     a.GW = d->ow;
     a.org_y = a.org_x = -1;
-    a.osy = a.osx = 1;
-    a.ooy = a.oox = 0;
-    if (d->stride == 2 && d->ih % 2 == 0 && d->iw % 2 == 0 && !a.ps) {
-      // Stride 2 on even extents: ONE stride-1 launch over the four input phases (y&1, x&1).  Output (i, j) reads
-      // phase (p, q) at half-resolution positions (i + a, j + b), a in {-1, 0}: row 2(i+a)+p = 2i + ky - 1 gives
-      // ky = 1 (p = 0, a = 0), ky = 0 (p = 1, a = -1), ky = 2 (p = 1, a = 0); same along x.  Each phase is a
-      // compact (TH+1) x 17 halo with unit pixel stride in LDS, so 64-channel chunks fit and every barrier step
-      // carries 32 MFMAs per wave (the strided kernel: a 17 x 33 halo, 32-channel chunks, 16 MFMAs per step).
-      a.phase_mode = 1;
-      a.ntaps = 0;
-      for (int p = 0; p < 2; ++p)
-        for (int q = 0; q < 2; ++q) {
-          const int ph = 2 * p + q;
-          int cnt = 0;
-          unsigned codes = 0;
-          for (int ky = 0; ky < 3; ++ky)
-            for (int kx = 0; kx < 3; ++kx) {
-              if (((ky + 1) & 1) != p || ((kx + 1) & 1) != q) continue;   // 2i + ky - 1 has parity (ky+1)&1
-              const int dy = (ky == 0) ? 0 : 1, dx = (kx == 0) ? 0 : 1;   // a + 1, b + 1 (halo origin at i-1, j-1)
-              codes |= ((unsigned)dy | ((unsigned)dx << 2) | ((unsigned)(ky * 3 + kx) << 4)) << (8 * cnt);
-              ++cnt;
-            }
-          a.ptaps[ph] = codes;
-          a.pntaps[ph] = cnt;
-        }
-      return fsr_conv_igemm_dispatch(d->dtype, a, 1, stream);
-    }
     a.ntaps = 9;
     for (int ky = 0; ky < 3; ++ky)
       for (int kx = 0; kx < 3; ++kx) {
@@ -117,6 +90,8 @@ extern "C" int fsr_conv3x3(const fsr_conv_desc* d, const void* in, const void* p
         a.tdx[t] = kx;
         a.tw[t] = t;
       }
+    a.osy = a.osx = 1;
+    a.ooy = a.oox = 0;
     return fsr_conv_igemm_dispatch(d->dtype, a, d->stride, stream);
   }
   if (d->mode != FSR_CONV_DGRAD) return fsr_fail(-2, "fsr_conv3x3: unknown mode %d", d->mode);

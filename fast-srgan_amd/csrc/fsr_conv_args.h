@@ -37,9 +37,4 @@ struct ConvKArgs {
   int in_ps;            // `in` is stored depth-to-space(2) (gradient of a pixel-shuffle conv)
   int out_f32;          // store float regardless of T
   int tiles_x, tiles_y, nblk_n;
-  // Phase mode (stride-2 forward on even extents as a stride-1 launch over the four input phases (y&1, x&1)):
-  // chunk c -> phase c / cpp, channel chunk c % cpp; each phase has its own tap list (1, 2, 2 and 4 of the 9 taps).
-  int phase_mode, cpp;
-  unsigned ptaps[4];    // per phase: up to 4 tap codes, one byte each
-  int pntaps[4];
 };
