@@ -49,6 +49,9 @@ def _check_dev(*ts):
 _pack_cache = {}   # id(weight) -> (weakref to the weight, {(mode, dtype, k_pad): (version, packed tensor)})
 
 
+PACK_C3 = "c3"   # packed_filter mode of the first-layer (image-input) kernels
+
+
 def packed_filter(cd, weight, mode, k_pad):
     """[9][rows_pad][k_pad] image of an OIHW float weight (fsr_pack_conv3x3), cached per weight OBJECT and version.
     Entries die with the weight (weak reference), so a recycled id()/address can never serve a stale filter."""
@@ -70,6 +73,11 @@ def packed_filter(cd, weight, mode, k_pad):
     if w.dtype != torch.float32 or not w.is_contiguous():
         w = w.float().contiguous()
     _check_dev(w)
+    if mode == PACK_C3:     # first-layer kernels: [rows_pad][32]
+        out = torch.empty(((cout + 15) // 16 * 16) * 32, dtype=cd.torch_dtype, device=w.device)
+        L.check(L.lib().fsr_pack_conv3x3_c3(cd.code, _p(w), cout, _p(out), _stream()), "fsr_pack_conv3x3_c3")
+        slot[1][key] = (ver, out)
+        return out
     out = torch.empty(9 * rows_pad * k_pad, dtype=cd.torch_dtype, device=w.device)
     L.check(L.lib().fsr_pack_conv3x3(cd.code, mode, _p(w), cout, cin, k_pad, _p(out), _stream()), "fsr_pack_conv3x3")
     slot[1][key] = (ver, out)
@@ -146,15 +154,19 @@ def _const_vec(values, device):
         _const[key] = t
     return t
 
+USE_C3_KERNELS = True   # tests flip this to compare the first-layer kernels with the padded-tensor path
+
 # bench.py sets this to a list to collect (start_event, end_event, algorithmic_flops, algorithmic_bytes) per conv launch
 PROFILE_CONV = None
 
 
 def _workspace(nbytes, device):
-    buf = _ws.get(device)
+    """Split-K scratch, one buffer per (device, stream): launches on different streams may overlap."""
+    key = (device, _stream())
+    buf = _ws.get(key)
     if buf is None or buf.numel() * 4 < nbytes:
         buf = torch.empty((nbytes + 3) // 4, dtype=torch.float32, device=device)
-        _ws[device] = buf
+        _ws[key] = buf
     return buf
 
 
@@ -259,6 +271,10 @@ class Conv3x3Fn(torch.autograd.Function):
     def forward(ctx, x, weight, bias, prelu, cfg):
         cd = cfg.cd
         cout, cin = weight.shape[0], weight.shape[1]
+        if (cfg.image_in and cfg.stride == 1 and cout % 16 == 0 and not (cfg.pixel_shuffle or cfg.stats or cfg.tanh_head)
+                and USE_C3_KERNELS):
+            return Conv3x3Fn._forward_c3(ctx, x, weight, bias, prelu, cfg)
+        ctx.c3 = False
         if cfg.image_in:
             xin = image_to_nhwc(cd, x, cfg.in_scale, cfg.in_shift)
         else:
@@ -285,6 +301,46 @@ class Conv3x3Fn(torch.autograd.Function):
         ctx.mark_non_differentiable(stats)
         if cfg.tanh_head:
             return out.permute(0, 3, 1, 2), stats
+        return out, stats
+
+    @staticmethod
+    def _forward_c3(ctx, x, weight, bias, prelu, cfg):
+        """First layer straight from the (N,3,H,W) float image (fsr_conv3x3_c3_fwd): no padded NHWC copy."""
+        cd = cfg.cd
+        _check_dev(x)
+        if x.dtype != torch.float32:
+            x = x.float()
+        n, c, h, w = x.shape
+        if c != 3:
+            raise ValueError("expected a 3-channel image batch, got %s" % (tuple(x.shape),))
+        cout = weight.shape[0]
+        wpk = packed_filter(cd, weight, PACK_C3, 32)
+        training = any(ctx.needs_input_grad)
+        want_pre = training and cfg.act == L.ACT_PRELU
+        b32 = bias if bias is None or bias.dtype == torch.float32 else bias.float()
+        out = torch.empty((n, h, w, cout), dtype=cd.torch_dtype, device=x.device)
+        pre = torch.empty_like(out) if want_pre else None
+        sn, sc, sh, sw = x.stride()
+        prof = PROFILE_CONV
+        if prof is not None:
+            ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            ev0.record()
+        L.check(L.lib().fsr_conv3x3_c3_fwd(cd.code, _p(x), sn, sc, sh, sw, n, h, w, *cfg.in_scale, *cfg.in_shift, _p(wpk),
+                                           _p(b32), cfg.act, float(cfg.slope), _p(prelu), cout, _p(out), _p(pre), _stream()),
+                "fsr_conv3x3_c3_fwd")
+        if prof is not None:
+            ev1.record()
+            nbytes = x.numel() * 4 + out.numel() * out.element_size() * (2 if want_pre else 1) + wpk.numel() * wpk.element_size()
+            prof.append((ev0, ev1, 2.0 * n * h * w * cout * 27, nbytes))
+        ctx.cfg = cfg
+        ctx.c3 = True
+        ctx.dims = (cout, 3, (n, h, w, cd.cpad))
+        ctx.has_bias = bias is not None
+        ctx.x_is_image = True
+        saved_act = pre if want_pre else (out if cfg.act in (L.ACT_RELU, L.ACT_LEAKY) else None)
+        ctx.save_for_backward(x, weight, prelu, saved_act)
+        stats = torch.empty(0, device=out.device)
+        ctx.mark_non_differentiable(stats)
         return out, stats
 
     @staticmethod
@@ -341,7 +397,15 @@ class Conv3x3Fn(torch.autograd.Function):
         dw = None
         if ctx.needs_input_grad[1]:
             arena = getattr(weight, "_fsr_grad", None)  # optim.ArenaAdamW: accumulate in place, hand autograd nothing
-            dw = conv3x3_wgrad_raw(cd, xin, dz, cout, cin, cfg.stride, dy_pixel_shuffled=cfg.pixel_shuffle, out=arena)
+            if ctx.c3:      # xin is the float image itself
+                dw = arena if arena is not None else torch.zeros((cout, 3, 3, 3), dtype=torch.float32, device=xin.device)
+                need = lib.fsr_conv3x3_c3_wgrad_workspace(n, ih, iw, cout)
+                sn, sc, sh, sw = xin.stride()
+                L.check(lib.fsr_conv3x3_c3_wgrad(cd.code, _p(xin), sn, sc, sh, sw, n, ih, iw, *cfg.in_scale, *cfg.in_shift,
+                                                 _p(dz), cout, _p(dw), _p(_workspace(need, xin.device)), st),
+                        "fsr_conv3x3_c3_wgrad")
+            else:
+                dw = conv3x3_wgrad_raw(cd, xin, dz, cout, cin, cfg.stride, dy_pixel_shuffled=cfg.pixel_shuffle, out=arena)
             if arena is not None:
                 dw = None
         db = dbias if (ctx.has_bias and ctx.needs_input_grad[2]) else None

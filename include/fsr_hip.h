@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define FSR_ABI_VERSION 3
+#define FSR_ABI_VERSION 4
 
 enum { FSR_F32 = 0, FSR_BF16 = 1 };
 enum { FSR_ACT_NONE = 0, FSR_ACT_RELU = 1, FSR_ACT_LEAKY = 2, FSR_ACT_PRELU = 3, FSR_ACT_TANH = 4 };
@@ -155,6 +155,26 @@ int fsr_image_to_nhwc(int dtype, const float* img, long long sn, long long sc, l
 int fsr_tanh_bwd_to_nhwc(int dtype, const float* g, long long sn, long long sc, long long sh, long long sw,
                          const float* y_nhwc3, int n, int h, int w, void* dz, int cpad, float* dbias,
                          fsr_stream_t stream);
+
+/* ------------------------------------------------------------------ first-layer convolutions straight from the image
+ * Conv2d(3 -> cout, k3, p1) of Generator.neck (model.py:75-78), Discriminator.neck (model.py:143-146) and
+ * vgg19.features.0 (model.py:8, with VGG19.forward's normalisation model.py:20-22 folded in) without the padded
+ * NHWC copy of the image: the kernels read img (float, element strides sn,sc,sh,sw) and use
+ * round_dtype(img*scale[c] + shift[c]) -- the value fsr_image_to_nhwc would have stored -- as the conv input.
+ * cout must be a multiple of 16.
+ *   fsr_pack_conv3x3_c3 : OIHW float [cout][3][3][3] -> `dtype` [round_up(cout,16)][32], k = (ky*3+kx)*3 + ci.
+ *   fsr_conv3x3_c3_fwd  : out[n,h,w,cout] = act(conv + bias); act NONE/RELU/LEAKY/PRELU; preact optional.
+ *   fsr_conv3x3_c3_wgrad: dw_oihw (float [cout][3][3][3]) += d loss / d weight for dz [n,h,w,cout] `dtype`;
+ *                         workspace of fsr_conv3x3_c3_wgrad_workspace(n,h,w,cout) bytes. */
+int fsr_pack_conv3x3_c3(int dtype, const float* w_oihw, int cout, void* packed, fsr_stream_t stream);
+int fsr_conv3x3_c3_fwd(int dtype, const float* img, long long sn, long long sc, long long sh, long long sw, int n, int h,
+                       int w, float scale0, float scale1, float scale2, float shift0, float shift1, float shift2,
+                       const void* packed_w, const float* bias, int act, float slope, const float* prelu_weight, int cout,
+                       void* out, void* preact, fsr_stream_t stream);
+size_t fsr_conv3x3_c3_wgrad_workspace(int n, int h, int w, int cout);
+int fsr_conv3x3_c3_wgrad(int dtype, const float* img, long long sn, long long sc, long long sh, long long sw, int n, int h,
+                         int w, float scale0, float scale1, float scale2, float shift0, float shift1, float shift2,
+                         const void* dz, int cout, float* dw_oihw, void* workspace, fsr_stream_t stream);
 
 /* ------------------------------------------------------------------ MaxPool2d(2,2) of vgg19.features (model.py:8)
  * x [n,h,w,c] -> y [n,h/2,w/2,c].  Backward routes g to the first maximum in window scan order; with

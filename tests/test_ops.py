@@ -4,7 +4,7 @@ import pytest
 import torch
 import torch.nn.functional as F
 
-from backend import BACKENDS, L, ops, relerr, select, tol
+from backend import BACKENDS, L, ops, relerr, relerr2, select, tol
 from oracle import srgan_cpu as O
 
 
@@ -117,6 +117,75 @@ def test_conv_image_in_and_tanh_head_autograd(dev, cdn):
     assert relerr(_nchw(xd.grad), xr.grad) < tol(cdn, 1e-4, 2e-2)
     assert relerr(wd.grad, wr.grad) < tol(cdn, 1e-4, 2e-2)
     assert relerr(bd.grad, br.grad) < tol(cdn, 1e-4, 1e-2)
+
+
+@pytest.mark.parametrize("cdn", ["f32", "bf16"])
+@pytest.mark.parametrize("cout,act,layout", [(32, L.ACT_NONE, "nchw"), (64, L.ACT_PRELU, "nchw"), (128, L.ACT_NONE, "nhwc"),
+                                             (128, L.ACT_RELU, "nhwc")])
+def test_first_layer_kernels(dev, cdn, cout, act, layout):
+    """fsr_conv3x3_c3_fwd / _wgrad (image read directly) against torch AND against the padded-tensor path they replace:
+    ragged sizes (partial 16x16 / 8x16 tiles), several slabs, channel blocks beyond 64, PReLU pre-activation."""
+    cd = ops.Compute(cdn)
+    torch.manual_seed(11)
+    n, h, w = (6, 163, 210) if _big(dev) else (2, 11, 21)   # GPU: 1764 tiles -> two per slab
+    img = torch.rand(n, 3, h, w) * 2 - 1
+    if layout == "nhwc":
+        img = img.permute(0, 2, 3, 1).contiguous().permute(0, 3, 1, 2)
+    wt = _q(torch.randn(cout, 3, 3, 3) * 0.2, cd)
+    b = torch.randn(cout) * 0.1
+    a = torch.tensor([0.25])
+    scale, shift = (0.9, 1.1, 1.3), (0.1, -0.2, 0.3)
+    cfg = ops.ConvCfg(cd, act=act, slope=0.0, image_in=True, in_scale=scale, in_shift=shift)
+
+    def run():
+        xi, wd, bd = leaf(img, dev), leaf(wt, dev), leaf(b, dev)
+        ad = leaf(a, dev) if act == L.ACT_PRELU else None
+        y, _ = ops.conv3x3(xi, wd, bd, ad, cfg)
+        return xi, wd, bd, ad, y
+
+    xi, wd, bd, ad, y = run()
+    xr, wr, br, ar = leaf(img), leaf(wt), leaf(b), leaf(a)
+    xn = xr * torch.tensor(scale).view(1, 3, 1, 1) + torch.tensor(shift).view(1, 3, 1, 1)
+    xn = xn + (_q(xn.detach(), cd) - xn.detach())
+    z = F.conv2d(xn, wr, br, 1, 1)
+    yr = {L.ACT_NONE: z, L.ACT_RELU: F.relu(z), L.ACT_PRELU: F.prelu(z, ar)}[act]
+    assert relerr(_nchw(y), yr) < tol(cdn, 1e-5, 2e-2)
+    g = _q(torch.randn_like(yr), cd)
+    y.backward(_nhwc(g, cd, dev))
+    yr.backward(g)
+    # A ReLU-family mask evaluated in a different summation order flips where |z| ~ 1e-7 -- a handful of the 10^7
+    # outputs of the GPU-sized case, each worth a whole input-gradient pixel / ~1e-3 of a filter-gradient entry -- so
+    # gradients behind an activation are compared in relative L2.
+    # (the activation-free cases keep the tight max-norm bound on the kernels themselves)
+    err, t32 = (relerr, 1e-4) if act == L.ACT_NONE else (relerr2, 2e-3)
+    assert err(wd.grad, wr.grad) < tol(cdn, t32, 2e-2)
+    assert err(bd.grad, br.grad) < tol(cdn, t32, 1e-2)
+    assert err(xi.grad, xr.grad) < tol(cdn, t32, 2e-2)
+    if ad is not None:
+        assert abs(ad.grad.item() - ar.grad.item()) < tol(cdn, t32, 2e-2) * max(1.0, abs(ar.grad.item()))
+    # the padded-tensor path computes the same sums in a different order
+    ops.USE_C3_KERNELS = False
+    try:
+        xi2, wd2, bd2, ad2, y2 = run()
+        y2.backward(_nhwc(g, cd, dev))
+    finally:
+        ops.USE_C3_KERNELS = True
+    assert relerr(y.float().cpu(), y2.float().cpu()) < tol(cdn, 1e-6, 1e-2)
+    assert err(wd.grad, wd2.grad) < tol(cdn, 1e-5 if act == L.ACT_NONE else t32, 1e-3)
+
+
+def test_first_layer_kernels_reject_bad_arguments(dev):
+    cd = ops.Compute("f32")
+    lib = L.lib()
+    img = torch.zeros(1, 3, 8, 8).to(dev)
+    out = torch.zeros(1, 8, 8, 24).to(dev)
+    wpk = torch.zeros(32 * 32).to(dev)
+    args = (img.data_ptr(), 192, 64, 8, 1, 1, 8, 8, 1.0, 1.0, 1.0, 0.0, 0.0, 0.0)
+    assert lib.fsr_conv3x3_c3_fwd(cd.code, *args, wpk.data_ptr(), None, L.ACT_NONE, 0.0, None, 24, out.data_ptr(), None, None) < 0
+    assert b"multiple of 16" in lib.fsr_last_error()
+    assert lib.fsr_conv3x3_c3_fwd(cd.code, *args, wpk.data_ptr(), None, L.ACT_PRELU, 0.0, None, 16, out.data_ptr(), None, None) < 0
+    assert lib.fsr_conv3x3_c3_wgrad(cd.code, *args, None, 16, out.data_ptr(), out.data_ptr(), None) < 0
+    assert lib.fsr_conv3x3_c3_wgrad_workspace(0, 8, 8, 16) == 0
 
 
 @pytest.mark.parametrize("cdn", ["f32", "bf16"])
