@@ -33,6 +33,7 @@
 #include "fsr_conv_args.h"
 #include "fsr_host.h"
 
+#include <stdlib.h>
 #include <utility>
 
 template <typename T> struct Frag;
@@ -64,8 +65,8 @@ __device__ __forceinline__ void store_vec4(T* p, f32x4 v) {
   }
 }
 
-template <typename T, int TH, int BN, int WM, int WN, int KC, int S>
-__global__ __launch_bounds__(WM * WN * 64, 2) void conv_igemm_kernel(const ConvKArgs a) {
+template <typename T, int TH, int BN, int WM, int WN, int KC, int S, int G = 1>
+__global__ __launch_bounds__(WM * WN * 64, 2) void conv_igemm_kernel(const ConvKArgs a_in, const ConvKClasses cls) {
   static_assert(WM * WN == 4 || WM * WN == 8, "4 or 8 waves per workgroup");
   constexpr int NTHR = WM * WN * 64;
   constexpr int MT = TH / WM;
@@ -91,7 +92,24 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv_igemm_kernel(const ConvK
   const int wm = wave / WN, wn = wave % WN;
   const int l15 = lane & 15, lg = lane >> 4;
 
-  int bid = xcd_remap((int)blockIdx.x, (int)gridDim.x);
+  // class selection (wave-uniform scalar selects; a single-class launch uses the arguments as they are)
+  ConvKArgs a = a_in;
+  int bid0 = (int)blockIdx.x, nwg = (int)gridDim.x;
+  if (cls.n > 1) {
+    ConvKClass k = cls.c[0];
+    int first = 0;
+#pragma unroll
+    for (int i = 1; i < 4; ++i)
+      if (i < cls.n && bid0 >= cls.c[i - 1].wg_end) {
+        k = cls.c[i];
+        first = cls.c[i - 1].wg_end;
+      }
+    a.GH = k.GH; a.GW = k.GW; a.ntaps = k.ntaps; a.ooy = k.ooy; a.oox = k.oox;
+    a.tiles_x = k.tiles_x; a.tiles_y = k.tiles_y; a.taps_lo = k.taps_lo;
+    bid0 -= first;
+    nwg = k.wg_end - first;
+  }
+  int bid = xcd_remap(bid0, nwg);
   const int nb = bid % a.nblk_n;
   bid /= a.nblk_n;
   const int tx = bid % a.tiles_x;
@@ -200,32 +218,44 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv_igemm_kernel(const ConvK
   // One step.  P = step parity: LDS buffer P holds this step's filter slice; register set `mine` receives the
   // loads of the step two ahead (same parity: chunk c2, tap t2), register set `other` holds the next step's slice,
   // loaded one step ago.  All step bookkeeping is incremental scalar arithmetic (no division in the loop).
-  auto step_body = [&](auto parity, int c, int t, bool has1, bool has2, int c2, int t2, u32x4 (&mine)[WPT], u32x4 (&other)[WPT]) {
-    constexpr int P = decltype(parity)::value;
-    if (has2) wload(mine, c2, t2);
-    if (t == 0 && c + 1 < nchunks) halo_issue(c + 1);
-    const T* wcur = wl + (size_t)P * BN * PITCHW;
+  // the MFMAs of one tap: filter slice at `wcur` in LDS, halo window shifted by the tap's offset
+  auto tap_mfma = [&](const T* wcur, int t) {
     const unsigned tc = tap_code(a, t);
     const int toff = ((int)(tc & 3u) * HW + (int)((tc >> 2) & 3u)) * PITCHX;
 #pragma unroll
     for (int ks = 0; ks < KC / KSTEP; ++ks) {
-      frag_t wf[NT], xf[MT];
-#pragma unroll
-      for (int n = 0; n < NT; ++n) wf[n] = *(const frag_t*)(wcur + wbase[n] + ks * KSTEP);
+      // filter fragments in groups of NH tiles: with multi-tap stages the 8-tile waves would otherwise hold 12
+      // fragments (48 registers) next to 128 accumulators and the staging registers, and spill
+      constexpr int NH = (G > 1 && NT > 4) ? 4 : NT;
+      frag_t xf[MT];
 #pragma unroll
       for (int m = 0; m < MT; ++m) xf[m] = *(const frag_t*)(halo + pixbase[m] + toff + ks * KSTEP);
 #pragma unroll
-      for (int m = 0; m < MT; ++m)
+      for (int n0 = 0; n0 < NT; n0 += NH) {
+        frag_t wf[NH];
 #pragma unroll
-        for (int n = 0; n < NT; ++n) {
-          if constexpr (sizeof(T) == 2) {
-            acc[m][n] = mfma_bf16_16x16x32(wf[n], xf[m], acc[m][n]);
-          } else {
+        for (int n = 0; n < NH; ++n) wf[n] = *(const frag_t*)(wcur + wbase[n0 + n] + ks * KSTEP);
 #pragma unroll
-            for (int j = 0; j < 4; ++j) acc[m][n] = mfma_f32_16x16x4(wf[n][j], xf[m][j], acc[m][n]);
+        for (int m = 0; m < MT; ++m)
+#pragma unroll
+          for (int n = 0; n < NH; ++n) {
+            if constexpr (sizeof(T) == 2) {
+              acc[m][n0 + n] = mfma_bf16_16x16x32(wf[n], xf[m], acc[m][n0 + n]);
+            } else {
+#pragma unroll
+              for (int j = 0; j < 4; ++j) acc[m][n0 + n] = mfma_f32_16x16x4(wf[n][j], xf[m][j], acc[m][n0 + n]);
+            }
           }
-        }
+        if constexpr (NH < NT) __builtin_amdgcn_sched_barrier(0);
+      }
     }
+  };
+
+  auto step_body = [&](auto parity, int c, int t, bool has1, bool has2, int c2, int t2, u32x4 (&mine)[WPT], u32x4 (&other)[WPT]) {
+    constexpr int P = decltype(parity)::value;
+    if (has2) wload(mine, c2, t2);
+    if (t == 0 && c + 1 < nchunks) halo_issue(c + 1);
+    tap_mfma(wl + (size_t)P * BN * PITCHW, t);
     if (has1) wstore(other, P ^ 1);
     __syncthreads();
     if (t + 1 == a.ntaps && c + 1 < nchunks) {
@@ -234,28 +264,72 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv_igemm_kernel(const ConvK
     }
   };
 
-  const int nsteps = nchunks * a.ntaps;
-  halo_issue(0);
-  halo_commit();
-  wload(wregA, 0, 0);
-  wstore(wregA, 0);
-  if (nsteps > 1) wload(wregB, a.ntaps > 1 ? 0 : 1, a.ntaps > 1 ? 1 : 0);
-  __syncthreads();
+  if constexpr (G == 1) {
+    const int nsteps = nchunks * a.ntaps;
+    halo_issue(0);
+    halo_commit();
+    wload(wregA, 0, 0);
+    wstore(wregA, 0);
+    if (nsteps > 1) wload(wregB, a.ntaps > 1 ? 0 : 1, a.ntaps > 1 ? 1 : 0);
+    __syncthreads();
 
-  {
-    int c = 0, t = 0;            // current step
-    int c2 = 0, t2 = 2;          // the step two ahead
-    while (t2 >= a.ntaps) { t2 -= a.ntaps; ++c2; }
-    for (int s = 0; s < nsteps; s += 2) {
-      step_body(std::integral_constant<int, 0>{}, c, t, s + 1 < nsteps, s + 2 < nsteps, c2, t2, wregA, wregB);
-      if (++t == a.ntaps) { t = 0; ++c; }
-      if (++t2 == a.ntaps) { t2 = 0; ++c2; }
-      if (s + 1 < nsteps) {
-        step_body(std::integral_constant<int, 1>{}, c, t, s + 2 < nsteps, s + 3 < nsteps, c2, t2, wregB, wregA);
+    {
+      int c = 0, t = 0;            // current step
+      int c2 = 0, t2 = 2;          // the step two ahead
+      while (t2 >= a.ntaps) { t2 -= a.ntaps; ++c2; }
+      for (int s = 0; s < nsteps; s += 2) {
+        step_body(std::integral_constant<int, 0>{}, c, t, s + 1 < nsteps, s + 2 < nsteps, c2, t2, wregA, wregB);
         if (++t == a.ntaps) { t = 0; ++c; }
         if (++t2 == a.ntaps) { t2 = 0; ++c2; }
+        if (s + 1 < nsteps) {
+          step_body(std::integral_constant<int, 1>{}, c, t, s + 2 < nsteps, s + 3 < nsteps, c2, t2, wregB, wregA);
+          if (++t == a.ntaps) { t = 0; ++c; }
+          if (++t2 == a.ntaps) { t2 = 0; ++c2; }
+        }
       }
     }
+
+  } else {
+    // Stage = up to G taps of one chunk.  The G filter slices of a stage sit in LDS together (single
+    // buffered); the slices of the next stage are loaded into registers right after the barriers and written one stage
+    // later: two barriers per G taps (G x MT x NT x KC/KSTEP MFMAs per wave) instead of one per tap, and the halo of
+    // the next chunk is committed between the same two barriers.
+    // G = 3 serves the 9-tap launches (host checked ntaps % 3 == 0): no per-tap guards, so the compiler schedules
+    // across the taps of a stage.  G = 2 serves the 1/2/2/4-tap classes: the last stage may hold a single tap.
+    constexpr bool EXACT = (G == 3);
+    u32x4 wreg[G][WPT];
+    const int spc = (a.ntaps + G - 1) / G;     // stages per chunk
+    const int nstages = nchunks * spc;
+    halo_issue(0);
+    static_for<0, G>([&](auto jc) {
+      constexpr int j = decltype(jc)::value;
+      if (EXACT || j < a.ntaps) wload(wreg[j], 0, j);
+    });
+    int c = 0, g = 0;
+    for (int s = 0; s < nstages; ++s) {
+      if (s) __syncthreads();                  // every wave is done reading the previous stage's slices (and halo)
+      static_for<0, G>([&](auto jc) {
+        constexpr int j = decltype(jc)::value;
+        if (EXACT || g * G + j < a.ntaps) wstore(wreg[j], j);
+      });
+      if (g == 0) halo_commit();
+      __syncthreads();
+      int cn = c, gn = g + 1;
+      if (gn == spc) { gn = 0; ++cn; }
+      if (s + 1 < nstages)
+        static_for<0, G>([&](auto jc) {
+          constexpr int j = decltype(jc)::value;
+          if (EXACT || gn * G + j < a.ntaps) wload(wreg[j], cn, gn * G + j);
+        });
+      if (g == 0 && c + 1 < nchunks) halo_issue(c + 1);
+      static_for<0, G>([&](auto jc) {
+        constexpr int j = decltype(jc)::value;
+        if (EXACT || g * G + j < a.ntaps) tap_mfma(wl + (size_t)j * BN * PITCHW, g * G + j);
+      });
+      c = cn;
+      g = gn;
+    }
+    if (a.stats) __syncthreads();              // the epilogue reuses the halo image for the statistics
   }
 
   // ---------------------------------------------------------------- epilogue
@@ -378,80 +452,137 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv_igemm_kernel(const ConvK
 }
 
 // ---------------------------------------------------------------------------- host side
-template <typename T, int TH, int BN, int WM, int WN, int KC, int S>
-static int launch_cfg(ConvKArgs& a, hipStream_t stream) {
+static int pack_taps(ConvKArgs& a) {
+  a.taps_lo = 0;
+  a.taps_hi = 0;
+  for (int t = 0; t < a.ntaps; ++t) {
+    if (a.tdy[t] > 2 || a.tdx[t] > 2) return fsr_fail(-2, "conv3x3: tap offsets exceed the 3x3 footprint");
+    const unsigned code = (unsigned)a.tdy[t] | ((unsigned)a.tdx[t] << 2) | ((unsigned)a.tw[t] << 4);
+    if (t < 8) a.taps_lo |= (unsigned long long)code << (8 * t);
+    else a.taps_hi = code;
+  }
+  return 0;
+}
+
+// `more` (optional): further classes of the same launch (see ConvKClasses); they share everything with `a` except
+// the output grid, the tap table and the output offset.
+template <typename T, int TH, int BN, int WM, int WN, int KC, int S, int G = 1>
+static int launch_cfg(ConvKArgs& a, hipStream_t stream, ConvKArgs* more = nullptr, int nmore = 0) {
   constexpr int EPB = 16 / (int)sizeof(T);
   constexpr int PITCHW = KC + 2 * EPB, PITCHX = KC + (S == 2 ? 1 : 2) * EPB;
   if (a.Cin % KC != 0) return fsr_fail(-2, "conv3x3: Cin=%d is not a multiple of the chunk %d", a.Cin, KC);
   if (a.in_ps && (a.Cin / 4) % KC != 0)
     return fsr_fail(-2, "conv3x3: pixel-shuffled input needs (Cin/4)=%d to be a multiple of the chunk %d", a.Cin / 4, KC);
   if (a.CoutPad % BN != 0) return fsr_fail(-2, "conv3x3: padded Cout=%d is not a multiple of %d", a.CoutPad, BN);
-  a.tiles_x = (a.GW + 15) / 16;
-  a.tiles_y = (a.GH + TH - 1) / TH;
   a.nblk_n = a.CoutPad / BN;
-  int maxdy = 0, maxdx = 0;
-  for (int t = 0; t < a.ntaps; ++t) {
-    if (a.tdy[t] > maxdy) maxdy = a.tdy[t];
-    if (a.tdx[t] > maxdx) maxdx = a.tdx[t];
-  }
-  a.taps_lo = 0;
-  a.taps_hi = 0;
-  for (int t = 0; t < a.ntaps; ++t) {
-    const unsigned code = (unsigned)a.tdy[t] | ((unsigned)a.tdx[t] << 2) | ((unsigned)a.tw[t] << 4);
-    if (t < 8) a.taps_lo |= (unsigned long long)code << (8 * t);
-    else a.taps_hi = code;
-  }
   a.HH = (TH - 1) * S + 3;
   a.HW = 15 * S + 3;
-  if (maxdy > 2 || maxdx > 2) return fsr_fail(-2, "conv3x3: tap offsets exceed the 3x3 footprint");
-  const size_t lds = ((size_t)a.HH * a.HW * PITCHX + 2 * (size_t)BN * PITCHW) * sizeof(T);
-  auto kern = conv_igemm_kernel<T, TH, BN, WM, WN, KC, S>;
+  if ((long long)a.N * a.IH * a.IW * a.Cin >= (1LL << 31) || (long long)a.N * a.FOH * a.FOW * a.Cout >= (1LL << 31))
+    return fsr_fail(-2, "conv3x3: tensors with 2^31 or more elements are not supported");
+  if (G == 3 && (a.ntaps % 3 != 0 || nmore > 0)) return fsr_fail(-2, "conv3x3: three-tap stages need a multiple of 3 taps");
+  ConvKClasses cls = {};
+  long long nwg = 0;
+  for (int k = 0; k <= nmore; ++k) {
+    ConvKArgs& b = k ? more[k - 1] : a;
+    if (int rc = pack_taps(b)) return rc;
+    if (k && b.ntaps > 8) return fsr_fail(-2, "conv3x3: a class of a multi-class launch has more than 8 taps");
+    b.tiles_x = (b.GW + 15) / 16;
+    b.tiles_y = (b.GH + TH - 1) / TH;
+    nwg += (long long)b.tiles_x * b.tiles_y * a.N * a.nblk_n;
+    if (nwg <= 0 || nwg > 0x7fffffffLL) return fsr_fail(-2, "conv3x3: bad grid");
+    ConvKClass& c = cls.c[k];
+    c.GH = b.GH; c.GW = b.GW; c.ntaps = b.ntaps; c.ooy = b.ooy; c.oox = b.oox;
+    c.tiles_x = b.tiles_x; c.tiles_y = b.tiles_y; c.taps_lo = b.taps_lo;
+    c.wg_end = (int)nwg;
+  }
+  cls.n = nmore + 1;
+  const size_t lds = ((size_t)a.HH * a.HW * PITCHX + (G == 1 ? 2 : G) * (size_t)BN * PITCHW) * sizeof(T);
+  auto kern = conv_igemm_kernel<T, TH, BN, WM, WN, KC, S, G>;
   static bool attr_set = false;
   if (!attr_set) {
     (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
     attr_set = true;
   }
-  if ((long long)a.N * a.IH * a.IW * a.Cin >= (1LL << 31) || (long long)a.N * a.FOH * a.FOW * a.Cout >= (1LL << 31))
-    return fsr_fail(-2, "conv3x3: tensors with 2^31 or more elements are not supported");
-  const long long nwg = (long long)a.tiles_x * a.tiles_y * a.N * a.nblk_n;
-  if (nwg <= 0 || nwg > 0x7fffffffLL) return fsr_fail(-2, "conv3x3: bad grid");
-  hipLaunchKernelGGL(kern, dim3((unsigned)nwg), dim3(WM * WN * 64), lds, stream, a);
+  hipLaunchKernelGGL(kern, dim3((unsigned)nwg), dim3(WM * WN * 64), lds, stream, a, cls);
   return fsr_check_launch("conv_igemm_kernel");
 }
 
+// Tuning / test switch FSR_CONV_STAGE (bit mask, read per launch; default 30):
+//   1  three-tap stages in the tall 16x128 configuration (off: the guard-free stage body spills there)
+//   2  three-tap stages for stride-2 forward launches          4  ... for the 8x128 configurations
+//   8  ... for the 64-wide configurations                     16  stride-2 data gradient as ONE four-class launch
+//   32 force 16-row tiles (tests: lets small shapes reach the tall configurations)
+static int stage_mode() {
+  const char* e = getenv("FSR_CONV_STAGE");
+  return e ? atoi(e) : 30;
+}
+int fsr_conv_stage_mode() { return stage_mode(); }
+
+#define FSR_GO(...) return launch_cfg<T, __VA_ARGS__>(a, stream, more, nmore)
+
 template <typename T, int KCW, int KCN>
-static int dispatch_T(ConvKArgs& a, int S, hipStream_t stream) {
+static int dispatch_T(ConvKArgs& a, int S, hipStream_t stream, ConvKArgs* more = nullptr, int nmore = 0) {
   // KCW: wide input-channel chunk (bf16: 64 channels = 128 B per pixel) used whenever Cin allows it at
   // stride 1 (half the barriers and halo passes per FLOP); KCN: narrow chunk (stride 2 halos are 4x larger)
   const int w16 = ((a.GH + 15) / 16) * 16 - a.GH, w8 = ((a.GH + 7) / 8) * 8 - a.GH;
   // 8-row tiles when 16-row tiles would waste half a tile, or when there are too few of them to give every CU
   // two workgroups (batch-1 inference: a 180x320 frame is only 240 tiles of 16x16 pixels)
-  const long long tiles16 = (long long)a.N * ((a.GH + 15) / 16) * ((a.GW + 15) / 16) * (a.CoutPad / 64 > 0 ? a.CoutPad / 64 : 1);
-  const bool th8 = (w16 - w8 >= 8) || tiles16 < 1024;
+  const long long tiles16 = (long long)a.N * ((a.GH + 15) / 16) * ((a.GW + 15) / 16) * (a.CoutPad / 64 > 0 ? a.CoutPad / 64 : 1) * (nmore + 1);
+  const int sm = stage_mode();
+  const bool th8 = !(sm & 32) && ((w16 - w8 >= 8) || tiles16 < 1024);
   const bool wide = (a.Cin % KCW == 0) && (!a.in_ps || (a.Cin / 4) % KCW == 0);
+  // multi-tap stages (template parameter G): 3 for the 9-tap launches, 2 for the 1/2/2/4-tap classes of a stride-2
+  // data gradient
+  const bool t9 = a.ntaps == 9, t2 = nmore > 0 || a.ntaps == 2 || a.ntaps == 4;
+  if (nmore > 0 && S != 1) return fsr_fail(-2, "conv3x3: multi-class launches are stride-1 launches");
   if (a.CoutPad % 128 == 0) {
-    if (S == 2) return launch_cfg<T, 8, 128, 2, 2, KCN, 2>(a, stream);
+    if (S == 2) {
+      if (t9 && (sm & 2)) FSR_GO(8, 128, 2, 2, KCN, 2, 3);
+      FSR_GO(8, 128, 2, 2, KCN, 2);
+    }
     // (8-wave variants <16,128,4,2> / <32,64,8,1> halve the filter traffic per FLOP but measured 5-10 % slower:
     // one workgroup per CU means every wave waits at the same barriers; two independent 4-wave workgroups overlap)
     // tall tile (256 px x 128 co per workgroup, wave = 64 px x 128 co): 12 fragment reads per 32 MFMAs instead of 16 and
     // half the workgroups; measured +2..7 % on the 128/256-channel layers.  Narrow chunks keep two workgroups per CU.
-    if (!th8 && a.Cin >= 128) return launch_cfg<T, 16, 128, 4, 1, KCN, 1>(a, stream);
-    if (wide) return launch_cfg<T, 8, 128, 2, 2, KCW, 1>(a, stream);
-    return launch_cfg<T, 8, 128, 2, 2, KCN, 1>(a, stream);
+    if (!th8 && a.Cin >= 128) {
+      if (t9 && (sm & 1)) FSR_GO(16, 128, 4, 1, KCN, 1, 3);
+      if (t2 && (sm & 1)) FSR_GO(16, 128, 4, 1, KCN, 1, 2);
+      FSR_GO(16, 128, 4, 1, KCN, 1);
+    }
+    if (t9 && (sm & 4)) FSR_GO(8, 128, 2, 2, KCN, 1, 3);
+    if (t2 && wide && (sm & 4)) FSR_GO(8, 128, 2, 2, KCW, 1, 2);
+    if (wide) FSR_GO(8, 128, 2, 2, KCW, 1);
+    FSR_GO(8, 128, 2, 2, KCN, 1);
   }
   if (a.CoutPad % 64 == 0) {
-    if (S == 2) return launch_cfg<T, 8, 64, 2, 2, KCN, 2>(a, stream);
-    if (th8) return wide ? launch_cfg<T, 8, 64, 2, 2, KCW, 1>(a, stream) : launch_cfg<T, 8, 64, 2, 2, KCN, 1>(a, stream);
-    if (wide) return launch_cfg<T, 16, 64, 4, 1, KCW, 1>(a, stream);
-    return launch_cfg<T, 16, 64, 4, 1, KCN, 1>(a, stream);
+    if (S == 2) {
+      if (t9 && (sm & 2)) FSR_GO(8, 64, 2, 2, KCN, 2, 3);
+      FSR_GO(8, 64, 2, 2, KCN, 2);
+    }
+    if (th8) {
+      if (t2 && wide && (sm & 8)) FSR_GO(8, 64, 2, 2, KCW, 1, 2);
+      if (wide) FSR_GO(8, 64, 2, 2, KCW, 1);
+      FSR_GO(8, 64, 2, 2, KCN, 1);
+    }
+    if (t9 && (sm & 8)) FSR_GO(16, 64, 4, 1, KCN, 1, 3);
+    if (t2 && wide && (sm & 8)) FSR_GO(16, 64, 4, 1, KCW, 1, 2);
+    if (wide) FSR_GO(16, 64, 4, 1, KCW, 1);
+    FSR_GO(16, 64, 4, 1, KCN, 1);
   }
   if (a.CoutPad % 16 == 0) {  // thin outputs (head conv, image gradients) and small test networks
-    if (S == 2) return launch_cfg<T, 8, 16, 4, 1, KCN, 2>(a, stream);
+    if (S == 2) FSR_GO(8, 16, 4, 1, KCN, 2);
     // bandwidth/latency-bound: small 8x16 tiles keep 4-5 workgroups per CU in flight
-    if (wide) return launch_cfg<T, 8, 16, 4, 1, KCW, 1>(a, stream);
-    return launch_cfg<T, 8, 16, 4, 1, KCN, 1>(a, stream);
+    if (wide) FSR_GO(8, 16, 4, 1, KCW, 1);
+    FSR_GO(8, 16, 4, 1, KCN, 1);
   }
   return fsr_fail(-2, "conv3x3: unsupported padded Cout=%d (need a multiple of 16)", a.CoutPad);
+}
+
+int fsr_conv_igemm_dispatch_classes(int dtype, ConvKArgs* cls, int n, hipStream_t stream) {
+  if (n < 1 || n > 4) return fsr_fail(-2, "conv3x3: %d classes in one launch", n);
+  if (dtype == FSR_BF16) return dispatch_T<bf16_t, 64, 32>(cls[0], 1, stream, cls + 1, n - 1);
+  if (dtype == FSR_F32) return dispatch_T<float, 16, 16>(cls[0], 1, stream, cls + 1, n - 1);
+  return fsr_fail(-2, "conv3x3: unknown dtype %d", dtype);
 }
 
 int fsr_conv_igemm_dispatch(int dtype, ConvKArgs& a, int S, hipStream_t stream) {

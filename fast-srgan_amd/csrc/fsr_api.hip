@@ -117,8 +117,11 @@ extern "C" int fsr_conv3x3(const fsr_conv_desc* d, const void* in, const void* p
   }
   // stride 2: split dx into its four parity classes.  For dx row y = 2i+py the contributing
   // filter rows are ky = 1 (py = 0; dy row i) or ky in {0, 2} (py = 1; dy rows i+1, i).
-  for (int py = 0; py < 2; ++py)
-    for (int px = 0; px < 2; ++px) {
+  // The four classes go out as ONE launch, the 4-tap class first (longest workgroups first).
+  ConvKArgs cls[4];
+  int ncls = 0;
+  for (int py = 1; py >= 0; --py)
+    for (int px = 1; px >= 0; --px) {
       ConvKArgs b = a;
       b.GH = (d->oh - py + 1) / 2;
       b.GW = (d->ow - px + 1) / 2;
@@ -138,8 +141,10 @@ extern "C" int fsr_conv3x3(const fsr_conv_desc* d, const void* in, const void* p
       b.osy = b.osx = 2;
       b.ooy = py;
       b.oox = px;
-      int rc = fsr_conv_igemm_dispatch(d->dtype, b, 1, stream);
-      if (rc != 0) return rc;
+      cls[ncls++] = b;
     }
+  if (fsr_conv_stage_mode() & 16) return fsr_conv_igemm_dispatch_classes(d->dtype, cls, ncls, stream);
+  for (int k = 0; k < ncls; ++k)
+    if (int rc = fsr_conv_igemm_dispatch(d->dtype, cls[k], 1, stream)) return rc;
   return 0;
 }

@@ -38,3 +38,15 @@ struct ConvKArgs {
   int out_f32;          // store float regardless of T
   int tiles_x, tiles_y, nblk_n;
 };
+
+// A launch may cover up to four "classes" that differ only in their output grid, tap table and output offset (the
+// parity classes of a stride-2 data gradient: one launch, workgroups [wg_end[k-1], wg_end[k]) belong to class k, longest
+// classes first).  n <= 1: the ConvKArgs fields are used as they are.
+struct ConvKClass {
+  int GH, GW, ntaps, ooy, oox, tiles_x, tiles_y, wg_end;
+  unsigned long long taps_lo;
+};
+struct ConvKClasses {
+  int n;
+  ConvKClass c[4];
+};

@@ -12,5 +12,8 @@ int fsr_fail(int code, const char* fmt, ...);
 int fsr_check_launch(const char* what);
 
 int fsr_conv_igemm_dispatch(int dtype, ConvKArgs& a, int S, hipStream_t stream);
+// `n` launches that differ only in output grid / taps / output offset (stride-2 data-gradient classes) as ONE launch
+int fsr_conv_igemm_dispatch_classes(int dtype, ConvKArgs* cls, int n, hipStream_t stream);
+int fsr_conv_stage_mode();   // FSR_CONV_STAGE tuning / test switch, see conv_igemm.hip
 // 1 = launched, 0 = shape not handled by the LDS-resident-filter kernel, < 0 = error
 int fsr_conv64_persistent_try(int dtype, ConvKArgs& a, int S, hipStream_t stream);

@@ -275,3 +275,4 @@ inline float __logf(float x) { return logf(x); }
 #define __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, x, y, z) emu::mfma_f32_16x16x4((a), (b), (c))
 #define __builtin_amdgcn_ds_read_tr16_b64_v4i16(p) emu::ds_read_tr16((const void*)(p))
 #define __builtin_amdgcn_readfirstlane(x) (x)
+#define __builtin_amdgcn_sched_barrier(mask) ((void)0)

@@ -74,6 +74,31 @@ def test_conv_fwd_dgrad_wgrad(dev, cdn, stride, cin, cout, ps):
     assert relerr(dw, wr.grad) < tol(cdn, 2e-5, 2e-3)
 
 
+@pytest.mark.parametrize("mode", [0, 31, 63])
+@pytest.mark.parametrize("cdn", ["f32", "bf16"])
+@pytest.mark.parametrize("stride,cin,cout", [(1, 128, 128), (2, 64, 128), (2, 128, 64), (1, 64, 64)])
+def test_conv_stage_modes(dev, cdn, stride, cin, cout, mode, monkeypatch):
+    """Every main-loop variant of the implicit-GEMM kernel (FSR_CONV_STAGE: single-tap steps, multi-tap stages,
+    four-class stride-2 data gradient, forced 16-row tiles) gives the same forward and data gradient."""
+    monkeypatch.setenv("FSR_CONV_STAGE", str(mode))
+    cd = ops.Compute(cdn)
+    torch.manual_seed(5)
+    n, h, w = (2, 45, 37) if _big(dev) else (1, 9, 21)
+    x = _q(torch.randn(n, cin, h, w), cd)
+    wt = _q(torch.randn(cout, cin, 3, 3) * 0.05, cd)
+    xd = _nhwc(x, cd, dev)
+    wpk = ops.packed_filter(cd, wt.to(dev), L.PACK_FWD, cin)
+    y, _, _ = ops.conv3x3_raw(cd, xd, wpk, cout, stride=stride)
+    ref = F.conv2d(x, wt, None, stride, 1)
+    assert relerr(_nchw(y), ref) < tol(cdn, 1e-5, 1e-2)
+    g = _q(torch.randn_like(ref), cd)
+    xr = leaf(x)
+    F.conv2d(xr, wt, None, stride, 1).backward(g)
+    wpk_d = ops.packed_filter(cd, wt.to(dev), L.PACK_DGRAD, cout)
+    dx, _, _ = ops.conv3x3_raw(cd, _nhwc(g, cd, dev), wpk_d, cin, mode=L.CONV_DGRAD, out_hw=(h, w), stride=stride)
+    assert relerr(_nchw(dx), xr.grad) < tol(cdn, 1e-5, 1e-2)
+
+
 @pytest.mark.parametrize("cdn", ["f32", "bf16"])
 def test_conv_image_in_and_tanh_head_autograd(dev, cdn):
     """First-layer conv on a strided NCHW image (with the VGG normalisation fused) and the tanh head."""
