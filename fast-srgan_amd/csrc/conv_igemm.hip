@@ -65,7 +65,7 @@ __device__ __forceinline__ void store_vec4(T* p, f32x4 v) {
   }
 }
 
-template <typename T, int TH, int BN, int WM, int WN, int KC, int S, int G = 1>
+template <typename T, int TH, int BN, int WM, int WN, int KC, int S, int G = 1, int DMA = 0>
 __global__ __launch_bounds__(WM * WN * 64, 2) void conv_igemm_kernel(const ConvKArgs a_in, const ConvKClasses cls) {
   static_assert(WM * WN == 4 || WM * WN == 8, "4 or 8 waves per workgroup");
   constexpr int NTHR = WM * WN * 64;
@@ -213,7 +213,13 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv_igemm_kernel(const ConvK
 #pragma unroll
   for (int m = 0; m < MT; ++m) pixbase[m] = (((wm * MT + m) * S) * HW + l15 * S) * PITCHX + lg * EPB;
 #pragma unroll
-  for (int n = 0; n < NT; ++n) wbase[n] = ((wn * NT + n) * 16 + l15) * PITCHW + lg * EPB;
+  for (int n = 0; n < NT; ++n) wbase[n] = ((wn * NT + n) * 16 + l15) * (DMA ? KC : PITCHW) + (DMA ? 0 : lg * EPB);
+  // DMA filter images are unpadded rows of UNITS 16-byte units, the unit index XOR-swizzled by the row so that the
+  // four 16-lane groups of a ds_read_b128 fragment read hit 16 different slots (checked exhaustively for both widths)
+  auto swz = [](int row) { return UNITS == 4 ? ((row & 8) ? 3 : 0) : ((row >> 1) & 7); };
+  int wsw[KC / KSTEP];
+#pragma unroll
+  for (int ks = 0; ks < KC / KSTEP; ++ks) wsw[ks] = DMA ? ((ks * (KSTEP / EPB) + lg) ^ swz(l15)) * EPB : ks * KSTEP;
 
   // One step.  P = step parity: LDS buffer P holds this step's filter slice; register set `mine` receives the
   // loads of the step two ahead (same parity: chunk c2, tap t2), register set `other` holds the next step's slice,
@@ -234,7 +240,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv_igemm_kernel(const ConvK
       for (int n0 = 0; n0 < NT; n0 += NH) {
         frag_t wf[NH];
 #pragma unroll
-        for (int n = 0; n < NH; ++n) wf[n] = *(const frag_t*)(wcur + wbase[n0 + n] + ks * KSTEP);
+        for (int n = 0; n < NH; ++n) wf[n] = *(const frag_t*)(wcur + wbase[n0 + n] + wsw[ks]);
 #pragma unroll
         for (int m = 0; m < MT; ++m)
 #pragma unroll
@@ -264,7 +270,61 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv_igemm_kernel(const ConvK
     }
   };
 
-  if constexpr (G == 1) {
+  if constexpr (DMA) {
+    // Filter slices by LDS-DMA (global_load_lds_dwordx4: no staging registers, no ds_write pass), double buffered by
+    // stage (= G taps of one chunk): the DMA of stage s+1 runs under the MFMAs of stage s, ONE barrier per stage.
+    // A wave instruction writes 1 KB = 64 / UNITS filter rows linearly; the swizzle goes on the SOURCE address.
+    static_assert(UNITS == 4 || UNITS == 8, "DMA filter rows are 64 or 128 bytes");
+    constexpr bool EXACT = (G == 3);
+    constexpr int ROWS = 64 / UNITS;                       // filter rows per wave instruction
+    constexpr int NBLK = BN / ROWS;                        // wave instructions per slice
+    constexpr int NWV = WM * WN;
+    const int rib = lane / UNITS, up = lane % UNITS;       // this lane's row inside a block / LDS unit
+    const int spc = (a.ntaps + G - 1) / G;
+    const int nstages = nchunks * spc;
+    auto dma_stage = [&](int c, int g, int buf) {
+      static_for<0, G>([&](auto jc) {
+        constexpr int j = decltype(jc)::value;
+        const int t = g * G + j;
+        if (EXACT || t < a.ntaps) {
+          const T* src = wnb + ((tap_code(a, t) >> 4) * slice_stride + (unsigned)(c * KC));
+          T* dst = wl + (size_t)((buf * G + j) * BN) * KC;
+#pragma unroll
+          for (int i = 0; i < (NBLK + NWV - 1) / NWV; ++i) {
+            const int blk = wave + i * NWV;
+            if (NBLK % NWV == 0 || blk < NBLK) {
+              const int row = blk * ROWS + rib;
+              const T* g16 = src + (unsigned)(row * a.Cin + ((up ^ swz(row & 15)) * EPB));
+              __builtin_amdgcn_global_load_lds(FSR_GLOBAL_PTR(const void, g16), FSR_LDS_PTR(void, dst + blk * ROWS * KC), 16, 0, 0);
+            }
+          }
+        }
+      });
+    };
+    halo_issue(0);
+    dma_stage(0, 0, 0);
+    halo_commit();
+    __syncthreads();
+    int c = 0, g = 0;
+    for (int s = 0; s < nstages; ++s) {
+      const int buf = s & 1;
+      int cn = c, gn = g + 1;
+      if (gn == spc) { gn = 0; ++cn; }
+      if (s + 1 < nstages) dma_stage(cn, gn, buf ^ 1);   // that buffer was last read in stage s-1, a barrier ago
+      if (g == 0 && c + 1 < nchunks) halo_issue(c + 1);
+      static_for<0, G>([&](auto jc) {
+        constexpr int j = decltype(jc)::value;
+        if (EXACT || g * G + j < a.ntaps) tap_mfma(wl + (size_t)((buf * G + j) * BN) * KC, g * G + j);
+      });
+      if (gn == 0 && cn < nchunks) {           // the next stage opens a chunk: replace the halo between two barriers
+        __syncthreads();
+        halo_commit();
+      }
+      __syncthreads();                         // (drains the DMA: an LDS-DMA is a pending LDS write on vmcnt)
+      c = cn;
+      g = gn;
+    }
+  } else if constexpr (G == 1) {
     const int nsteps = nchunks * a.ntaps;
     halo_issue(0);
     halo_commit();
@@ -466,7 +526,7 @@ static int pack_taps(ConvKArgs& a) {
 
 // `more` (optional): further classes of the same launch (see ConvKClasses); they share everything with `a` except
 // the output grid, the tap table and the output offset.
-template <typename T, int TH, int BN, int WM, int WN, int KC, int S, int G = 1>
+template <typename T, int TH, int BN, int WM, int WN, int KC, int S, int G = 1, int DMA = 0>
 static int launch_cfg(ConvKArgs& a, hipStream_t stream, ConvKArgs* more = nullptr, int nmore = 0) {
   constexpr int EPB = 16 / (int)sizeof(T);
   constexpr int PITCHW = KC + 2 * EPB, PITCHX = KC + (S == 2 ? 1 : 2) * EPB;
@@ -496,8 +556,8 @@ static int launch_cfg(ConvKArgs& a, hipStream_t stream, ConvKArgs* more = nullpt
     c.wg_end = (int)nwg;
   }
   cls.n = nmore + 1;
-  const size_t lds = ((size_t)a.HH * a.HW * PITCHX + (G == 1 ? 2 : G) * (size_t)BN * PITCHW) * sizeof(T);
-  auto kern = conv_igemm_kernel<T, TH, BN, WM, WN, KC, S, G>;
+  const size_t lds = ((size_t)a.HH * a.HW * PITCHX + (DMA ? 2 * G * (size_t)BN * KC : (G == 1 ? 2 : G) * (size_t)BN * PITCHW)) * sizeof(T);
+  auto kern = conv_igemm_kernel<T, TH, BN, WM, WN, KC, S, G, DMA>;
   static bool attr_set = false;
   if (!attr_set) {
     (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
@@ -507,14 +567,17 @@ static int launch_cfg(ConvKArgs& a, hipStream_t stream, ConvKArgs* more = nullpt
   return fsr_check_launch("conv_igemm_kernel");
 }
 
-// Tuning / test switch FSR_CONV_STAGE (bit mask, read per launch; default 30):
-//   1  three-tap stages in the tall 16x128 configuration (off: the guard-free stage body spills there)
-//   2  three-tap stages for stride-2 forward launches          4  ... for the 8x128 configurations
-//   8  ... for the 64-wide configurations                     16  stride-2 data gradient as ONE four-class launch
-//   32 force 16-row tiles (tests: lets small shapes reach the tall configurations)
+// Tuning / test switch FSR_CONV_STAGE (bit mask, read per launch; default 1374 = every variant that measured faster):
+//   1    three-tap register-staged stages in the tall 16x128 configuration (off: that stage body spills)
+//   2    three-tap stages for stride-2 forward launches            4  ... for the 8x128 configurations
+//   8    ... for the 64-wide configurations                       16  stride-2 data gradient as ONE four-class launch
+//   32   force 16-row tiles (tests: lets small shapes reach the tall configurations)
+//   64   tall configuration: filter slices by LDS-DMA, double-buffered three-tap stages
+//   256  8x128 configuration with 64-channel chunks: LDS-DMA filter slices (one tap per stage)
+//   1024 stride-2 forward, 64 output channels: LDS-DMA three-tap stages
 static int stage_mode() {
   const char* e = getenv("FSR_CONV_STAGE");
-  return e ? atoi(e) : 30;
+  return e ? atoi(e) : 1374;
 }
 int fsr_conv_stage_mode() { return stage_mode(); }
 
@@ -545,10 +608,13 @@ static int dispatch_T(ConvKArgs& a, int S, hipStream_t stream, ConvKArgs* more =
     // tall tile (256 px x 128 co per workgroup, wave = 64 px x 128 co): 12 fragment reads per 32 MFMAs instead of 16 and
     // half the workgroups; measured +2..7 % on the 128/256-channel layers.  Narrow chunks keep two workgroups per CU.
     if (!th8 && a.Cin >= 128) {
+      if (t9 && (sm & 64)) FSR_GO(16, 128, 4, 1, KCN, 1, 3, 1);
+      if (t2 && (sm & 64)) FSR_GO(16, 128, 4, 1, KCN, 1, 2, 1);
       if (t9 && (sm & 1)) FSR_GO(16, 128, 4, 1, KCN, 1, 3);
       if (t2 && (sm & 1)) FSR_GO(16, 128, 4, 1, KCN, 1, 2);
       FSR_GO(16, 128, 4, 1, KCN, 1);
     }
+    if (t9 && wide && (sm & 256)) FSR_GO(8, 128, 2, 2, KCW, 1, 1, 1);
     if (t9 && (sm & 4)) FSR_GO(8, 128, 2, 2, KCN, 1, 3);
     if (t2 && wide && (sm & 4)) FSR_GO(8, 128, 2, 2, KCW, 1, 2);
     if (wide) FSR_GO(8, 128, 2, 2, KCW, 1);
@@ -556,6 +622,7 @@ static int dispatch_T(ConvKArgs& a, int S, hipStream_t stream, ConvKArgs* more =
   }
   if (a.CoutPad % 64 == 0) {
     if (S == 2) {
+      if (t9 && (sm & 1024)) FSR_GO(8, 64, 2, 2, KCN, 2, 3, 1);
       if (t9 && (sm & 2)) FSR_GO(8, 64, 2, 2, KCN, 2, 3);
       FSR_GO(8, 64, 2, 2, KCN, 2);
     }

@@ -25,6 +25,9 @@ typedef __bf16 bf16x8_hw __attribute__((ext_vector_type(8)));
 #ifndef FSR_LDS_PTR
 #define FSR_LDS_PTR(T, p) ((__attribute__((address_space(3))) T*)(p))
 #endif
+#ifndef FSR_GLOBAL_PTR
+#define FSR_GLOBAL_PTR(T, p) ((__attribute__((address_space(1))) T*)(p))
+#endif
 
 // dtype / activation / mode enums come from the public ABI header
 #include "fsr_hip.h"

@@ -27,6 +27,7 @@
 #define __launch_bounds__(...)
 #define HIP_KERNEL_NAME(...) __VA_ARGS__
 #define FSR_LDS_PTR(T, p) ((T*)(p))
+#define FSR_GLOBAL_PTR(T, p) ((T*)(p))
 
 struct dim3 {
   unsigned x, y, z;
@@ -230,6 +231,16 @@ inline s16x4_e ds_read_tr16(const void* p) {
   return r;
 }
 
+// global_load_lds_dwordx4 & co.: every lane copies `size` bytes from ITS global address to
+// (LDS base of lane 0, the value the hardware takes from M0) + offset + lane * size.
+inline void global_load_lds(const void* gsrc, void* lds_base, unsigned size, int offset) {
+  ctx.w->u64[ctx.lane] = (uint64_t)(uintptr_t)lds_base;
+  wave_sync();
+  char* base = (char*)(uintptr_t)ctx.w->u64[0];
+  wave_sync();
+  memcpy(base + offset + (size_t)ctx.lane * size, gsrc, size);
+}
+
 inline float atomic_add_f32(float* addr, float v) {
   uint32_t* p = (uint32_t*)addr;
   uint32_t old = __atomic_load_n(p, __ATOMIC_RELAXED);
@@ -276,3 +287,4 @@ inline float __logf(float x) { return logf(x); }
 #define __builtin_amdgcn_ds_read_tr16_b64_v4i16(p) emu::ds_read_tr16((const void*)(p))
 #define __builtin_amdgcn_readfirstlane(x) (x)
 #define __builtin_amdgcn_sched_barrier(mask) ((void)0)
+#define __builtin_amdgcn_global_load_lds(g, l, size, off, aux) emu::global_load_lds((const void*)(g), (void*)(l), (size), (off))
