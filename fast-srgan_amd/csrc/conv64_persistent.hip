@@ -209,7 +209,182 @@ __global__ __launch_bounds__(NTHR64, 2) void conv64_persistent_kernel(const Conv
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Data gradient of the 64 -> 64 STRIDE-2 convolution (Discriminator block 0, /root/reference/model.py:148-152), all four
+// output-parity classes in one pass.  As four class launches of the generic kernel the layer is latency-bound (K is only
+// 64..256 per class, a workgroup lives for a prologue and an epilogue) at ~2 TB/s.  Here a persistent workgroup keeps
+// the whole transposed filter in LDS, walks 16x16 tiles of dz with the next halo prefetched, and computes for every
+// tile the 32x32 block of dx: tap (ky, kx) feeds class (py, px) = (1 - (ky & 1), 1 - (kx & 1)) from dz[i + (ky == 0),
+// j + (kx == 0)], 144 MFMAs per wave and tile into 32 accumulator tiles (4 classes x 2 rows x 4 channel tiles).  dz is
+// read once, dx (and the fused activation mask) as whole rows.
+__global__ __launch_bounds__(NTHR64, 2) void conv64_s2dgrad_kernel(const ConvKArgs a) {
+  typedef bf16_t T;
+  constexpr int HUNITS = HT * HT * 8;
+  constexpr int HPT = (HUNITS + NTHR64 - 1) / NTHR64;
+  HIP_DYNAMIC_SHARED(char, smem)
+  T* wl = (T*)smem;
+  T* halo = (T*)(smem + W_BYTES);
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int l15 = lane & 15, lg = lane >> 4;
+  const T* in = (const T*)a.in;
+  const int tiles_per_img = a.tiles_x * a.tiles_y;
+  const int ntiles = tiles_per_img * a.N;
+  {
+    const T* wpk = (const T*)a.wpk;
+#pragma unroll
+    for (int i = 0; i < 9; ++i) {
+      const int u = tid + i * NTHR64;
+      const u32x4 v = *(const u32x4*)(wpk + (size_t)u * 8);
+      *(u32x4*)(wl + (u >> 3) * P64 + (u & 7) * 8) = v;
+    }
+  }
+  u32x4 hreg[HPT];
+  auto halo_issue = [&](int tile) {
+    const int img = tile / tiles_per_img;
+    const int rem = tile - img * tiles_per_img;
+    const int ty = rem / a.tiles_x, tx = rem - ty * a.tiles_x;
+    const int iy0 = ty * 16, ix0 = tx * 16;
+#pragma unroll
+    for (int i = 0; i < HPT; ++i) {
+      const int u = tid + i * NTHR64;
+      u32x4 v = (u32x4){0u, 0u, 0u, 0u};
+      if (u < HUNITS) {
+        const int unit = u & 7, p = u >> 3;
+        const int hy = p / HT, hx = p - hy * HT;
+        const int iy = iy0 + hy, ix = ix0 + hx;
+        if (iy < a.IH && ix < a.IW) v = *(const u32x4*)(in + ((unsigned)((img * a.IH + iy) * a.IW + ix) * 64u + (unsigned)(unit * 8)));
+      }
+      hreg[i] = v;
+    }
+  };
+  auto halo_commit = [&]() {
+#pragma unroll
+    for (int i = 0; i < HPT; ++i) {
+      const int u = tid + i * NTHR64;
+      if (u < HUNITS) *(u32x4*)(halo + (u >> 3) * P64 + (u & 7) * 8) = hreg[i];
+    }
+  };
+  T* outp = (T*)a.out;
+  const T* maskp = (const T*)a.dmask;
+  int pixbase[2], wbase[4];
+#pragma unroll
+  for (int m = 0; m < 2; ++m) pixbase[m] = ((wave * 2 + m) * HT + l15) * P64 + lg * 8;
+#pragma unroll
+  for (int n = 0; n < 4; ++n) wbase[n] = (n * 16 + l15) * P64 + lg * 8;
+
+  const int tile_begin = (int)blockIdx.x * a.nblk_n;
+  const int tile_end = (tile_begin + a.nblk_n < ntiles) ? tile_begin + a.nblk_n : ntiles;
+  int tile = tile_begin;
+  if (tile < tile_end) halo_issue(tile);
+  __syncthreads();
+  if (tile < tile_end) halo_commit();
+  __syncthreads();
+
+  for (; tile < tile_end; ++tile) {
+    const int next = tile + 1;
+    if (next < tile_end) halo_issue(next);
+
+    f32x4 acc[4][2][4];   // [class 2*py + px][row][channel tile]
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+      for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int n = 0; n < 4; ++n) acc[q][m][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    static_for<0, 9>([&](auto tcn) {
+      constexpr int t = decltype(tcn)::value;
+      constexpr int ky = t / 3, kx = t % 3;
+      constexpr int q = 2 * (1 - (ky & 1)) + (1 - (kx & 1));
+      constexpr int toff = ((ky == 0 ? 1 : 0) * HT + (kx == 0 ? 1 : 0)) * P64;
+      const T* wsl = wl + t * 64 * P64;
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        s16x8 wf[4], xf[2];
+#pragma unroll
+        for (int n = 0; n < 4; ++n) wf[n] = *(const s16x8*)(wsl + wbase[n] + ks * 32);
+#pragma unroll
+        for (int m = 0; m < 2; ++m) xf[m] = *(const s16x8*)(halo + pixbase[m] + toff + ks * 32);
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
+#pragma unroll
+          for (int n = 0; n < 4; ++n) acc[q][m][n] = mfma_bf16_16x16x32(wf[n], xf[m], acc[q][m][n]);
+      }
+      __builtin_amdgcn_sched_barrier(0);   // 128 accumulators + the prefetched halo: keep fragment live ranges to one tap
+    });
+
+    const int img = tile / tiles_per_img;
+    const int rem = tile - img * tiles_per_img;
+    const int ty = rem / a.tiles_x, tx = rem - ty * a.tiles_x;
+    const int gx = tx * 16 + l15, gyb = ty * 16 + wave * 2;
+    const unsigned rstride = (unsigned)(a.FOW * 64);
+    static_for<0, 4>([&](auto qc) {
+      constexpr int q = decltype(qc)::value;
+      constexpr int py = q >> 1, px = q & 1;
+      const int ox = 2 * gx + px;
+      static_for<0, 2>([&](auto mc) {
+        constexpr int m = decltype(mc)::value;
+        const int oy = 2 * (gyb + m) + py;
+        if (ox < a.FOW && oy < a.FOH) {
+          const unsigned base = (unsigned)((img * a.FOH + oy) * a.FOW + ox) * 64u + (unsigned)(lg * 4);
+          static_for<0, 4>([&](auto nc) {
+            constexpr int n = decltype(nc)::value;
+            const unsigned off = base + n * 16;
+            f32x4 v = acc[q][m][n];
+            if (maskp) {
+              const u32x2 tm = *(const u32x2*)(maskp + off);
+              const float mk[4] = {__uint_as_float(tm.x << 16), __uint_as_float(tm.x & 0xffff0000u),
+                                   __uint_as_float(tm.y << 16), __uint_as_float(tm.y & 0xffff0000u)};
+#pragma unroll
+              for (int r = 0; r < 4; ++r) v[r] = mk[r] > 0.f ? v[r] : v[r] * a.dmask_slope;
+            }
+            u32x2 pk;
+            pk.x = pack_bf16x2(v[0], v[1]);
+            pk.y = pack_bf16x2(v[2], v[3]);
+            *(u32x2*)(outp + off) = pk;
+          });
+        }
+      });
+    });
+    (void)rstride;
+    __syncthreads();
+    if (next < tile_end) halo_commit();
+    __syncthreads();
+  }
+}
+
 }  // namespace
+
+// Stride-2 data gradient, 64 -> 64 channels: 1 = launched, 0 = not this kernel's shape, < 0 = error.
+// `a`: in = dz [N, IH, IW, 64], out = dx [N, FOH, FOW, 64], wpk = the [9][64][64] data-gradient pack.
+int fsr_conv64_s2dgrad_try(int dtype, ConvKArgs& a, hipStream_t stream) {
+  if (dtype != FSR_BF16 || a.Cin != 64 || a.Cout != 64 || a.CoutPad != 64) return 0;
+  if (a.ps || a.in_ps || a.out_f32 || a.preact || a.oscale || a.bias || a.stats || a.act != FSR_ACT_NONE) return 0;
+  if (a.IH != (a.FOH - 1) / 2 + 1 || a.IW != (a.FOW - 1) / 2 + 1) return 0;
+  if ((long long)a.N * a.FOH * a.FOW * 64 >= (1LL << 31)) return 0;
+  a.tiles_x = (a.IW + 15) / 16;
+  a.tiles_y = (a.IH + 15) / 16;
+  const long long ntiles = (long long)a.tiles_x * a.tiles_y * a.N;
+  if (ntiles <= 0 || ntiles > 0x7fffffffLL) return 0;
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute((const void*)conv64_s2dgrad_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS64);
+    attr_set = true;
+  }
+  static int cus = 0;
+  if (cus == 0) {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    cus = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
+              ? prop.multiProcessorCount : 256;
+  }
+  const int per = (int)((ntiles + cus - 1) / cus);
+  a.nblk_n = per;
+  const int grid = (int)((ntiles + per - 1) / per);
+  hipLaunchKernelGGL(conv64_s2dgrad_kernel, dim3(grid), dim3(NTHR64), LDS64, stream, a);
+  int rc = fsr_check_launch("conv64_s2dgrad_kernel");
+  return rc ? rc : 1;
+}
 
 // Returns 1 if the launch was taken, 0 if the shape is not this kernel's, < 0 on error.
 int fsr_conv64_persistent_try(int dtype, ConvKArgs& a, int S, hipStream_t stream) {

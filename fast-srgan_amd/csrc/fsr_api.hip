@@ -117,6 +117,10 @@ extern "C" int fsr_conv3x3(const fsr_conv_desc* d, const void* in, const void* p
   }
   // stride 2: split dx into its four parity classes.  For dx row y = 2i+py the contributing
   // filter rows are ky = 1 (py = 0; dy row i) or ky in {0, 2} (py = 1; dy rows i+1, i).
+  if (!(fsr_conv_stage_mode() & 32768)) {   // 64 -> 64: persistent kernel, all four classes per tile (conv64_persistent.hip)
+    ConvKArgs p = a;
+    if (const int rc = fsr_conv64_s2dgrad_try(d->dtype, p, stream)) return rc < 0 ? rc : 0;
+  }
   // The four classes go out as ONE launch, the 4-tap class first (longest workgroups first).
   ConvKArgs cls[4];
   int ncls = 0;

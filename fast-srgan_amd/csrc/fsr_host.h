@@ -17,3 +17,4 @@ int fsr_conv_igemm_dispatch_classes(int dtype, ConvKArgs* cls, int n, hipStream_
 int fsr_conv_stage_mode();   // FSR_CONV_STAGE tuning / test switch, see conv_igemm.hip
 // 1 = launched, 0 = shape not handled by the LDS-resident-filter kernel, < 0 = error
 int fsr_conv64_persistent_try(int dtype, ConvKArgs& a, int S, hipStream_t stream);
+int fsr_conv64_s2dgrad_try(int dtype, ConvKArgs& a, hipStream_t stream);   // stride-2 data gradient, 64 -> 64, all parity classes

@@ -74,9 +74,9 @@ def test_conv_fwd_dgrad_wgrad(dev, cdn, stride, cin, cout, ps):
     assert relerr(dw, wr.grad) < tol(cdn, 2e-5, 2e-3)
 
 
-@pytest.mark.parametrize("mode", [0, 31, 63, 1374, 1406])
+@pytest.mark.parametrize("mode", [0, 31, 63, 1374, 1406, 34142])
 @pytest.mark.parametrize("cdn", ["f32", "bf16"])
-@pytest.mark.parametrize("stride,cin,cout", [(1, 128, 128), (2, 64, 128), (2, 128, 64), (1, 64, 64)])
+@pytest.mark.parametrize("stride,cin,cout", [(1, 128, 128), (2, 64, 128), (2, 128, 64), (1, 64, 64), (2, 64, 64)])
 def test_conv_stage_modes(dev, cdn, stride, cin, cout, mode, monkeypatch):
     """Every main-loop variant of the implicit-GEMM kernel (FSR_CONV_STAGE: single-tap steps, multi-tap stages,
     four-class stride-2 data gradient, forced 16-row tiles) gives the same forward and data gradient."""
@@ -338,20 +338,23 @@ def test_losses_and_adamw(dev):
 
 
 @pytest.mark.parametrize("cdn", ["f32", "bf16"])
-@pytest.mark.parametrize("cin,cout", [(64, 64), (64, 128)])
-def test_dgrad_with_fused_activation_mask(dev, cdn, cin, cout):
-    """Data gradient fused with the producer's ReLU / LeakyReLU backward (mask = saved forward input)."""
+@pytest.mark.parametrize("cin,cout,stride", [(64, 64, 1), (64, 128, 1), (64, 64, 2), (128, 64, 2)])
+def test_dgrad_with_fused_activation_mask(dev, cdn, cin, cout, stride):
+    """Data gradient fused with the producer's ReLU / LeakyReLU backward (mask = saved forward input); stride 2 with
+    64 -> 64 channels is the persistent all-classes kernel, odd sizes leave partial parity classes."""
     cd = ops.Compute(cdn)
     torch.manual_seed(9)
-    n, h, w = (2, 33, 40) if _big(dev) else (1, 6, 18)
+    n, h, w = (2, 33, 40) if _big(dev) else (1, 7, 18)
     x = _q(torch.randn(n, cin, h, w), cd)                 # forward input = output of the producing activation
     wt = _q(torch.randn(cout, cin, 3, 3) * 0.1, cd)
-    g = _q(torch.randn(n, cout, h, w), cd)
     xr = x.clone().requires_grad_(True)
-    F.conv2d(xr, wt, None, 1, 1).backward(g)
+    y = F.conv2d(xr, wt, None, stride, 1)
+    g = _q(torch.randn_like(y), cd)
+    y.backward(g)
     for slope in (0.0, 0.2):
         want = xr.grad * torch.where(x > 0, torch.ones(()), torch.tensor(slope))
         wpk = ops.packed_filter(cd, wt.to(dev), L.PACK_DGRAD, cout)
         xd = _nhwc(x, cd, dev)
-        dx, _, _ = ops.conv3x3_raw(cd, _nhwc(g, cd, dev), wpk, cin, mode=L.CONV_DGRAD, out_hw=(h, w), dact_mask=xd, dact_slope=slope)
+        dx, _, _ = ops.conv3x3_raw(cd, _nhwc(g, cd, dev), wpk, cin, mode=L.CONV_DGRAD, out_hw=(h, w), stride=stride, dact_mask=xd,
+                                   dact_slope=slope)
         assert relerr(_nchw(dx), want) < tol(cdn, 1e-5, 1e-2)
