@@ -34,8 +34,8 @@ sys.path.insert(0, ROOT)
 MFMA_PEAK_TFLOPS = {"bf16": 2500.0, "f32": 157.3}   # /opt/skills/guides/MI355X_MICROARCH.md, dense
 STEP_GFLOP_PER_IMAGE = 686.71                         # BASELINE.md section 2, as the reference graph executes it
 # HBM bytes per conv launch (forward + data-gradient calls of one iteration, batch 32, bf16) from the PMC counters:
-# 168 kernel launches per iteration x (2 x 80520 KB FETCH_SIZE + 143630 KB WRITE_SIZE) / 132 API-level launches
-CONV_HBM_BYTES_PER_LAUNCH = 3.97e8
+# 117 launches per iteration x (2 x 114777 KB FETCH_SIZE + 198516 KB WRITE_SIZE) (tools/gpu_pmc_step.sh, tools/pmc_traffic.py)
+CONV_HBM_BYTES_PER_LAUNCH = 4.38e8
 
 
 def ns(**k):

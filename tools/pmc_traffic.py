@@ -1,0 +1,27 @@
+"""HBM traffic of the 3x3 conv forward / data-gradient kernels per iteration from two rocprofv3 --pmc passes
+(FETCH_SIZE, WRITE_SIZE; counter_collection.csv) over `bench.py --steps 1 --warmup 1 --no-graph` (= 4 iterations).
+FETCH_SIZE on gfx950 counts half the bytes (MI355X_MICROARCH.md): x2.  Units: KB."""
+import csv
+import sys
+
+KERNELS = ("conv_igemm_kernel", "conv64_persistent_kernel", "conv64_s2dgrad_kernel", "conv_c3_fwd_kernel")
+
+
+def total_kb(path, counter):
+    tot, n = 0.0, 0
+    for r in csv.DictReader(open(path)):
+        if r["Counter_Name"] == counter and any(k in r["Kernel_Name"] for k in KERNELS):
+            tot += float(r["Counter_Value"])
+            n += 1
+    return tot, n
+
+
+fetch, n1 = total_kb(sys.argv[1], "FETCH_SIZE")
+write, n2 = total_kb(sys.argv[2], "WRITE_SIZE")
+iters = int(sys.argv[3]) if len(sys.argv) > 3 else 4
+api = int(sys.argv[4]) if len(sys.argv) > 4 else 0
+byt = (2 * fetch + write) * 1024 / iters
+print("conv kernel dispatches per iteration: %.1f / %.1f" % (n1 / iters, n2 / iters))
+print("FETCH_SIZE %.0f KB (x2) + WRITE_SIZE %.0f KB per iteration -> %.3e bytes per iteration" % (fetch / iters, write / iters, byt))
+if api:
+    print("per API-level conv launch (%d per iteration): %.3e bytes" % (api, byt / api))
