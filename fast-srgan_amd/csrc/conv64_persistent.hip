@@ -147,6 +147,7 @@ __global__ __launch_bounds__(NTHR64, 2) void conv64_persistent_kernel(const Conv
     }
 
     // ---- epilogue of this tile
+    FSR_WAIT_LOADS();   // the prefetched halo has landed; the stores below then drain under the next tile
     const int img = tile / tiles_per_img;
     const int rem = tile - img * tiles_per_img;
     const int ty = rem / a.tiles_x, tx = rem - ty * a.tiles_x;
@@ -155,6 +156,15 @@ __global__ __launch_bounds__(NTHR64, 2) void conv64_persistent_kernel(const Conv
     const unsigned rstride = (unsigned)(a.FOW * 64);
     const unsigned base0 = (unsigned)((img * a.FOH + gyb) * a.FOW + gx) * 64u + (unsigned)(lg * 4);
     const bool flush = want_stats && (next >= tile_end || next / tiles_per_img != img);
+    // mask vectors of the whole tile before its first store (see conv64_s2dgrad_kernel)
+    u32x2 mkv[2][4];
+    if (maskp) {
+#pragma unroll
+      for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int n = 0; n < 4; ++n)
+          mkv[m][n] = (col_ok && gyb + m < a.GH) ? *(const u32x2*)(maskp + (base0 + m * rstride + n * 16)) : (u32x2){0u, 0u};
+    }
     static_for<0, 4>([&](auto nc) {
       constexpr int n = decltype(nc)::value;
       static_for<0, 2>([&](auto mc) {
@@ -163,7 +173,7 @@ __global__ __launch_bounds__(NTHR64, 2) void conv64_persistent_kernel(const Conv
           const unsigned off = base0 + m * rstride + n * 16;
           f32x4 v = acc[m][n] + bias[n];
           if (maskp) {
-            const u32x2 t = *(const u32x2*)(maskp + off);
+            const u32x2 t = mkv[m][n];
             const float mk[4] = {__uint_as_float(t.x << 16), __uint_as_float(t.x & 0xffff0000u),
                                  __uint_as_float(t.y << 16), __uint_as_float(t.y & 0xffff0000u)};
 #pragma unroll
@@ -313,6 +323,7 @@ __global__ __launch_bounds__(NTHR64, 2) void conv64_s2dgrad_kernel(const ConvKAr
       __builtin_amdgcn_sched_barrier(0);   // 128 accumulators + the prefetched halo: keep fragment live ranges to one tap
     });
 
+    FSR_WAIT_LOADS();   // (see conv64_persistent_kernel)
     const int img = tile / tiles_per_img;
     const int rem = tile - img * tiles_per_img;
     const int ty = rem / a.tiles_x, tx = rem - ty * a.tiles_x;
@@ -322,17 +333,30 @@ __global__ __launch_bounds__(NTHR64, 2) void conv64_s2dgrad_kernel(const ConvKAr
       constexpr int q = decltype(qc)::value;
       constexpr int py = q >> 1, px = q & 1;
       const int ox = 2 * gx + px;
+      // the class's eight mask vectors first, then its stores: a mask load issued after a store would wait for that
+      // store to reach memory (one counter for loads and stores, possible aliasing) -- once per class instead of per row
+      u32x2 mkv[2][4];
+      unsigned base[2];
+      bool ok[2];
+#pragma unroll
+      for (int m = 0; m < 2; ++m) {
+        const int oy = 2 * (gyb + m) + py;
+        ok[m] = ox < a.FOW && oy < a.FOH;
+        base[m] = (unsigned)((img * a.FOH + oy) * a.FOW + ox) * 64u + (unsigned)(lg * 4);
+        if (maskp) {
+#pragma unroll
+          for (int n = 0; n < 4; ++n) mkv[m][n] = ok[m] ? *(const u32x2*)(maskp + base[m] + n * 16) : (u32x2){0u, 0u};
+        }
+      }
       static_for<0, 2>([&](auto mc) {
         constexpr int m = decltype(mc)::value;
-        const int oy = 2 * (gyb + m) + py;
-        if (ox < a.FOW && oy < a.FOH) {
-          const unsigned base = (unsigned)((img * a.FOH + oy) * a.FOW + ox) * 64u + (unsigned)(lg * 4);
+        if (ok[m]) {
           static_for<0, 4>([&](auto nc) {
             constexpr int n = decltype(nc)::value;
-            const unsigned off = base + n * 16;
+            const unsigned off = base[m] + n * 16;
             f32x4 v = acc[q][m][n];
             if (maskp) {
-              const u32x2 tm = *(const u32x2*)(maskp + off);
+              const u32x2 tm = mkv[m][n];
               const float mk[4] = {__uint_as_float(tm.x << 16), __uint_as_float(tm.x & 0xffff0000u),
                                    __uint_as_float(tm.y << 16), __uint_as_float(tm.y & 0xffff0000u)};
 #pragma unroll

@@ -434,6 +434,26 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv_igemm_kernel(const ConvK
   T* prep = (T*)a.preact;
   const T* maskp = (const T*)a.dmask;
   const bool want_stats = a.stats != nullptr;
+  // Masks (fused activation backward) are loaded for ALL tiles of the wave before the first store: a load issued after
+  // a store may alias it as far as the compiler knows, and gfx9 counts loads and stores on one counter, so every
+  // (tile row) mask load would otherwise wait for the previous row's store to reach memory -- MT x NT serialised
+  // round trips per workgroup.
+  constexpr bool PREMASK = sizeof(T) == 2;
+  u32x2 mkreg[PREMASK ? NT : 1][PREMASK ? MT : 1];
+  const bool premask = PREMASK && maskp && !a.ps && a.premask;
+  if (premask) {
+    const unsigned base0 = (unsigned)((img * a.FOH + gyb * a.osy + a.ooy) * a.FOW + gx * a.osx + a.oox) * (unsigned)a.Cout + (unsigned)cob;
+    const unsigned rs = (unsigned)(a.osy * a.FOW * a.Cout);
+    static_for<0, NT>([&](auto nc) {
+      constexpr int n = decltype(nc)::value;
+      static_for<0, MT>([&](auto mc) {
+        constexpr int m = decltype(mc)::value;
+        u32x2 t = (u32x2){0u, 0u};
+        if (col_ok && gyb + m < a.GH) t = *(const u32x2*)(maskp + (base0 + n * 16 + m * rs));
+        if constexpr (PREMASK) mkreg[n][m] = t;
+      });
+    });
+  }
   static_for<0, NT>([&](auto nc) {
     constexpr int n = decltype(nc)::value;
     const int co = cob + n * 16;
@@ -465,7 +485,9 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv_igemm_kernel(const ConvK
             const f32x4 t = *(const f32x4*)(maskp + (base + m * rstride));
             mk[0] = t[0]; mk[1] = t[1]; mk[2] = t[2]; mk[3] = t[3];
           } else {
-            const u32x2 t = *(const u32x2*)(maskp + (base + m * rstride));
+            u32x2 t;
+            if (premask) t = mkreg[PREMASK ? n : 0][PREMASK ? m : 0];
+            else t = *(const u32x2*)(maskp + (base + m * rstride));
             mk[0] = __uint_as_float(t.x << 16); mk[1] = __uint_as_float(t.x & 0xffff0000u);
             mk[2] = __uint_as_float(t.y << 16); mk[3] = __uint_as_float(t.y & 0xffff0000u);
           }
@@ -512,6 +534,8 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv_igemm_kernel(const ConvK
 }
 
 // ---------------------------------------------------------------------------- host side
+static int stage_mode();
+
 static int pack_taps(ConvKArgs& a) {
   a.taps_lo = 0;
   a.taps_hi = 0;
@@ -535,6 +559,7 @@ static int launch_cfg(ConvKArgs& a, hipStream_t stream, ConvKArgs* more = nullpt
     return fsr_fail(-2, "conv3x3: pixel-shuffled input needs (Cin/4)=%d to be a multiple of the chunk %d", a.Cin / 4, KC);
   if (a.CoutPad % BN != 0) return fsr_fail(-2, "conv3x3: padded Cout=%d is not a multiple of %d", a.CoutPad, BN);
   a.nblk_n = a.CoutPad / BN;
+  a.premask = (stage_mode() & 65536) ? 0 : 1;
   a.HH = (TH - 1) * S + 3;
   a.HW = 15 * S + 3;
   if ((long long)a.N * a.IH * a.IW * a.Cin >= (1LL << 31) || (long long)a.N * a.FOH * a.FOW * a.Cout >= (1LL << 31))
@@ -575,6 +600,7 @@ static int launch_cfg(ConvKArgs& a, hipStream_t stream, ConvKArgs* more = nullpt
 //   64   tall configuration: filter slices by LDS-DMA, double-buffered three-tap stages
 //   256  8x128 configuration with 64-channel chunks: LDS-DMA filter slices (one tap per stage)
 //   1024 stride-2 forward, 64 output channels: LDS-DMA three-tap stages
+//   65536 DISABLE the up-front mask loads of the epilogue
 //   32768 (fsr_api.hip) DISABLE the persistent all-classes kernel of the 64 -> 64 stride-2 data gradient
 static int stage_mode() {
   const char* e = getenv("FSR_CONV_STAGE");

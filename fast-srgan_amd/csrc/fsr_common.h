@@ -25,6 +25,14 @@ typedef __bf16 bf16x8_hw __attribute__((ext_vector_type(8)));
 #ifndef FSR_LDS_PTR
 #define FSR_LDS_PTR(T, p) ((__attribute__((address_space(3))) T*)(p))
 #endif
+// gfx9 counts loads AND stores on vmcnt, and the two kinds complete out of order with each other, so the compiler waits
+// vmcnt(0) -- for every store in flight as well -- wherever a loaded register is first used.  A persistent kernel that
+// prefetches the next tile before its epilogue therefore waits for the prefetch HERE, before the epilogue's stores are
+// issued (the loads have had the whole tile to land): the later use of the prefetched registers then needs no wait and
+// the stores drain under the next tile.   0x0F70 = vmcnt(0), expcnt / lgkmcnt untouched.
+#ifndef FSR_WAIT_LOADS
+#define FSR_WAIT_LOADS() __builtin_amdgcn_s_waitcnt(0x0F70)
+#endif
 #ifndef FSR_GLOBAL_PTR
 #define FSR_GLOBAL_PTR(T, p) ((__attribute__((address_space(1))) T*)(p))
 #endif

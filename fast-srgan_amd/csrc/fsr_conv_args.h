@@ -37,6 +37,7 @@ struct ConvKArgs {
   int in_ps;            // `in` is stored depth-to-space(2) (gradient of a pixel-shuffle conv)
   int out_f32;          // store float regardless of T
   int tiles_x, tiles_y, nblk_n;
+  int premask;          // epilogue loads every mask value before its first store
 };
 
 // A launch may cover up to four "classes" that differ only in their output grid, tap table and output offset (the

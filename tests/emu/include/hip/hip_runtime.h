@@ -28,6 +28,7 @@
 #define HIP_KERNEL_NAME(...) __VA_ARGS__
 #define FSR_LDS_PTR(T, p) ((T*)(p))
 #define FSR_GLOBAL_PTR(T, p) ((T*)(p))
+#define FSR_WAIT_LOADS() ((void)0)
 
 struct dim3 {
   unsigned x, y, z;
