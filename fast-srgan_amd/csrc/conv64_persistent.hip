@@ -48,13 +48,17 @@ __global__ __launch_bounds__(NTHR64, 2) void conv64_persistent_kernel(const Conv
   const int tiles_per_img = a.tiles_x * a.tiles_y;
   const int ntiles = tiles_per_img * a.N;
 
-  // ---- the whole packed filter [9][64][64] -> LDS (4608 units, 9 per thread), once
+  // Output channels come in blocks of 64 (Cout = 64, 128, 256): workgroup w owns block nb = w % nblk for its tile range;
+  // with a fused PixelShuffle (Cout / 4 = 64 channels per quadrant) block nb IS quadrant nb of the packed filter.
+  const int nblk = a.CoutPad >> 6;
+  const int nb = (int)blockIdx.x % nblk;
+  // ---- the 64 filter rows of this block, all nine taps: [9][64][64] -> LDS (4608 units, 9 per thread), once
   {
-    const T* wpk = (const T*)a.wpk;
+    const T* wpk = (const T*)a.wpk + (size_t)nb * 64 * 64;
 #pragma unroll
     for (int i = 0; i < 9; ++i) {
       const int u = tid + i * NTHR64;                   // (slice*64 + row)*8 + unit
-      const u32x4 v = *(const u32x4*)(wpk + (size_t)u * 8);
+      const u32x4 v = *(const u32x4*)(wpk + ((size_t)(u >> 9) * a.CoutPad * 64 + (size_t)(u & 511) * 8));
       *(u32x4*)(wl + (u >> 3) * P64 + (u & 7) * 8) = v;
     }
     if (tid < 128) sred[tid] = 0.f;
@@ -93,6 +97,7 @@ __global__ __launch_bounds__(NTHR64, 2) void conv64_persistent_kernel(const Conv
   if (a.act == FSR_ACT_RELU) slope = 0.f;
   const bool want_stats = a.stats != nullptr;
   T* outp = (T*)a.out;
+  T* prep = (T*)a.preact;
   const T* maskp = (const T*)a.dmask;
 
   int pixbase[2], wbase[4];
@@ -102,11 +107,19 @@ __global__ __launch_bounds__(NTHR64, 2) void conv64_persistent_kernel(const Conv
   for (int n = 0; n < 4; ++n) wbase[n] = (n * 16 + l15) * P64 + lg * 8;
   f32x4 bias[4];
 #pragma unroll
-  for (int n = 0; n < 4; ++n) bias[n] = a.bias ? *(const f32x4*)(a.bias + n * 16 + lg * 4) : (f32x4){0.f, 0.f, 0.f, 0.f};
+  for (int n = 0; n < 4; ++n) {
+    bias[n] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    if (a.bias) {
+      if (!a.ps) bias[n] = *(const f32x4*)(a.bias + nb * 64 + n * 16 + lg * 4);
+      else
+#pragma unroll
+        for (int r = 0; r < 4; ++r) bias[n][r] = a.bias[4 * (n * 16 + lg * 4 + r) + nb];   // torch order 4*cc + quadrant
+    }
+  }
 
   // a workgroup walks a CONTIGUOUS range of tiles (mostly one image): InstanceNorm statistics stay in registers
   // across tiles and are flushed (lane shuffle -> LDS -> 128 global atomics) only when the image changes
-  const int tile_begin = (int)blockIdx.x * a.nblk_n;   // nblk_n = tiles per workgroup (set by the host)
+  const int tile_begin = ((int)blockIdx.x / nblk) * a.nblk_n;   // nblk_n = tiles per workgroup (set by the host)
   const int tile_end = (tile_begin + a.nblk_n < ntiles) ? tile_begin + a.nblk_n : ntiles;
   f32x4 s1acc[4], s2acc[4];
 #pragma unroll
@@ -153,8 +166,11 @@ __global__ __launch_bounds__(NTHR64, 2) void conv64_persistent_kernel(const Conv
     const int ty = rem / a.tiles_x, tx = rem - ty * a.tiles_x;
     const int gx = tx * 16 + l15, gyb = ty * 16 + wave * 2;
     const bool col_ok = gx < a.GW;
-    const unsigned rstride = (unsigned)(a.FOW * 64);
-    const unsigned base0 = (unsigned)((img * a.FOH + gyb) * a.FOW + gx) * 64u + (unsigned)(lg * 4);
+    // plain: pixel (gy, gx), channels nb*64 + ...; PixelShuffle(2): pixel (2 gy + (nb >> 1), 2 gx + (nb & 1)) of the
+    // [2 FOH, 2 FOW, 64] tensor, channels 0..63
+    const unsigned rstride = a.ps ? (unsigned)(4 * a.FOW * 64) : (unsigned)(a.FOW * a.Cout);
+    const unsigned base0 = a.ps ? (unsigned)((img * 2 * a.FOH + 2 * gyb + (nb >> 1)) * (2 * a.FOW) + 2 * gx + (nb & 1)) * 64u + (unsigned)(lg * 4)
+                                : (unsigned)((img * a.FOH + gyb) * a.FOW + gx) * (unsigned)a.Cout + (unsigned)(nb * 64 + lg * 4);
     const bool flush = want_stats && (next >= tile_end || next / tiles_per_img != img);
     // mask vectors of the whole tile before its first store (see conv64_s2dgrad_kernel)
     u32x2 mkv[2][4];
@@ -182,6 +198,12 @@ __global__ __launch_bounds__(NTHR64, 2) void conv64_persistent_kernel(const Conv
           if (want_stats) {
             s1acc[n] += v;
             s2acc[n] += v * v;
+          }
+          if (prep) {
+            u32x2 pp;
+            pp.x = pack_bf16x2(v[0], v[1]);
+            pp.y = pack_bf16x2(v[2], v[3]);
+            *(u32x2*)(prep + off) = pp;
           }
 #pragma unroll
           for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f) + slope * fminf(v[r], 0.f);
@@ -211,7 +233,7 @@ __global__ __launch_bounds__(NTHR64, 2) void conv64_persistent_kernel(const Conv
     });
     __syncthreads();   // every wave is done with the halo (and with its statistics contributions)
     if (flush && tid < 128) {
-      atomicAdd(a.stats + ((size_t)img * 64 + (tid >> 1)) * 2 + (tid & 1), sred[tid]);
+      atomicAdd(a.stats + ((size_t)img * a.Cout + nb * 64 + (tid >> 1)) * 2 + (tid & 1), sred[tid]);
       sred[tid] = 0.f;
     }
     if (next < tile_end) halo_commit();
@@ -412,10 +434,13 @@ int fsr_conv64_s2dgrad_try(int dtype, ConvKArgs& a, hipStream_t stream) {
 
 // Returns 1 if the launch was taken, 0 if the shape is not this kernel's, < 0 on error.
 int fsr_conv64_persistent_try(int dtype, ConvKArgs& a, int S, hipStream_t stream) {
-  if (dtype != FSR_BF16 || S != 1 || a.Cin != 64 || a.Cout != 64 || a.CoutPad != 64 || a.ntaps != 9) return 0;
-  if (a.ps || a.in_ps || a.out_f32 || a.preact || a.oscale) return 0;
+  if (dtype != FSR_BF16 || S != 1 || a.Cin != 64 || a.Cout % 64 != 0 || a.CoutPad != a.Cout || a.Cout > 256 || a.ntaps != 9) return 0;
+  if (a.in_ps || a.out_f32 || a.oscale) return 0;
+  if (a.ps && (a.Cout != 256 || a.stats || a.dmask)) return 0;   // PixelShuffle(2): one quadrant = one 64-row block
+  if (a.preact && a.dmask) return 0;
+  if (a.stats && a.dmask) return 0;   // InstanceNorm backward sums: generic kernel
   if (a.osy != 1 || a.osx != 1 || a.ooy != 0 || a.oox != 0) return 0;
-  if ((long long)a.N * a.IH * a.IW * 64 >= (1LL << 31)) return 0;
+  if ((long long)a.N * a.IH * a.IW * 64 >= (1LL << 31) || (long long)a.N * a.FOH * a.FOW * a.Cout >= (1LL << 31)) return 0;
   a.tiles_x = (a.GW + 15) / 16;
   a.tiles_y = (a.GH + 15) / 16;
   a.taps_lo = 0;
@@ -440,9 +465,12 @@ int fsr_conv64_persistent_try(int dtype, ConvKArgs& a, int S, hipStream_t stream
     cus = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
               ? prop.multiProcessorCount : 256;
   }
-  const int per = (int)((ntiles + cus - 1) / cus);          // contiguous tiles per workgroup
+  const int nblk = a.Cout / 64;                              // channel blocks: workgroup w -> block w % nblk
+  int slots = cus / nblk;                                    // tile ranges
+  if (slots < 1) slots = 1;
+  const int per = (int)((ntiles + slots - 1) / slots);      // contiguous tiles per workgroup
   a.nblk_n = per;
-  const int grid = (int)((ntiles + per - 1) / per);
+  const int grid = (int)((ntiles + per - 1) / per) * nblk;
   hipLaunchKernelGGL(conv64_persistent_kernel, dim3(grid), dim3(NTHR64), LDS64, stream, a);
   int rc = fsr_check_launch("conv64_persistent_kernel");
   return rc ? rc : 1;
