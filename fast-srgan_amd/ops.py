@@ -7,6 +7,7 @@ enqueued on torch's current stream; nothing here synchronises, allocates pinned 
 back to a torch implementation of the math.
 """
 import ctypes
+import os
 import weakref
 
 import torch
@@ -168,6 +169,60 @@ def _workspace(nbytes, device):
         buf = torch.empty((nbytes + 3) // 4, dtype=torch.float32, device=device)
         _ws[key] = buf
     return buf
+
+
+# ---------------------------------------------------------------------------------- weight gradients on their own stream
+# A weight gradient depends only on (x, dz) and nothing downstream depends on it before the optimizer step, so it can run
+# beside the data-gradient chain instead of inside it.  `wgrad_stream_begin(device)` (the trainer, per iteration) turns
+# this on; Conv3x3Fn.backward then launches its weight gradient on the side stream after an event of the producing
+# stream, and `wgrad_stream_join()` makes the current stream wait for all of them (before gradients are reduced / used).
+# The tensors a queued launch reads are kept referenced until the join, so the caching allocator cannot hand their
+# memory to later work on the producing stream.
+_wgrad_state = {"stream": None, "active": False, "refs": []}
+USE_WGRAD_STREAM = os.environ.get("FSR_WGRAD_STREAM", "1") != "0"
+
+
+def wgrad_stream_begin(device):
+    if not USE_WGRAD_STREAM or L.is_emulation() or not torch.cuda.is_available():
+        return
+    if _wgrad_state["stream"] is None:
+        _wgrad_state["stream"] = torch.cuda.Stream(device=device)
+    _wgrad_state["active"] = True
+
+
+def wgrad_stream_join():
+    st = _wgrad_state
+    if st["active"] and st["refs"]:
+        torch.cuda.current_stream().wait_stream(st["stream"])
+    st["refs"] = []
+
+
+def wgrad_stream_end():
+    wgrad_stream_join()
+    _wgrad_state["active"] = False
+
+
+class _on_wgrad_stream:
+    """with _on_wgrad_stream(tensors): the body's launches go to the weight-gradient stream (if active), ordered after
+    everything queued so far on the current stream."""
+
+    def __init__(self, *tensors):
+        self.tensors = tensors
+        self.ctx = None
+
+    def __enter__(self):
+        st = _wgrad_state
+        if st["active"] and self.tensors[0].is_cuda:
+            st["stream"].wait_stream(torch.cuda.current_stream())
+            st["refs"].append(self.tensors)
+            self.ctx = torch.cuda.stream(st["stream"])
+            self.ctx.__enter__()
+        return self
+
+    def __exit__(self, *exc):
+        if self.ctx is not None:
+            self.ctx.__exit__(*exc)
+        return False
 
 
 # ---------------------------------------------------------------------------------- raw launches
@@ -397,15 +452,23 @@ class Conv3x3Fn(torch.autograd.Function):
         dw = None
         if ctx.needs_input_grad[1]:
             arena = getattr(weight, "_fsr_grad", None)  # optim.ArenaAdamW: accumulate in place, hand autograd nothing
-            if ctx.c3:      # xin is the float image itself
-                dw = arena if arena is not None else torch.zeros((cout, 3, 3, 3), dtype=torch.float32, device=xin.device)
-                need = lib.fsr_conv3x3_c3_wgrad_workspace(n, ih, iw, cout)
-                sn, sc, sh, sw = xin.stride()
-                L.check(lib.fsr_conv3x3_c3_wgrad(cd.code, _p(xin), sn, sc, sh, sw, n, ih, iw, *cfg.in_scale, *cfg.in_shift,
-                                                 _p(dz), cout, _p(dw), _p(_workspace(need, xin.device)), st),
-                        "fsr_conv3x3_c3_wgrad")
+
+            def launch_wgrad():
+                if ctx.c3:      # xin is the float image itself
+                    out = arena if arena is not None else torch.zeros((cout, 3, 3, 3), dtype=torch.float32, device=xin.device)
+                    need = lib.fsr_conv3x3_c3_wgrad_workspace(n, ih, iw, cout)
+                    sn, sc, sh, sw = xin.stride()
+                    L.check(lib.fsr_conv3x3_c3_wgrad(cd.code, _p(xin), sn, sc, sh, sw, n, ih, iw, *cfg.in_scale, *cfg.in_shift,
+                                                     _p(dz), cout, _p(out), _p(_workspace(need, xin.device)), _stream()),
+                            "fsr_conv3x3_c3_wgrad")
+                    return out
+                return conv3x3_wgrad_raw(cd, xin, dz, cout, cin, cfg.stride, dy_pixel_shuffled=cfg.pixel_shuffle, out=arena)
+
+            if arena is not None:   # nothing downstream reads the arena before the optimizer: own stream (see above)
+                with _on_wgrad_stream(xin, dz):
+                    launch_wgrad()
             else:
-                dw = conv3x3_wgrad_raw(cd, xin, dz, cout, cin, cfg.stride, dy_pixel_shuffled=cfg.pixel_shuffle, out=arena)
+                dw = launch_wgrad()
             if arena is not None:
                 dw = None
         db = dbias if (ctx.has_bias and ctx.needs_input_grad[2]) else None

@@ -85,9 +85,11 @@ class Trainer:
     def train_step(self, lr_images, hr_images, noise=None):
         """noise: optional (n0, n1, n2) replacing the torch.rand_like draws of trainer.py:175,176,187."""
         ops.zero_pool_reset(lr_images.device)   # one memset for all statistics / reduction scratch of the iteration
+        ops.wgrad_stream_begin(lr_images.device)   # weight gradients run beside the data-gradient chain (ops.py)
         try:
             return self._train_step(lr_images, hr_images, noise)
         finally:
+            ops.wgrad_stream_end()
             ops.zero_pool_end(lr_images.device)
 
     def _train_step(self, lr_images, hr_images, noise):
@@ -126,6 +128,7 @@ class Trainer:
         loss_fake = self.loss_fn(y_fake, fake_labels)                           # :178
         discriminator_loss = 0.5 * loss_real + 0.5 * loss_fake                  # :179
         discriminator_loss.backward()                                           # :180
+        ops.wgrad_stream_join()
         self._sync_d.start()
         # content branch of the generator step (:190, :192) starts as soon as sr_images exists
         content_loss = on_side(lambda: self.l1_loss(V.features_nhwc(sr_images), real_features))
@@ -145,6 +148,7 @@ class Trainer:
         generator_loss.backward()                                               # :195
         for p in Dm.parameters():
             p.requires_grad_(True)
+        ops.wgrad_stream_join()
         self._sync_g.start()
         self._sync_g.wait()
         self.optim_generator.step()                                             # :196
