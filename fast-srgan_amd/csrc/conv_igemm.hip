@@ -12,7 +12,12 @@
 // Work decomposition
 //   workgroup (WM x WN waves: 4; 8 also compiles) -> TH x 16 output pixels of one image x BN output channels
 //   wave                              -> MT pixel rows (16 px each) x NT 16-wide channel tiles
-//   K loop                            -> steps = (input-channel chunk of KC) x (tap); one barrier per step
+//   K loop                            -> (input-channel chunk of KC) x (tap).  Three main-loop forms, by template parameter:
+//        G = 1, DMA = 0 : one tap per step, filter slices register-staged two steps ahead, one barrier per step;
+//        G = 2 / 3      : G taps per stage, slices single-buffered in LDS and prefetched into registers, two barriers per
+//                         stage (stride-2 forward, 64-wide configurations, the classes of a stride-2 data gradient);
+//        DMA = 1        : slices by LDS-DMA (global_load_lds_dwordx4) into a double buffer, XOR-swizzled unpadded rows,
+//                         one barrier per stage (the tall 128..512-channel configuration).
 // LDS images
 //   halo : [(TH-1)*S+3][15*S+3][KC] input pixels of the current chunk, loaded ONCE per chunk and re-read by every
 //          tap (9x reuse out of LDS instead of L2).  The loads of chunk c+1 are issued into registers at the start
@@ -593,7 +598,6 @@ static int launch_cfg(ConvKArgs& a, hipStream_t stream, ConvKArgs* more = nullpt
 }
 
 // Tuning / test switch FSR_CONV_STAGE (bit mask, read per launch; default 1374 = every variant that measured faster):
-//   1    three-tap register-staged stages in the tall 16x128 configuration (off: that stage body spills)
 //   2    three-tap stages for stride-2 forward launches            4  ... for the 8x128 configurations
 //   8    ... for the 64-wide configurations                       16  stride-2 data gradient as ONE four-class launch
 //   32   force 16-row tiles (tests: lets small shapes reach the tall configurations)
@@ -637,8 +641,6 @@ static int dispatch_T(ConvKArgs& a, int S, hipStream_t stream, ConvKArgs* more =
     if (!th8 && a.Cin >= 128) {
       if (t9 && (sm & 64)) FSR_GO(16, 128, 4, 1, KCN, 1, 3, 1);
       if (t2 && (sm & 64)) FSR_GO(16, 128, 4, 1, KCN, 1, 2, 1);
-      if (t9 && (sm & 1)) FSR_GO(16, 128, 4, 1, KCN, 1, 3);
-      if (t2 && (sm & 1)) FSR_GO(16, 128, 4, 1, KCN, 1, 2);
       FSR_GO(16, 128, 4, 1, KCN, 1);
     }
     if (t9 && wide && (sm & 256)) FSR_GO(8, 128, 2, 2, KCW, 1, 1, 1);
