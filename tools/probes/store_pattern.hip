@@ -1,4 +1,5 @@
 // Probe: HBM write bandwidth of the conv epilogue's store patterns (NHWC bf16, 64 or 128 channels per pixel).
+// Build: hipcc --offload-arch=gfx950 -O3 -o tools/probes/store_pattern tools/probes/store_pattern.hip ; run it on the GPU box.
 //   mode 0: lane (l15, lg) stores 8 B at pixel l15, channel n*16 + lg*4     (generic epilogue: 32-B pieces per pixel)
 //   mode 1: lane stores 16 B at pixel l15, byte p*64 + lg*16                  (first-layer kernel: 64-B pieces)
 //   mode 2: lane stores 16 B, 64 lanes contiguous (1 KB per instruction)      (what a transposing epilogue would do)
