@@ -161,13 +161,14 @@ def main():
     value = world * B * args.steps / elapsed
 
     # ---- roofline of the dominant kernel: one instrumented iteration (outside the timed region)
-    # (single-stream: with the perceptual branch on its second stream, kernels of both streams share the GPU and an
-    # event pair around one launch would also time its neighbours)
-    side = trainer.use_side_stream
+    # (single-stream: with the perceptual branch and the weight gradients on their own streams, kernels of several
+    # streams share the GPU and an event pair around one launch would also time its neighbours)
+    side, wstream = trainer.use_side_stream, ops.USE_WGRAD_STREAM
     trainer.use_side_stream = False
+    ops.USE_WGRAD_STREAM = False
     trainer.train_step(lr, hr)
     launches, conv_ms, conv_flops, conv_bytes = conv_profile(ops, lambda: trainer.train_step(lr, hr))
-    trainer.use_side_stream = side
+    trainer.use_side_stream, ops.USE_WGRAD_STREAM = side, wstream
     achieved = conv_flops / (conv_ms * 1e-3) / 1e12 if conv_ms > 0 else 0.0
     peak = MFMA_PEAK_TFLOPS[args.dtype]
     roofline = {"bound": "mfma", "kernel": "conv_igemm_kernel / conv64_persistent_kernel (3x3 conv forward + data-gradient launches)",
