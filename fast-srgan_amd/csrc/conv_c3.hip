@@ -51,16 +51,34 @@ template <typename T> __device__ __forceinline__ float round_T(float v);
 template <> __device__ __forceinline__ float round_T<float>(float v) { return v; }
 template <> __device__ __forceinline__ float round_T<bf16_t>(float v) { return bf2f(f2bf(v)); }
 
-// stage rows [y0-1, y0+TH] x cols [x0-1, x0+16] of image n, normalised and rounded to T, as floats
+// stage rows [y0-1, y0+TH] x cols [x0-1, x0+16] of image n, normalised and rounded to T, as floats.
+// All loads of a thread are issued before the first use: the address of an out-of-image element is clamped to the
+// image origin and its value discarded (a load under a divergent branch is followed by its own s_waitcnt, which made
+// the patch four sequential memory round trips), and scale / shift are picked with selects, not indexed from memory.
 template <typename T, int TH>
 __device__ __forceinline__ void stage_patch(const C3Args& a, float* patch, int n, int y0, int x0, int tid) {
-  for (int i = tid; i < (TH + 2) * PW * 3; i += 256) {
+  constexpr int PN = (TH + 2) * PW * 3;
+  constexpr int PPT = (PN + 255) / 256;
+  const float* src = a.img + n * a.sn;
+  float v[PPT];
+  unsigned okmask = 0u;
+#pragma unroll
+  for (int j = 0; j < PPT; ++j) {
+    const int i = tid + j * 256;
     const int ci = i % 3, p = i / 3;
     const int px = p % PW, py = p / PW;
     const int y = y0 - 1 + py, x = x0 - 1 + px;
-    float v = 0.f;
-    if (y >= 0 && y < a.H && x >= 0 && x < a.W) v = round_T<T>(a.img[n * a.sn + ci * a.sc + y * a.sh + x * a.sw] * a.scale[ci] + a.shift[ci]);
-    patch[i] = v;
+    const bool ok = i < PN && y >= 0 && y < a.H && x >= 0 && x < a.W;
+    okmask |= (ok ? 1u : 0u) << j;
+    v[j] = src[ok ? ci * a.sc + y * a.sh + x * a.sw : 0];
+  }
+#pragma unroll
+  for (int j = 0; j < PPT; ++j) {
+    const int i = tid + j * 256;
+    const int ci = i % 3;
+    const float sc = ci == 0 ? a.scale[0] : (ci == 1 ? a.scale[1] : a.scale[2]);
+    const float sh = ci == 0 ? a.shift[0] : (ci == 1 ? a.shift[1] : a.shift[2]);
+    if (i < PN) patch[i] = ((okmask >> j) & 1u) ? round_T<T>(v[j] * sc + sh) : 0.f;
   }
 }
 
@@ -228,13 +246,25 @@ __global__ __launch_bounds__(256) void conv_c3_wgrad_kernel(const C3Args a) {
     const int n = tile / (a.tiles_x * a.tiles_y);
     __syncthreads();
     stage_patch<T, TH>(a, patch, n, ty * TH, tx * 16, tid);
-    for (int u = tid; u < TH * 16 * (64 / EPB); u += 256) {
-      const int unit = u % (64 / EPB), p = u / (64 / EPB);
-      const int y = ty * TH + p / 16, x = tx * 16 + (p & 15);
-      u32x4 v = (u32x4){0u, 0u, 0u, 0u};
-      if (y < a.H && x < a.W && unit * EPB < cvalid)
-        v = *(const u32x4*)(dzg + (((size_t)n * a.H + y) * a.W + x) * a.cout + nb * 64 + unit * EPB);
-      *(u32x4*)(dzt + p * PA + unit * EPB) = v;
+    {   // dz tile: all loads of a thread first, then the LDS writes (a load consumed under its own branch costs one
+        // memory round trip each)
+      constexpr int DU = TH * 16 * (64 / EPB), DPT = DU / 256;
+      static_assert(DU % 256 == 0, "dz tile units per thread");
+      u32x4 dv[DPT];
+#pragma unroll
+      for (int j = 0; j < DPT; ++j) {
+        const int u = tid + j * 256;
+        const int unit = u % (64 / EPB), p = u / (64 / EPB);
+        const int y = ty * TH + p / 16, x = tx * 16 + (p & 15);
+        const bool ok = y < a.H && x < a.W && unit * EPB < cvalid;
+        const u32x4 t = *(const u32x4*)(dzg + (ok ? (((size_t)n * a.H + y) * a.W + x) * a.cout + nb * 64 + unit * EPB : 0));
+        dv[j] = ok ? t : (u32x4){0u, 0u, 0u, 0u};
+      }
+#pragma unroll
+      for (int j = 0; j < DPT; ++j) {
+        const int u = tid + j * 256;
+        *(u32x4*)(dzt + (u / (64 / EPB)) * PA + (u % (64 / EPB)) * EPB) = dv[j];
+      }
     }
     __syncthreads();
     if (!active) continue;
