@@ -20,6 +20,8 @@
 #include "fsr_conv_args.h"
 #include "fsr_host.h"
 
+#include <stdlib.h>
+
 namespace {
 
 constexpr int P64 = 80;          // LDS pitch in bf16 elements (160 B = 10 slots of 16 B: P = 2 mod 4)
@@ -33,14 +35,21 @@ __device__ __forceinline__ unsigned tap64(const ConvKArgs& a, int t) {
   return (t < 8) ? (unsigned)((a.taps_lo >> (8 * t)) & 0xffull) : a.taps_hi;
 }
 
+// NT = 16-row tiles of output channels per workgroup: 4 (a 64-channel block) or 1 (THIN: a float output of at most 16
+// channels -- the 64 -> 3 head with its tanh, and the image gradients with their per-channel scale; the filter is then
+// 9 x 16 rows and the kernel streams the 64-channel input at memory speed instead of living one tile per workgroup).
+template <int NT>
 __global__ __launch_bounds__(NTHR64, 2) void conv64_persistent_kernel(const ConvKArgs a) {
+  constexpr bool THIN = NT == 1;
+  constexpr int ROWS = NT * 16;
   typedef bf16_t T;
   constexpr int HUNITS = HT * HT * 8;                   // 16-byte units of one halo
   constexpr int HPT = (HUNITS + NTHR64 - 1) / NTHR64;   // 6
   HIP_DYNAMIC_SHARED(char, smem)
   T* wl = (T*)smem;
-  T* halo = (T*)(smem + W_BYTES);
-  float* sred = (float*)(smem + W_BYTES + H_BYTES);     // [64][2]
+  constexpr int WB = 9 * NT * 16 * P64 * 2;            // bytes of the resident filter block
+  T* halo = (T*)(smem + WB);
+  float* sred = (float*)(smem + WB + H_BYTES);          // [64][2]
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int l15 = lane & 15, lg = lane >> 4;
@@ -50,16 +59,20 @@ __global__ __launch_bounds__(NTHR64, 2) void conv64_persistent_kernel(const Conv
 
   // Output channels come in blocks of 64 (Cout = 64, 128, 256): workgroup w owns block nb = w % nblk for its tile range;
   // with a fused PixelShuffle (Cout / 4 = 64 channels per quadrant) block nb IS quadrant nb of the packed filter.
-  const int nblk = a.CoutPad >> 6;
+  const int nblk = THIN ? 1 : (a.CoutPad >> 6);
   const int nb = (int)blockIdx.x % nblk;
   // ---- the 64 filter rows of this block, all nine taps: [9][64][64] -> LDS (4608 units, 9 per thread), once
   {
     const T* wpk = (const T*)a.wpk + (size_t)nb * 64 * 64;
+    constexpr int WU = 9 * ROWS * 8;                    // 16-byte units of the resident filter block
 #pragma unroll
-    for (int i = 0; i < 9; ++i) {
-      const int u = tid + i * NTHR64;                   // (slice*64 + row)*8 + unit
-      const u32x4 v = *(const u32x4*)(wpk + ((size_t)(u >> 9) * a.CoutPad * 64 + (size_t)(u & 511) * 8));
-      *(u32x4*)(wl + (u >> 3) * P64 + (u & 7) * 8) = v;
+    for (int i = 0; i < (WU + NTHR64 - 1) / NTHR64; ++i) {
+      const int u = tid + i * NTHR64;                   // (slice*ROWS + row)*8 + unit
+      if (WU % NTHR64 == 0 || u < WU) {
+        const int slice = u / (ROWS * 8), ru = u % (ROWS * 8);
+        const u32x4 v = *(const u32x4*)(wpk + ((size_t)slice * a.CoutPad * 64 + (size_t)ru * 8));
+        *(u32x4*)(wl + (u >> 3) * P64 + (u & 7) * 8) = v;
+      }
     }
     if (tid < 128) sred[tid] = 0.f;
   }
@@ -93,23 +106,26 @@ __global__ __launch_bounds__(NTHR64, 2) void conv64_persistent_kernel(const Conv
   };
 
   float slope = (a.act == FSR_ACT_PRELU) ? a.prelu[0] : a.slope;
-  if (a.act == FSR_ACT_NONE) slope = 1.f;
+  if (a.act == FSR_ACT_NONE || a.act == FSR_ACT_TANH) slope = 1.f;
   if (a.act == FSR_ACT_RELU) slope = 0.f;
   const bool want_stats = a.stats != nullptr;
   T* outp = (T*)a.out;
   T* prep = (T*)a.preact;
   const T* maskp = (const T*)a.dmask;
 
-  int pixbase[2], wbase[4];
+  int pixbase[2], wbase[NT];
 #pragma unroll
   for (int m = 0; m < 2; ++m) pixbase[m] = ((wave * 2 + m) * HT + l15) * P64 + lg * 8;
 #pragma unroll
-  for (int n = 0; n < 4; ++n) wbase[n] = (n * 16 + l15) * P64 + lg * 8;
-  f32x4 bias[4];
+  for (int n = 0; n < NT; ++n) wbase[n] = (n * 16 + l15) * P64 + lg * 8;
+  f32x4 bias[NT];
 #pragma unroll
-  for (int n = 0; n < 4; ++n) {
+  for (int n = 0; n < NT; ++n) {
     bias[n] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    if (a.bias) {
+    if (a.bias && THIN) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) bias[n][r] = a.bias[lg * 4 + r < a.Cout ? lg * 4 + r : 0];
+    } else if (a.bias) {
       if (!a.ps) bias[n] = *(const f32x4*)(a.bias + nb * 64 + n * 16 + lg * 4);
       else
 #pragma unroll
@@ -121,9 +137,14 @@ __global__ __launch_bounds__(NTHR64, 2) void conv64_persistent_kernel(const Conv
   // across tiles and are flushed (lane shuffle -> LDS -> 128 global atomics) only when the image changes
   const int tile_begin = ((int)blockIdx.x / nblk) * a.nblk_n;   // nblk_n = tiles per workgroup (set by the host)
   const int tile_end = (tile_begin + a.nblk_n < ntiles) ? tile_begin + a.nblk_n : ntiles;
-  f32x4 s1acc[4], s2acc[4];
+  f32x4 oscale = (f32x4){1.f, 1.f, 1.f, 1.f};     // THIN: optional per-channel scale (VGG normalisation in the image gradient)
+  if (THIN && a.oscale) {
 #pragma unroll
-  for (int n = 0; n < 4; ++n) s1acc[n] = s2acc[n] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int r = 0; r < 4; ++r) oscale[r] = a.oscale[lg * 4 + r < a.Cout ? lg * 4 + r : 0];
+  }
+  f32x4 s1acc[NT], s2acc[NT];
+#pragma unroll
+  for (int n = 0; n < NT; ++n) s1acc[n] = s2acc[n] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
   int tile = tile_begin;
   if (tile < tile_end) halo_issue(tile);
@@ -135,27 +156,27 @@ __global__ __launch_bounds__(NTHR64, 2) void conv64_persistent_kernel(const Conv
     const int next = tile + 1;
     if (next < tile_end) halo_issue(next);
 
-    f32x4 acc[2][4];
+    f32x4 acc[2][NT];
 #pragma unroll
     for (int m = 0; m < 2; ++m)
 #pragma unroll
-      for (int n = 0; n < 4; ++n) acc[m][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      for (int n = 0; n < NT; ++n) acc[m][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int t = 0; t < 9; ++t) {
       const unsigned tc = tap64(a, t);
       const int toff = ((int)(tc & 3u) * HT + (int)((tc >> 2) & 3u)) * P64;
-      const T* wsl = wl + (int)(tc >> 4) * 64 * P64;
+      const T* wsl = wl + (int)(tc >> 4) * ROWS * P64;
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks) {
-        s16x8 wf[4], xf[2];
+        s16x8 wf[NT], xf[2];
 #pragma unroll
-        for (int n = 0; n < 4; ++n) wf[n] = *(const s16x8*)(wsl + wbase[n] + ks * 32);
+        for (int n = 0; n < NT; ++n) wf[n] = *(const s16x8*)(wsl + wbase[n] + ks * 32);
 #pragma unroll
         for (int m = 0; m < 2; ++m) xf[m] = *(const s16x8*)(halo + pixbase[m] + toff + ks * 32);
 #pragma unroll
         for (int m = 0; m < 2; ++m)
 #pragma unroll
-          for (int n = 0; n < 4; ++n) acc[m][n] = mfma_bf16_16x16x32(wf[n], xf[m], acc[m][n]);
+          for (int n = 0; n < NT; ++n) acc[m][n] = mfma_bf16_16x16x32(wf[n], xf[m], acc[m][n]);
       }
     }
 
@@ -166,6 +187,26 @@ __global__ __launch_bounds__(NTHR64, 2) void conv64_persistent_kernel(const Conv
     const int ty = rem / a.tiles_x, tx = rem - ty * a.tiles_x;
     const int gx = tx * 16 + l15, gyb = ty * 16 + wave * 2;
     const bool col_ok = gx < a.GW;
+    if constexpr (THIN) {
+      // float output, Cout <= 16 valid channels (lane group lg holds channels 4 lg .. 4 lg + 3): scale, bias, tanh / slope
+#pragma unroll
+      for (int m = 0; m < 2; ++m) {
+        if (col_ok && gyb + m < a.GH) {
+          const size_t off = (((size_t)img * a.FOH + gyb + m) * a.FOW + gx) * a.Cout + lg * 4;
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+            if (lg * 4 + r < a.Cout) {
+              float v = acc[m][0][r] * oscale[r] + bias[0][r];
+              v = (a.act == FSR_ACT_TANH) ? tanhf(v) : (v > 0.f ? v : v * slope);
+              ((float*)a.out)[off + r] = v;
+            }
+        }
+      }
+      __syncthreads();
+      if (next < tile_end) halo_commit();
+      __syncthreads();
+      continue;
+    }
     // plain: pixel (gy, gx), channels nb*64 + ...; PixelShuffle(2): pixel (2 gy + (nb >> 1), 2 gx + (nb & 1)) of the
     // [2 FOH, 2 FOW, 64] tensor, channels 0..63
     const unsigned rstride = a.ps ? (unsigned)(4 * a.FOW * 64) : (unsigned)(a.FOW * a.Cout);
@@ -178,10 +219,10 @@ __global__ __launch_bounds__(NTHR64, 2) void conv64_persistent_kernel(const Conv
 #pragma unroll
       for (int m = 0; m < 2; ++m)
 #pragma unroll
-        for (int n = 0; n < 4; ++n)
+        for (int n = 0; n < NT; ++n)
           mkv[m][n] = (col_ok && gyb + m < a.GH) ? *(const u32x2*)(maskp + (base0 + m * rstride + n * 16)) : (u32x2){0u, 0u};
     }
-    static_for<0, 4>([&](auto nc) {
+    static_for<0, NT>([&](auto nc) {
       constexpr int n = decltype(nc)::value;
       static_for<0, 2>([&](auto mc) {
         constexpr int m = decltype(mc)::value;
@@ -434,11 +475,16 @@ int fsr_conv64_s2dgrad_try(int dtype, ConvKArgs& a, hipStream_t stream) {
 
 // Returns 1 if the launch was taken, 0 if the shape is not this kernel's, < 0 on error.
 int fsr_conv64_persistent_try(int dtype, ConvKArgs& a, int S, hipStream_t stream) {
-  if (dtype != FSR_BF16 || S != 1 || a.Cin != 64 || a.Cout % 64 != 0 || a.CoutPad != a.Cout || a.Cout > 256 || a.ntaps != 9) return 0;
-  if (a.in_ps || a.out_f32 || a.oscale) return 0;
-  if (a.ps && (a.Cout != 256 || a.stats || a.dmask)) return 0;   // PixelShuffle(2): one quadrant = one 64-row block
-  if (a.preact && a.dmask) return 0;
-  if (a.stats && a.dmask) return 0;   // InstanceNorm backward sums: generic kernel
+  if (dtype != FSR_BF16 || S != 1 || a.Cin != 64 || a.ntaps != 9) return 0;
+  // thin: float output of at most 16 channels (head conv, image gradients); otherwise 64-channel blocks
+  const bool thin = a.CoutPad == 16 && a.out_f32 && !a.ps && !a.in_ps && !a.stats && !a.preact && !a.dmask;
+  if (!thin) {
+    if (a.Cout % 64 != 0 || a.CoutPad != a.Cout || a.Cout > 256) return 0;
+    if (a.in_ps || a.out_f32 || a.oscale) return 0;
+    if (a.ps && (a.Cout != 256 || a.stats || a.dmask)) return 0;   // PixelShuffle(2): one quadrant = one 64-row block
+    if (a.preact && a.dmask) return 0;
+    if (a.stats && a.dmask) return 0;   // InstanceNorm backward sums: generic kernel
+  }
   if (a.osy != 1 || a.osx != 1 || a.ooy != 0 || a.oox != 0) return 0;
   if ((long long)a.N * a.IH * a.IW * 64 >= (1LL << 31) || (long long)a.N * a.FOH * a.FOW * a.Cout >= (1LL << 31)) return 0;
   a.tiles_x = (a.GW + 15) / 16;
@@ -455,7 +501,8 @@ int fsr_conv64_persistent_try(int dtype, ConvKArgs& a, int S, hipStream_t stream
   if (ntiles <= 0 || ntiles > 0x7fffffffLL) return 0;
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute((const void*)conv64_persistent_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS64);
+    (void)hipFuncSetAttribute((const void*)conv64_persistent_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS64);
+    (void)hipFuncSetAttribute((const void*)conv64_persistent_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS64);
     attr_set = true;
   }
   static int cus = 0;    // one persistent workgroup per CU (LDS admits exactly one)
@@ -465,13 +512,14 @@ int fsr_conv64_persistent_try(int dtype, ConvKArgs& a, int S, hipStream_t stream
     cus = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
               ? prop.multiProcessorCount : 256;
   }
-  const int nblk = a.Cout / 64;                              // channel blocks: workgroup w -> block w % nblk
-  int slots = cus / nblk;                                    // tile ranges
+  const int nblk = thin ? 1 : a.Cout / 64;                   // channel blocks: workgroup w -> block w % nblk
+  int slots = thin ? 2 * cus : cus / nblk;                   // tile ranges (the thin kernel's LDS admits two workgroups per CU)
   if (slots < 1) slots = 1;
   const int per = (int)((ntiles + slots - 1) / slots);      // contiguous tiles per workgroup
   a.nblk_n = per;
   const int grid = (int)((ntiles + per - 1) / per) * nblk;
-  hipLaunchKernelGGL(conv64_persistent_kernel, dim3(grid), dim3(NTHR64), LDS64, stream, a);
+  if (thin) hipLaunchKernelGGL(conv64_persistent_kernel<1>, dim3(grid), dim3(NTHR64), 9 * 16 * P64 * 2 + H_BYTES + 128 * 4, stream, a);
+  else hipLaunchKernelGGL(conv64_persistent_kernel<4>, dim3(grid), dim3(NTHR64), LDS64, stream, a);
   int rc = fsr_check_launch("conv64_persistent_kernel");
   return rc ? rc : 1;
 }
