@@ -134,6 +134,24 @@ __global__ __launch_bounds__(256) void conv_c3_fwd_kernel(const C3Args a) {
   T* outp = (T*)a.out;
   T* prep = (T*)a.preact;
   const int gx = tx * 16 + l15;
+  // the lane's bias values, fetched BEFORE the first store (a load issued after a store waits for that store: one
+  // counter for both); wide layout: [pair][low / high run], plain: [tile]
+  f32x4 bv[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) bv[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  if (a.bias) {
+    if (wide) {
+#pragma unroll
+      for (int p = 0; p < 2; ++p) {
+        bv[2 * p] = *(const f32x4*)(a.bias + nb * 64 + p * 32 + lg * 8);
+        bv[2 * p + 1] = *(const f32x4*)(a.bias + nb * 64 + p * 32 + lg * 8 + 4);
+      }
+    } else {
+#pragma unroll
+      for (int t = 0; t < 4; ++t)
+        if (t < ntile) bv[t] = *(const f32x4*)(a.bias + nb * 64 + t * 16 + lg * 4);
+    }
+  }
 #pragma unroll
   for (int m = 0; m < 4; ++m) {
     const int r = wave * 4 + m;                   // row of the tile
@@ -158,10 +176,8 @@ __global__ __launch_bounds__(256) void conv_c3_fwd_kernel(const C3Args a) {
 #pragma unroll
           for (int p = 0; p < 2; ++p) {
             f32x4 lo = acc[2 * p], hi = acc[2 * p + 1];
-            if (a.bias) {
-              lo += *(const f32x4*)(a.bias + nb * 64 + p * 32 + lg * 8);
-              hi += *(const f32x4*)(a.bias + nb * 64 + p * 32 + lg * 8 + 4);
-            }
+            lo += bv[2 * p];
+            hi += bv[2 * p + 1];
             if (prep)
               *(u32x4*)(prep + off + p * 32) = (u32x4){pack_bf16x2(lo[0], lo[1]), pack_bf16x2(lo[2], lo[3]),
                                                        pack_bf16x2(hi[0], hi[1]), pack_bf16x2(hi[2], hi[3])};
@@ -190,7 +206,7 @@ __global__ __launch_bounds__(256) void conv_c3_fwd_kernel(const C3Args a) {
         if (gx < a.W && gy < a.H) {
           const int co = nb * 64 + t * 16 + lg * 4;
           const size_t off = (((size_t)n * a.H + gy) * a.W + gx) * a.cout + co;
-          if (a.bias) acc += *(const f32x4*)(a.bias + co);
+          acc += bv[t];
           if constexpr (sizeof(T) == 2) {
             if (prep) {
               u32x2 pk;
