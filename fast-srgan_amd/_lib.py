@@ -9,7 +9,8 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libfsr_hip.so")
+# FSR_HIP_LIB: another build of the same sources (kernel A/B experiments, tools/ab.py); the default is the in-tree library
+LIB_PATH = os.environ.get("FSR_HIP_LIB") or os.path.join(_HERE, "libfsr_hip.so")
 
 FSR_F32, FSR_BF16 = 0, 1
 ACT_NONE, ACT_RELU, ACT_LEAKY, ACT_PRELU, ACT_TANH = 0, 1, 2, 3, 4
