@@ -17,9 +17,10 @@
 //   workgroup -> BM output channels x BN input channels x all 9 taps, for a slab of pixel tiles
 //                (TPH x 16 output pixels each); the dy tile and the x halo of a pixel tile are
 //                staged in LDS once and reused by all 9 taps (x) / all taps and channel tiles (dy);
-//   wave      -> one 16-row co tile x TPW 16-wide ci tiles x 9 taps of accumulators in registers; the
-//                64x64 block runs with 8 waves (TPW = 2, 72 accumulator registers) so that two waves share
-//                each SIMD and cover each other's transposing-read latency;
+//   wave      -> 64x64 blocks (8 waves, two per SIMD covering each other's transposing-read latency): TWO co tiles x
+//                one ci tile x 9 taps (72 accumulator registers) -- every transposed x fragment feeds two MFMAs, 22
+//                transposing reads per 18 MFMAs (one co tile x two ci tiles needs 38: measured 10-20 % slower);
+//                other blocks: one co tile x TPW ci tiles x 9 taps;
 //   split-K   -> slabs write f32 partials [slab][9][cout_pad][cin_pad] to the workspace; a second
 //                kernel sums the slabs and adds the result into the OIHW float gradient.
 #include "fsr_common.h"
@@ -62,8 +63,12 @@ __global__ __launch_bounds__((BM == 64 && BN == 64) ? 512 : 256) void conv_wgrad
   const int bm = bid % a.nbm;
   const int slab = bid / a.nbm;
 
+  // 64x64 blocks (8 waves): wave -> (pair of co tiles, one ci tile): a transposed x fragment feeds TWO MFMAs, 22 instead
+  // of 38 transposing reads per 18 MFMAs.  Other blocks: wave -> (one co tile, TPW ci tiles).
+  constexpr bool COPAIR = (BM == 64 && BN == 64);
   const bool active = wave * TPW < NPAIR;
-  const int co_t = (wave * TPW) / NBT, ci_t0 = (wave * TPW) % NBT;
+  const int co_t = COPAIR ? (wave / NBT) * 2 : (wave * TPW) / NBT;
+  const int ci_t0 = COPAIR ? wave % NBT : (wave * TPW) % NBT;
 
   f32x4 acc[9][TPW];
 #pragma unroll
@@ -152,23 +157,33 @@ __global__ __launch_bounds__((BM == 64 && BN == 64) ? 512 : 256) void conv_wgrad
       for (int s = 0; s < TPH / 2; ++s) {
         const int r = 2 * s + (lg >> 1);
         const int c0 = 8 * (lg & 1);
-        s16x8 af;
-        {
-          const T* pa = dyt + (r * 16 + c0 + qrow) * PA + co_t * 16 + qch;
+        constexpr int NA = COPAIR ? TPW : 1;       // co tiles per wave
+        s16x8 af[NA];
+#pragma unroll
+        for (int w = 0; w < NA; ++w) {
+          const T* pa = dyt + (r * 16 + c0 + qrow) * PA + (co_t + w) * 16 + qch;
           const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(FSR_LDS_PTR(s16x4, pa));
           const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(FSR_LDS_PTR(s16x4, pa + 4 * PA));
-          af = (s16x8){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+          af[w] = (s16x8){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
         }
 #pragma unroll
         for (int t = 0; t < 9; ++t) {
           const int ky = t / 3, kx = t % 3;
           const T* pb0 = halo + ((r * S + ky) * HW + (c0 + qrow) * S + kx) * PB + ci_t0 * 16 + qch;
-#pragma unroll
-          for (int j = 0; j < TPW; ++j) {
-            const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(FSR_LDS_PTR(s16x4, pb0 + j * 16));
-            const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(FSR_LDS_PTR(s16x4, pb0 + j * 16 + 4 * S * PB));
+          if constexpr (COPAIR) {
+            const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(FSR_LDS_PTR(s16x4, pb0));
+            const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(FSR_LDS_PTR(s16x4, pb0 + 4 * S * PB));
             const s16x8 bf = (s16x8){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-            acc[t][j] = mfma_bf16_16x16x32(af, bf, acc[t][j]);
+#pragma unroll
+            for (int w = 0; w < TPW; ++w) acc[t][w] = mfma_bf16_16x16x32(af[w], bf, acc[t][w]);
+          } else {
+#pragma unroll
+            for (int j = 0; j < TPW; ++j) {
+              const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(FSR_LDS_PTR(s16x4, pb0 + j * 16));
+              const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(FSR_LDS_PTR(s16x4, pb0 + j * 16 + 4 * S * PB));
+              const s16x8 bf = (s16x8){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+              acc[t][j] = mfma_bf16_16x16x32(af[0], bf, acc[t][j]);
+            }
           }
         }
       }
@@ -178,12 +193,19 @@ __global__ __launch_bounds__((BM == 64 && BN == 64) ? 512 : 256) void conv_wgrad
       for (int s = 0; s < TPH * 4; ++s) {
         const int r = s >> 2, c = 4 * (s & 3) + lg;
         const float av = dyt[(r * 16 + c) * PA + co_t * 16 + l15];
+        const float av1 = COPAIR ? dyt[(r * 16 + c) * PA + (co_t + 1) * 16 + l15] : 0.f;
 #pragma unroll
         for (int t = 0; t < 9; ++t) {
           const int ky = t / 3, kx = t % 3;
           const T* pb = halo + ((r * S + ky) * HW + c * S + kx) * PB + ci_t0 * 16 + l15;
+          if constexpr (COPAIR) {
+            const float bv = pb[0];
+            acc[t][0] = mfma_f32_16x16x4(av, bv, acc[t][0]);
+            acc[t][1] = mfma_f32_16x16x4(av1, bv, acc[t][1]);
+          } else {
 #pragma unroll
-          for (int j = 0; j < TPW; ++j) acc[t][j] = mfma_f32_16x16x4(av, pb[j * 16], acc[t][j]);
+            for (int j = 0; j < TPW; ++j) acc[t][j] = mfma_f32_16x16x4(av, pb[j * 16], acc[t][j]);
+          }
         }
       }
     }
@@ -195,7 +217,8 @@ __global__ __launch_bounds__((BM == 64 && BN == 64) ? 512 : 256) void conv_wgrad
   for (int t = 0; t < 9; ++t)
 #pragma unroll
     for (int j = 0; j < TPW; ++j) {
-      float* o = a.ws + (((size_t)slab * 9 + t) * a.CoutPad + bm * BM + co_t * 16 + lg * 4) * a.CinPad + bn * BN + (ci_t0 + j) * 16 + l15;
+      const int cot = COPAIR ? co_t + j : co_t, cit = COPAIR ? ci_t0 : ci_t0 + j;
+      float* o = a.ws + (((size_t)slab * 9 + t) * a.CoutPad + bm * BM + cot * 16 + lg * 4) * a.CinPad + bn * BN + cit * 16 + l15;
 #pragma unroll
       for (int r = 0; r < 4; ++r) o[(size_t)r * a.CinPad] = acc[t][j][r];
     }
