@@ -16,7 +16,7 @@ FSR_F32, FSR_BF16 = 0, 1
 ACT_NONE, ACT_RELU, ACT_LEAKY, ACT_PRELU, ACT_TANH = 0, 1, 2, 3, 4
 CONV_FWD, CONV_DGRAD = 0, 1
 PACK_FWD, PACK_FWD_PS, PACK_DGRAD, PACK_DGRAD_PS = 0, 1, 2, 3
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 c_int, c_float, c_void_p, c_size_t, c_ll = ctypes.c_int, ctypes.c_float, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_longlong
 
@@ -63,7 +63,7 @@ SIGNATURES = {
                                    c_float, c_float, P, P, c_int, c_float, P, c_int, P, P, P]),
     "fsr_conv3x3_c3_wgrad_workspace": (ctypes.c_size_t, [c_int, c_int, c_int, c_int]),
     "fsr_conv3x3_c3_wgrad": (c_int, [c_int, P, c_ll, c_ll, c_ll, c_ll, c_int, c_int, c_int, c_float, c_float, c_float,
-                                     c_float, c_float, c_float, P, c_int, P, P, P]),
+                                     c_float, c_float, c_float, P, c_int, P, P, P, P]),
     "fsr_tanh_bwd_to_nhwc": (c_int, [c_int, P, c_ll, c_ll, c_ll, c_ll, P, c_int, c_int, c_int, P, c_int, P, P]),
     "fsr_maxpool2_fwd": (c_int, [c_int, P, P, c_int, c_int, c_int, c_int, P]),
     "fsr_maxpool2_bwd": (c_int, [c_int, P, P, P, P, c_int, c_int, c_int, c_int, c_int, P]),

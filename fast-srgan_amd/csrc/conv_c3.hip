@@ -252,6 +252,9 @@ __global__ __launch_bounds__(256) void conv_c3_wgrad_kernel(const C3Args a) {
 
   // patch offsets of this lane's two columns j = l15 and j = 16 + l15 (k = column index; k >= 27 is padding)
   const int off0 = patch_off(l15), off1 = (16 + l15 < 27) ? patch_off(16 + l15) : -1;
+  // column 27 (the first padding column) is a column of ones: dW[co][27] = sum over pixels of dz = the BIAS gradient,
+  // for free (tile pixels outside the image have dz = 0)
+  const float ones27 = (l15 == 11) ? 1.f : 0.f;
   f32x4 acc0 = (f32x4){0.f, 0.f, 0.f, 0.f}, acc1 = (f32x4){0.f, 0.f, 0.f, 0.f};
 
   const int t0 = slab * a.tiles_per_slab;
@@ -299,7 +302,7 @@ __global__ __launch_bounds__(256) void conv_c3_wgrad_kernel(const C3Args a) {
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
           b0[e] = pb[e * 3 + off0];
-          b1[e] = off1 >= 0 ? pb[e * 3 + off1] : 0.f;
+          b1[e] = off1 >= 0 ? pb[e * 3 + off1] : ones27;
         }
         const s16x8 bf0 = __builtin_bit_cast(s16x8, (u32x4){pack_bf16x2(b0[0], b0[1]), pack_bf16x2(b0[2], b0[3]),
                                                            pack_bf16x2(b0[4], b0[5]), pack_bf16x2(b0[6], b0[7])});
@@ -316,7 +319,7 @@ __global__ __launch_bounds__(256) void conv_c3_wgrad_kernel(const C3Args a) {
         const float av = dzt[(r * 16 + c) * PA + wave * 16 + l15];
         const float* pb = patch + (r * PW + c) * 3;
         acc0 = mfma_f32_16x16x4(av, pb[off0], acc0);
-        acc1 = mfma_f32_16x16x4(av, off1 >= 0 ? pb[off1] : 0.f, acc1);
+        acc1 = mfma_f32_16x16x4(av, off1 >= 0 ? pb[off1] : ones27, acc1);
       }
     }
   }
@@ -333,17 +336,17 @@ __global__ __launch_bounds__(256) void conv_c3_wgrad_kernel(const C3Args a) {
 // dw[co][ci][ky][kx] += sum_slab ws[slab][co][k], k = (ky*3+kx)*3 + ci
 // blockIdx.y = a group of slabs; each group adds its share with one float atomic per element
 __global__ __launch_bounds__(256) void conv_c3_wgrad_reduce_kernel(const float* __restrict__ ws, float* __restrict__ dw, int nslab,
-                                                                   int cout, int slabs_per_group) {
+                                                                   int cout, int slabs_per_group, float* __restrict__ dbias) {
   const int total = cout * 32;
   const int j0 = blockIdx.y * slabs_per_group;
   const int j1 = (j0 + slabs_per_group < nslab) ? j0 + slabs_per_group : nslab;
   for (int i = blockIdx.x * 256 + threadIdx.x; i < total; i += gridDim.x * 256) {
     const int k = i & 31, co = i >> 5;
-    if (k >= 27) continue;
+    if (k > 27 || (k == 27 && !dbias)) continue;
     float s = 0.f;
     for (int j = j0; j < j1; ++j) s += ws[(size_t)j * total + i];
     const int tap = k / 3, ci = k - tap * 3;
-    float* o = dw + ((size_t)co * 3 + ci) * 9 + tap;
+    float* o = (k == 27) ? dbias + co : dw + ((size_t)co * 3 + ci) * 9 + tap;
     if (gridDim.y == 1) *o += s;
     else atomicAdd(o, s);
   }
@@ -441,7 +444,7 @@ extern "C" size_t fsr_conv3x3_c3_wgrad_workspace(int n, int h, int w, int cout) 
 
 extern "C" int fsr_conv3x3_c3_wgrad(int dtype, const float* img, long long sn, long long sc, long long sh, long long sw,
                                     int n, int h, int w, float scale0, float scale1, float scale2, float shift0,
-                                    float shift1, float shift2, const void* dz, int cout, float* dw_oihw, void* workspace,
+                                    float shift1, float shift2, const void* dz, int cout, float* dw_oihw, float* dbias, void* workspace,
                                     fsr_stream_t stream_) {
   C3Args a = {};
   const float scale3[3] = {scale0, scale1, scale2}, shift3[3] = {shift0, shift1, shift2};
@@ -457,6 +460,6 @@ extern "C" int fsr_conv3x3_c3_wgrad(int dtype, const float* img, long long sn, l
   if (int rc = fsr_check_launch("conv_c3_wgrad_kernel")) return rc;
   const int per_group = nslab > 64 ? 16 : nslab;
   hipLaunchKernelGGL(conv_c3_wgrad_reduce_kernel, dim3((cout * 32 + 255) / 256, (nslab + per_group - 1) / per_group), dim3(256), 0,
-                     (hipStream_t)stream_, (const float*)workspace, dw_oihw, nslab, cout, per_group);
+                     (hipStream_t)stream_, (const float*)workspace, dw_oihw, nslab, cout, per_group, dbias);
   return fsr_check_launch("conv_c3_wgrad_reduce_kernel");
 }

@@ -389,6 +389,7 @@ class Conv3x3Fn(torch.autograd.Function):
             prof.append((ev0, ev1, 2.0 * n * h * w * cout * 27, nbytes))
         ctx.cfg = cfg
         ctx.c3 = True
+        ctx.bias_param = bias
         ctx.dims = (cout, 3, (n, h, w, cd.cpad))
         ctx.has_bias = bias is not None
         ctx.x_is_image = True
@@ -419,9 +420,14 @@ class Conv3x3Fn(torch.autograd.Function):
                                              st), "fsr_tanh_bwd_to_nhwc")
         else:
             g = g if g.is_contiguous() else g.contiguous()
+            # first-layer kernels with arena gradients: the weight-gradient launch also produces the bias gradient (a column
+            # of ones in its padded K dimension), straight into the bias' arena slice
+            bias_arena = getattr(getattr(ctx, "bias_param", None), "_fsr_grad", None) if ctx.c3 else None
+            fused_dbias = (bias_arena is not None and cfg.act_bwd_by_consumer and ctx.needs_input_grad[1] and ctx.needs_input_grad[2]
+                           and getattr(weight, "_fsr_grad", None) is not None)
             if cfg.act_bwd_by_consumer:
                 dz = g          # already multiplied by this layer's act'() in the consumer's data-gradient epilogue
-                if ctx.has_bias and ctx.needs_input_grad[2]:    # bias gradient: column sums of dz, one read pass
+                if ctx.has_bias and ctx.needs_input_grad[2] and not fused_dbias:    # bias gradient: column sums of dz, one read pass
                     _, h, w, c = g.shape
                     L.check(lib.fsr_act_bwd(cd.code, _p(g), None, L.ACT_NONE, 0.0, None, None, _p(dbias), None, n, h, w, c,
                                             int(cfg.pixel_shuffle), st), "fsr_act_bwd")
@@ -459,7 +465,8 @@ class Conv3x3Fn(torch.autograd.Function):
                     need = lib.fsr_conv3x3_c3_wgrad_workspace(n, ih, iw, cout)
                     sn, sc, sh, sw = xin.stride()
                     L.check(lib.fsr_conv3x3_c3_wgrad(cd.code, _p(xin), sn, sc, sh, sw, n, ih, iw, *cfg.in_scale, *cfg.in_shift,
-                                                     _p(dz), cout, _p(out), _p(_workspace(need, xin.device)), _stream()),
+                                                     _p(dz), cout, _p(out), _p(bias_arena) if fused_dbias else None,
+                                                     _p(_workspace(need, xin.device)), _stream()),
                             "fsr_conv3x3_c3_wgrad")
                     return out
                 return conv3x3_wgrad_raw(cd, xin, dz, cout, cin, cfg.stride, dy_pixel_shuffled=cfg.pixel_shuffle, out=arena)
@@ -472,6 +479,8 @@ class Conv3x3Fn(torch.autograd.Function):
             if arena is not None:
                 dw = None
         db = dbias if (ctx.has_bias and ctx.needs_input_grad[2]) else None
+        if not cfg.tanh_head and ctx.c3 and fused_dbias:
+            db = None       # accumulated in the arena by the weight-gradient launch
         dp = dprelu if (dprelu is not None and ctx.needs_input_grad[3]) else None
         return dx, dw, db, dp, None
 

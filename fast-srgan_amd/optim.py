@@ -38,8 +38,8 @@ class ArenaAdamW(torch.optim.Optimizer):
             self.flat_param[off:off + n].copy_(p.detach().reshape(-1))
             p.data = self.flat_param[off:off + n].view(p.shape)
             p.grad = self.flat_grad[off:off + n].view(p.shape)
-            if p.dim() == 4 and p.shape[2:] == (3, 3):
-                p._fsr_grad = p.grad  # conv3x3 weight-gradient kernels accumulate here directly
+            if (p.dim() == 4 and p.shape[2:] == (3, 3)) or p.dim() == 1:
+                p._fsr_grad = p.grad  # conv3x3 weight-gradient kernels accumulate here directly (weights; first-layer biases)
             self._slices.append((off, n))
             off += n
 

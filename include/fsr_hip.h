@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define FSR_ABI_VERSION 4
+#define FSR_ABI_VERSION 5
 
 enum { FSR_F32 = 0, FSR_BF16 = 1 };
 enum { FSR_ACT_NONE = 0, FSR_ACT_RELU = 1, FSR_ACT_LEAKY = 2, FSR_ACT_PRELU = 3, FSR_ACT_TANH = 4 };
@@ -165,6 +165,8 @@ int fsr_tanh_bwd_to_nhwc(int dtype, const float* g, long long sn, long long sc, 
  *   fsr_pack_conv3x3_c3 : OIHW float [cout][3][3][3] -> `dtype` [round_up(cout,16)][32], k = (ky*3+kx)*3 + ci.
  *   fsr_conv3x3_c3_fwd  : out[n,h,w,cout] = act(conv + bias); act NONE/RELU/LEAKY/PRELU; preact optional.
  *   fsr_conv3x3_c3_wgrad: dw_oihw (float [cout][3][3][3]) += d loss / d weight for dz [n,h,w,cout] `dtype`;
+ *                         dbias (optional, float [cout]) += per-channel sums of dz (the bias gradient: a column of
+ *                         ones in the padded K dimension of the same MFMAs);
  *                         workspace of fsr_conv3x3_c3_wgrad_workspace(n,h,w,cout) bytes. */
 int fsr_pack_conv3x3_c3(int dtype, const float* w_oihw, int cout, void* packed, fsr_stream_t stream);
 int fsr_conv3x3_c3_fwd(int dtype, const float* img, long long sn, long long sc, long long sh, long long sw, int n, int h,
@@ -174,7 +176,7 @@ int fsr_conv3x3_c3_fwd(int dtype, const float* img, long long sn, long long sc, 
 size_t fsr_conv3x3_c3_wgrad_workspace(int n, int h, int w, int cout);
 int fsr_conv3x3_c3_wgrad(int dtype, const float* img, long long sn, long long sc, long long sh, long long sw, int n, int h,
                          int w, float scale0, float scale1, float scale2, float shift0, float shift1, float shift2,
-                         const void* dz, int cout, float* dw_oihw, void* workspace, fsr_stream_t stream);
+                         const void* dz, int cout, float* dw_oihw, float* dbias, void* workspace, fsr_stream_t stream);
 
 /* ------------------------------------------------------------------ MaxPool2d(2,2) of vgg19.features (model.py:8)
  * x [n,h,w,c] -> y [n,h/2,w/2,c].  Backward routes g to the first maximum in window scan order; with

@@ -200,6 +200,31 @@ def test_first_layer_kernels(dev, cdn, cout, act, layout):
     assert err(wd.grad, wd2.grad) < tol(cdn, 1e-5 if act == L.ACT_NONE else t32, 1e-3)
 
 
+@pytest.mark.parametrize("cdn", ["f32", "bf16"])
+def test_first_layer_bias_gradient_from_the_weight_gradient_launch(dev, cdn):
+    """Arena gradients + activation backward done by the consumer (the Discriminator neck): fsr_conv3x3_c3_wgrad also
+    accumulates the bias gradient (a column of ones in its padded K dimension) straight into the bias' arena slice."""
+    cd = ops.Compute(cdn)
+    torch.manual_seed(31)
+    n, h, w, cout = (3, 70, 52, 64) if _big(dev) else (2, 9, 19, 32)
+    img = torch.rand(n, 3, h, w) * 2 - 1
+    wt = _q(torch.randn(cout, 3, 3, 3) * 0.2, cd)
+    b = torch.randn(cout) * 0.1
+    cfg = ops.ConvCfg(cd, act=L.ACT_LEAKY, slope=0.2, image_in=True, act_bwd_by_consumer=True)
+    xi, wd, bd = img.to(dev), leaf(wt, dev), leaf(b, dev)
+    wd._fsr_grad = torch.zeros_like(wd)           # what optim.ArenaAdamW sets up
+    bd._fsr_grad = torch.zeros_like(bd)
+    y, _ = ops.conv3x3(xi, wd, bd, None, cfg)
+    dz = _q(torch.randn(n, cout, h, w), cd)       # "already multiplied by act'" gradient, as the consumer hands it over
+    y.backward(_nhwc(dz, cd, dev))
+    assert wd.grad is None and bd.grad is None    # autograd was handed nothing: both went to the arena
+    xn = _q(img, cd)
+    wr = leaf(wt)
+    F.conv2d(xn, wr, None, 1, 1).backward(dz)
+    assert relerr(wd._fsr_grad, wr.grad) < tol(cdn, 1e-4, 2e-2)
+    assert relerr(bd._fsr_grad, dz.sum((0, 2, 3))) < tol(cdn, 1e-4, 1e-2)
+
+
 def test_first_layer_kernels_reject_bad_arguments(dev):
     cd = ops.Compute("f32")
     lib = L.lib()
@@ -210,7 +235,7 @@ def test_first_layer_kernels_reject_bad_arguments(dev):
     assert lib.fsr_conv3x3_c3_fwd(cd.code, *args, wpk.data_ptr(), None, L.ACT_NONE, 0.0, None, 24, out.data_ptr(), None, None) < 0
     assert b"multiple of 16" in lib.fsr_last_error()
     assert lib.fsr_conv3x3_c3_fwd(cd.code, *args, wpk.data_ptr(), None, L.ACT_PRELU, 0.0, None, 16, out.data_ptr(), None, None) < 0
-    assert lib.fsr_conv3x3_c3_wgrad(cd.code, *args, None, 16, out.data_ptr(), out.data_ptr(), None) < 0
+    assert lib.fsr_conv3x3_c3_wgrad(cd.code, *args, None, 16, out.data_ptr(), None, out.data_ptr(), None) < 0
     assert lib.fsr_conv3x3_c3_wgrad_workspace(0, 8, 8, 16) == 0
 
 
