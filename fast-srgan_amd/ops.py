@@ -354,6 +354,7 @@ class Conv3x3Fn(torch.autograd.Function):
         if stats is None:
             stats = torch.empty(0, device=out.device)
         ctx.mark_non_differentiable(stats)
+        ctx.set_materialize_grads(False)    # no zero-filled gradient tensor for the statistics output per backward call
         if cfg.tanh_head:
             return out.permute(0, 3, 1, 2), stats
         return out, stats
@@ -397,10 +398,13 @@ class Conv3x3Fn(torch.autograd.Function):
         ctx.save_for_backward(x, weight, prelu, saved_act)
         stats = torch.empty(0, device=out.device)
         ctx.mark_non_differentiable(stats)
+        ctx.set_materialize_grads(False)    # no zero-filled gradient tensor for the statistics output per backward call
         return out, stats
 
     @staticmethod
     def backward(ctx, g, _gstats):
+        if g is None:       # (gradients are not materialised: only the statistics output was used downstream)
+            return None, None, None, None, None
         cfg, cd = ctx.cfg, ctx.cfg.cd
         xin, weight, prelu, saved = ctx.saved_tensors
         cout, cin, xshape = ctx.dims
