@@ -140,6 +140,13 @@ def test_full_size_modules_vs_oracle_gpu(pkg, cdn):
         for k, p in mod.named_parameters():
             if p.numel() < 1000 and cdn == "bf16":
                 continue   # PReLU slopes, biases: a few cancelling sums, their relative error says nothing in bf16
+            if p.numel() == 1:
+                # a PReLU slope's gradient is ONE cancelling sum over every activation of its layer: when the float atomics
+                # of the InstanceNorm statistics land in another order, a sign flip upstream moves it by several per cent
+                # (tests/flake_probe.py: 2e-3 .. 7e-2 over 40 runs of this very check).  The operator tests bound it
+                # against the magnitude of its terms (test_ops.py); here it only has to be finite and of the right size.
+                assert relerr2(p.grad, ref[(tag, k)]) < 0.5, (tag, k)
+                continue
             assert relerr2(p.grad, ref[(tag, k)]) < t_grad, (tag, k, relerr2(p.grad, ref[(tag, k)]))
 
 
