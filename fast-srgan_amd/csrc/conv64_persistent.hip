@@ -391,7 +391,6 @@ __global__ __launch_bounds__(NTHR64, 2) void conv64_s2dgrad_kernel(const ConvKAr
     const int rem = tile - img * tiles_per_img;
     const int ty = rem / a.tiles_x, tx = rem - ty * a.tiles_x;
     const int gx = tx * 16 + l15, gyb = ty * 16 + wave * 2;
-    const unsigned rstride = (unsigned)(a.FOW * 64);
     static_for<0, 4>([&](auto qc) {
       constexpr int q = decltype(qc)::value;
       constexpr int py = q >> 1, px = q & 1;
@@ -433,7 +432,6 @@ __global__ __launch_bounds__(NTHR64, 2) void conv64_s2dgrad_kernel(const ConvKAr
         }
       });
     });
-    (void)rstride;
     __syncthreads();
     if (next < tile_end) halo_commit();
     __syncthreads();
