@@ -225,6 +225,48 @@ def test_first_layer_bias_gradient_from_the_weight_gradient_launch(dev, cdn):
     assert relerr(bd._fsr_grad, dz.sum((0, 2, 3))) < tol(cdn, 1e-4, 1e-2)
 
 
+def test_c_abi_rejects_malformed_calls(dev):
+    """Error behaviour of the boundary: a rejected call returns a negative code, leaves a message in fsr_last_error and
+    enqueues nothing (empty / ragged / mis-sized inputs)."""
+    import ctypes
+    lib = L.lib()
+    buf = torch.zeros(1 << 16).to(dev)
+    p = buf.data_ptr()
+
+    def desc(**kw):
+        base = dict(dtype=L.FSR_F32, mode=L.CONV_FWD, n=1, ih=8, iw=8, cin=16, oh=8, ow=8, cout=16, stride=1, act=L.ACT_NONE, slope=0.0,
+                    pixel_shuffle=0, in_pixel_shuffled=0, out_f32=0)
+        base.update(kw)
+        return L.ConvDesc(*[base[k] for k in ("dtype", "mode", "n", "ih", "iw", "cin", "oh", "ow", "cout", "stride", "act", "slope",
+                                              "pixel_shuffle", "in_pixel_shuffled", "out_f32")])
+
+    def conv(d, **kw):
+        a = dict(inp=p, w=p, bias=None, prelu=None, oscale=None, mask=None, out=p, pre=None, stats=None)
+        a.update(kw)
+        return lib.fsr_conv3x3(ctypes.byref(d), a["inp"], a["w"], a["bias"], a["prelu"], a["oscale"], a["mask"], 0.0, a["out"],
+                               a["pre"], a["stats"], None)
+
+    assert conv(desc()) == 0                                        # the well-formed call goes through
+    bad = [desc(n=0), desc(oh=7), desc(cin=12), desc(dtype=7), desc(mode=5), desc(stride=3), desc(act=L.ACT_PRELU),
+           desc(pixel_shuffle=1, cout=18), desc(in_pixel_shuffled=1, cin=18)]
+    for d in bad:
+        assert conv(d) < 0 and len(lib.fsr_last_error()) > 0
+    assert conv(desc(), inp=None) < 0 and conv(desc(), out=None) < 0
+    assert conv(desc(pixel_shuffle=1, cout=64), stats=p) < 0          # statistics + pixel shuffle
+    assert conv(desc(cout=3), stats=p) < 0                            # statistics need cout % 16 == 0
+    # weight gradient: dims must match k=3, p=1
+    wd = L.WgradDesc(L.FSR_F32, 1, 8, 8, 16, 16, 7, 8, 16, 16, 1, 0)
+    assert lib.fsr_conv3x3_wgrad_workspace(ctypes.byref(wd)) == 0
+    assert lib.fsr_conv3x3_wgrad(ctypes.byref(wd), p, p, p, p, None) < 0
+    # elementwise kernels: channel count must be a multiple of the vector width, pointers non-null
+    assert lib.fsr_instnorm_act_fwd(L.FSR_BF16, p, p, None, L.ACT_NONE, 0.0, None, p, 1, 64, 12, None) < 0
+    assert lib.fsr_instnorm_act_fwd(L.FSR_F32, None, p, None, L.ACT_NONE, 0.0, None, p, 1, 64, 16, None) < 0
+    assert lib.fsr_act_bwd(L.FSR_F32, p, None, L.ACT_RELU, 0.0, None, p, None, None, 1, 8, 8, 16, 0, None) < 0
+    assert lib.fsr_maxpool2_fwd(L.FSR_F32, p, p, 1, 7, 8, 16, None) < 0
+    assert lib.fsr_adamw_step(p, p, p, p, 0, 1e-3, 0.9, 0.999, 1e-8, 0.0, p, 1.0, None) < 0
+    assert lib.fsr_pack_conv3x3(L.FSR_F32, 9, p, 16, 16, 16, p, None) < 0
+
+
 def test_first_layer_kernels_reject_bad_arguments(dev):
     cd = ops.Compute("f32")
     lib = L.lib()
