@@ -16,7 +16,7 @@ FSR_F32, FSR_BF16 = 0, 1
 ACT_NONE, ACT_RELU, ACT_LEAKY, ACT_PRELU, ACT_TANH = 0, 1, 2, 3, 4
 CONV_FWD, CONV_DGRAD = 0, 1
 PACK_FWD, PACK_FWD_PS, PACK_DGRAD, PACK_DGRAD_PS = 0, 1, 2, 3
-ABI_VERSION = 5
+ABI_VERSION = 6
 
 c_int, c_float, c_void_p, c_size_t, c_ll = ctypes.c_int, ctypes.c_float, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_longlong
 
@@ -49,13 +49,16 @@ SIGNATURES = {
     "fsr_last_error": (ctypes.c_char_p, []),
     "fsr_device_info": (c_int, [ctypes.c_char_p, c_size_t]),
     "fsr_pack_conv3x3": (c_int, [c_int, c_int, P, c_int, c_int, c_int, P, P]),
-    "fsr_conv3x3": (c_int, [ctypes.POINTER(ConvDesc), P, P, P, P, P, P, c_float, P, P, P, P]),
+    "fsr_conv3x3_scratch": (c_size_t, [ctypes.POINTER(ConvDesc)]),
+    "fsr_conv3x3": (c_int, [ctypes.POINTER(ConvDesc), P, P, P, P, P, P, c_float, P, P, P, P, P]),
     "fsr_conv3x3_wgrad_workspace": (c_size_t, [ctypes.POINTER(WgradDesc)]),
     "fsr_conv3x3_wgrad": (c_int, [ctypes.POINTER(WgradDesc), P, P, P, P, P]),
     "fsr_instnorm_act_fwd": (c_int, [c_int, P, P, P, c_int, c_float, P, P, c_int, c_int, c_int, P]),
-    "fsr_instnorm_act_bwd_reduce": (c_int, [c_int, P, P, P, c_int, c_float, P, P, P, c_int, c_int, c_int, P]),
+    "fsr_instnorm_act_bwd_scratch": (c_size_t, [c_int, c_int, c_int]),
+    "fsr_instnorm_act_bwd_reduce": (c_int, [c_int, P, P, P, c_int, c_float, P, P, P, P, c_int, c_int, c_int, P]),
     "fsr_instnorm_act_bwd_apply": (c_int, [c_int, P, P, P, P, c_int, c_float, P, P, c_int, c_int, c_int, P]),
-    "fsr_act_bwd": (c_int, [c_int, P, P, c_int, c_float, P, P, P, P, c_int, c_int, c_int, c_int, c_int, P]),
+    "fsr_act_bwd_scratch": (c_size_t, [c_int, c_int, c_int, c_int, c_int]),
+    "fsr_act_bwd": (c_int, [c_int, P, P, c_int, c_float, P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, P]),
     "fsr_image_to_nhwc": (c_int, [c_int, P, c_ll, c_ll, c_ll, c_ll, c_int, c_int, c_int, c_float, c_float, c_float,
                                   c_float, c_float, c_float, P, c_int, P]),
     "fsr_pack_conv3x3_c3": (c_int, [c_int, P, c_int, P, P]),
@@ -64,14 +67,17 @@ SIGNATURES = {
     "fsr_conv3x3_c3_wgrad_workspace": (ctypes.c_size_t, [c_int, c_int, c_int, c_int]),
     "fsr_conv3x3_c3_wgrad": (c_int, [c_int, P, c_ll, c_ll, c_ll, c_ll, c_int, c_int, c_int, c_float, c_float, c_float,
                                      c_float, c_float, c_float, P, c_int, P, P, P, P]),
-    "fsr_tanh_bwd_to_nhwc": (c_int, [c_int, P, c_ll, c_ll, c_ll, c_ll, P, c_int, c_int, c_int, P, c_int, P, P]),
+    "fsr_tanh_bwd_scratch": (c_size_t, []),
+    "fsr_tanh_bwd_to_nhwc": (c_int, [c_int, P, c_ll, c_ll, c_ll, c_ll, P, c_int, c_int, c_int, P, c_int, P, P, P]),
     "fsr_maxpool2_fwd": (c_int, [c_int, P, P, c_int, c_int, c_int, c_int, P]),
     "fsr_maxpool2_bwd": (c_int, [c_int, P, P, P, P, c_int, c_int, c_int, c_int, c_int, P]),
     "fsr_conv1x1_c1_fwd": (c_int, [c_int, P, P, P, P, c_int, c_int, P]),
-    "fsr_conv1x1_c1_bwd": (c_int, [c_int, P, P, P, P, P, P, c_int, c_int, P]),
-    "fsr_bce_logits_fwd": (c_int, [P, P, P, c_ll, P]),
+    "fsr_conv1x1_c1_bwd_scratch": (c_size_t, [c_int]),
+    "fsr_conv1x1_c1_bwd": (c_int, [c_int, P, P, P, P, P, P, P, c_int, c_int, P]),
+    "fsr_loss_scratch": (c_size_t, []),
+    "fsr_bce_logits_fwd": (c_int, [P, P, P, P, c_ll, P]),
     "fsr_bce_logits_bwd": (c_int, [P, P, P, P, c_ll, P]),
-    "fsr_smooth_l1_fwd": (c_int, [c_int, P, P, P, c_ll, P]),
+    "fsr_smooth_l1_fwd": (c_int, [c_int, P, P, P, P, c_ll, P]),
     "fsr_smooth_l1_bwd": (c_int, [c_int, P, P, P, P, c_ll, P]),
     "fsr_adamw_step": (c_int, [P, P, P, P, c_ll, c_float, c_float, c_float, c_float, c_float, P, c_float, P]),
     "fsr_crop_resize": (c_int, [P, P, P, P, P, c_int, c_int, c_int, P, P, P, c_int, P, P, P, P]),

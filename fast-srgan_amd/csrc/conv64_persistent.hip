@@ -29,7 +29,8 @@ constexpr int HT = 18;           // halo extent of a 16x16 tile, 3x3 footprint
 constexpr int NTHR64 = 512;
 constexpr int W_BYTES = 9 * 64 * P64 * 2;
 constexpr int H_BYTES = HT * HT * P64 * 2;
-constexpr int LDS64 = W_BYTES + H_BYTES + 128 * 4;
+constexpr int SRED_BYTES = 8 * 128 * 4;   // per-wave InstanceNorm partial sums
+constexpr int LDS64 = W_BYTES + H_BYTES + SRED_BYTES;
 
 __device__ __forceinline__ unsigned tap64(const ConvKArgs& a, int t) {
   return (t < 8) ? (unsigned)((a.taps_lo >> (8 * t)) & 0xffull) : a.taps_hi;
@@ -49,7 +50,7 @@ __global__ __launch_bounds__(NTHR64, 2) void conv64_persistent_kernel(const Conv
   T* wl = (T*)smem;
   constexpr int WB = 9 * NT * 16 * P64 * 2;            // bytes of the resident filter block
   T* halo = (T*)(smem + WB);
-  float* sred = (float*)(smem + WB + H_BYTES);          // [64][2]
+  float* sred = (float*)(smem + WB + H_BYTES);          // [8 waves][64][2] statistics of the tiles walked so far in this image
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int l15 = lane & 15, lg = lane >> 4;
@@ -74,7 +75,6 @@ __global__ __launch_bounds__(NTHR64, 2) void conv64_persistent_kernel(const Conv
         *(u32x4*)(wl + (u >> 3) * P64 + (u & 7) * 8) = v;
       }
     }
-    if (tid < 128) sred[tid] = 0.f;
   }
 
   u32x4 hreg[HPT];
@@ -134,7 +134,9 @@ __global__ __launch_bounds__(NTHR64, 2) void conv64_persistent_kernel(const Conv
   }
 
   // a workgroup walks a CONTIGUOUS range of tiles (mostly one image): InstanceNorm statistics stay in registers
-  // across tiles and are flushed (lane shuffle -> LDS -> 128 global atomics) only when the image changes
+  // across tiles and are flushed (lane shuffle -> per-wave LDS slot -> the eight waves added in order -> this workgroup's
+  // slot of the image's partial buffer, plain stores) only when the image changes.  No atomics: reduce.hip adds an
+  // image's slots in order, so the statistics are bit-reproducible.
   const int tile_begin = ((int)blockIdx.x / nblk) * a.nblk_n;   // nblk_n = tiles per workgroup (set by the host)
   const int tile_end = (tile_begin + a.nblk_n < ntiles) ? tile_begin + a.nblk_n : ntiles;
   f32x4 oscale = (f32x4){1.f, 1.f, 1.f, 1.f};     // THIN: optional per-channel scale (VGG normalisation in the image gradient)
@@ -265,8 +267,8 @@ __global__ __launch_bounds__(NTHR64, 2) void conv64_persistent_kernel(const Conv
           }
           if (l15 == 0) {
             const int cl = n * 16 + lg * 4 + r;
-            atomicAdd(sred + 2 * cl, x1);
-            atomicAdd(sred + 2 * cl + 1, x2);
+            sred[(wave * 64 + cl) * 2] = x1;
+            sred[(wave * 64 + cl) * 2 + 1] = x2;
           }
         }
         s1acc[n] = s2acc[n] = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -274,8 +276,12 @@ __global__ __launch_bounds__(NTHR64, 2) void conv64_persistent_kernel(const Conv
     });
     __syncthreads();   // every wave is done with the halo (and with its statistics contributions)
     if (flush && tid < 128) {
-      atomicAdd(a.stats + ((size_t)img * a.Cout + nb * 64 + (tid >> 1)) * 2 + (tid & 1), sred[tid]);
-      sred[tid] = 0.f;
+      float s = sred[tid];
+#pragma unroll
+      for (int w = 1; w < 8; ++w) s += sred[w * 128 + tid];
+      // slot of this tile range among the ranges that intersect the image (fsr_launch_reduce_partials knows the rule)
+      const int slot = (int)blockIdx.x / nblk - (img * tiles_per_img) / a.nblk_n;
+      a.stats[(((size_t)img * a.stats_P + slot) * a.Cout + nb * 64 + (tid >> 1)) * 2 + (tid & 1)] = s;
     }
     if (next < tile_end) halo_commit();
     __syncthreads();
@@ -440,6 +446,23 @@ __global__ __launch_bounds__(NTHR64, 2) void conv64_s2dgrad_kernel(const ConvKAr
 
 }  // namespace
 
+// Workgroup slots of the persistent kernels: one per CU.  FSR_PERSIST_CUS overrides the device's CU count (tests: lets a
+// small problem exercise tile ranges that straddle image borders on any device).
+static int persistent_slots() {
+  if (const char* e = getenv("FSR_PERSIST_CUS")) {
+    const int v = atoi(e);
+    if (v > 0) return v;
+  }
+  static int cus = 0;
+  if (cus == 0) {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    cus = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
+              ? prop.multiProcessorCount : 256;
+  }
+  return cus;
+}
+
 // Stride-2 data gradient, 64 -> 64 channels: 1 = launched, 0 = not this kernel's shape, < 0 = error.
 // `a`: in = dz [N, IH, IW, 64], out = dx [N, FOH, FOW, 64], wpk = the [9][64][64] data-gradient pack.
 int fsr_conv64_s2dgrad_try(int dtype, ConvKArgs& a, hipStream_t stream) {
@@ -456,13 +479,7 @@ int fsr_conv64_s2dgrad_try(int dtype, ConvKArgs& a, hipStream_t stream) {
     (void)hipFuncSetAttribute((const void*)conv64_s2dgrad_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS64);
     attr_set = true;
   }
-  static int cus = 0;
-  if (cus == 0) {
-    int dev = 0;
-    hipDeviceProp_t prop;
-    cus = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
-              ? prop.multiProcessorCount : 256;
-  }
+  const int cus = persistent_slots();
   const int per = (int)((ntiles + cus - 1) / cus);
   a.nblk_n = per;
   const int grid = (int)((ntiles + per - 1) / per);
@@ -503,20 +520,18 @@ int fsr_conv64_persistent_try(int dtype, ConvKArgs& a, int S, hipStream_t stream
     (void)hipFuncSetAttribute((const void*)conv64_persistent_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS64);
     attr_set = true;
   }
-  static int cus = 0;    // one persistent workgroup per CU (LDS admits exactly one)
-  if (cus == 0) {
-    int dev = 0;
-    hipDeviceProp_t prop;
-    cus = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
-              ? prop.multiProcessorCount : 256;
-  }
+  const int cus = persistent_slots();    // one persistent workgroup per CU (LDS admits exactly one)
   const int nblk = thin ? 1 : a.Cout / 64;                   // channel blocks: workgroup w -> block w % nblk
   int slots = thin ? 2 * cus : cus / nblk;                   // tile ranges (the thin kernel's LDS admits two workgroups per CU)
   if (slots < 1) slots = 1;
   const int per = (int)((ntiles + slots - 1) / slots);      // contiguous tiles per workgroup
   a.nblk_n = per;
+  // statistics: one partial slot per tile range that intersects an image
+  a.stats_tpi = a.tiles_x * a.tiles_y;
+  a.stats_per = per;
+  a.stats_P = (a.stats_tpi + per - 1) / per + 1;
   const int grid = (int)((ntiles + per - 1) / per) * nblk;
-  if (thin) hipLaunchKernelGGL(conv64_persistent_kernel<1>, dim3(grid), dim3(NTHR64), 9 * 16 * P64 * 2 + H_BYTES + 128 * 4, stream, a);
+  if (thin) hipLaunchKernelGGL(conv64_persistent_kernel<1>, dim3(grid), dim3(NTHR64), 9 * 16 * P64 * 2 + H_BYTES + 16, stream, a);
   else hipLaunchKernelGGL(conv64_persistent_kernel<4>, dim3(grid), dim3(NTHR64), LDS64, stream, a);
   int rc = fsr_check_launch("conv64_persistent_kernel");
   return rc ? rc : 1;

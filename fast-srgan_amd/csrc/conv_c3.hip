@@ -333,22 +333,36 @@ __global__ __launch_bounds__(256) void conv_c3_wgrad_kernel(const C3Args a) {
   }
 }
 
-// dw[co][ci][ky][kx] += sum_slab ws[slab][co][k], k = (ky*3+kx)*3 + ci
-// blockIdx.y = a group of slabs; each group adds its share with one float atomic per element
+// dw[co][ci][ky][kx] += sum_slab ws[slab][co][k], k = (ky*3+kx)*3 + ci;  k == 27: the bias gradient.
+// Block = 32 consecutive k of one output channel x 8 slab lanes: lane j adds slabs j, j+8, ... in order, the eight lane
+// sums are added in order and one thread adds the result (no atomics: bit-reproducible).
 __global__ __launch_bounds__(256) void conv_c3_wgrad_reduce_kernel(const float* __restrict__ ws, float* __restrict__ dw, int nslab,
-                                                                   int cout, int slabs_per_group, float* __restrict__ dbias) {
+                                                                   int cout, float* __restrict__ dbias) {
+  __shared__ float red[8][32];
   const int total = cout * 32;
-  const int j0 = blockIdx.y * slabs_per_group;
-  const int j1 = (j0 + slabs_per_group < nslab) ? j0 + slabs_per_group : nslab;
-  for (int i = blockIdx.x * 256 + threadIdx.x; i < total; i += gridDim.x * 256) {
-    const int k = i & 31, co = i >> 5;
-    if (k > 27 || (k == 27 && !dbias)) continue;
-    float s = 0.f;
-    for (int j = j0; j < j1; ++j) s += ws[(size_t)j * total + i];
+  const int k = threadIdx.x & 31, pl = threadIdx.x >> 5;
+  const int co = blockIdx.x;
+  const int i = co * 32 + k;
+  float s = 0.f;
+  const bool live = k < 27 || (k == 27 && dbias);
+  if (live) {
+    int j = pl;
+    for (; j + 24 < nslab; j += 32) {
+      const float v0 = ws[(size_t)j * total + i], v1 = ws[(size_t)(j + 8) * total + i];
+      const float v2 = ws[(size_t)(j + 16) * total + i], v3 = ws[(size_t)(j + 24) * total + i];
+      s = ((s + v0) + v1) + v2 + v3;
+    }
+    for (; j < nslab; j += 8) s += ws[(size_t)j * total + i];
+  }
+  red[pl][k] = s;
+  __syncthreads();
+  if (pl == 0 && live) {
+    float r = red[0][k];
+#pragma unroll
+    for (int j = 1; j < 8; ++j) r += red[j][k];
     const int tap = k / 3, ci = k - tap * 3;
     float* o = (k == 27) ? dbias + co : dw + ((size_t)co * 3 + ci) * 9 + tap;
-    if (gridDim.y == 1) *o += s;
-    else atomicAdd(o, s);
+    *o += r;
   }
 }
 
@@ -458,8 +472,7 @@ extern "C" int fsr_conv3x3_c3_wgrad(int dtype, const float* img, long long sn, l
   if (dtype == FSR_BF16) hipLaunchKernelGGL(conv_c3_wgrad_kernel<bf16_t>, grid, dim3(256), 0, (hipStream_t)stream_, a);
   else hipLaunchKernelGGL(conv_c3_wgrad_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream_, a);
   if (int rc = fsr_check_launch("conv_c3_wgrad_kernel")) return rc;
-  const int per_group = nslab > 64 ? 16 : nslab;
-  hipLaunchKernelGGL(conv_c3_wgrad_reduce_kernel, dim3((cout * 32 + 255) / 256, (nslab + per_group - 1) / per_group), dim3(256), 0,
-                     (hipStream_t)stream_, (const float*)workspace, dw_oihw, nslab, cout, per_group, dbias);
+  hipLaunchKernelGGL(conv_c3_wgrad_reduce_kernel, dim3(cout), dim3(256), 0, (hipStream_t)stream_, (const float*)workspace,
+                     dw_oihw, nslab, cout, dbias);
   return fsr_check_launch("conv_c3_wgrad_reduce_kernel");
 }

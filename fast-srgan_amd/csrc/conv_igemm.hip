@@ -401,11 +401,9 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv_igemm_kernel(const ConvK
   float slope = (a.act == FSR_ACT_PRELU) ? a.prelu[0] : a.slope;
   if (a.act == FSR_ACT_NONE || a.act == FSR_ACT_TANH) slope = 1.f;
   if (a.act == FSR_ACT_RELU) slope = 0.f;
-  float* sred = (float*)smem;  // [BN][2] statistics of this workgroup (reuses the halo image)
-  if (a.stats) {               // the main loop ended on a barrier: every wave is done with LDS
-    for (int i = tid; i < 2 * BN; i += NTHR) sred[i] = 0.f;
-    __syncthreads();
-  }
+  // [WM][BN][2] statistics of this workgroup's pixel-row groups (reuses the halo image: the main loop ended on a barrier,
+  // every wave is done with LDS).  Every slot is written exactly once, by the wave (wm, wn) that owns it.
+  float* sred = (float*)smem;
   const int gx = gx0 + l15;
   const int gyb = gy0 + wm * MT;            // first grid row of this wave
   const int cob = nb * BN + wn * NT * 16 + lg * 4;  // first of this lane's channels (tile n adds 16 n)
@@ -510,9 +508,9 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv_igemm_kernel(const ConvK
       }
     });
     if (want_stats) {
-      // per-(image, channel) partial sums: xor-reduce the 16 pixel lanes of each lane group, meet the
-      // other waves of the workgroup in LDS (the halo image is dead by now), one global atomic per
-      // (workgroup, channel, quantity) below.
+      // per-(image, channel) partial sums: xor-reduce the 16 pixel lanes of each lane group (a fixed butterfly), park the
+      // wave's sums in its own LDS slot; the WM row groups are added in order below and the workgroup's vector goes to
+      // its slot of the partial buffer (no atomics: the sums are bit-reproducible, reduce.hip adds the slots in order).
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         float x1 = s1[r], x2 = s2[r];
@@ -523,17 +521,21 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv_igemm_kernel(const ConvK
         }
         if (l15 == 0) {
           const int cl = (wn * NT + n) * 16 + lg * 4 + r;
-          atomicAdd(sred + 2 * cl, x1);
-          atomicAdd(sred + 2 * cl + 1, x2);
+          sred[(wm * BN + cl) * 2] = x1;
+          sred[(wm * BN + cl) * 2 + 1] = x2;
         }
       }
     }
   });
   if (a.stats) {
     __syncthreads();
+    const int slot = ty * a.tiles_x + tx;
     for (int i = tid; i < 2 * BN; i += NTHR) {
+      float s = sred[i];
+#pragma unroll
+      for (int w = 1; w < WM; ++w) s += sred[w * 2 * BN + i];
       const int co = nb * BN + (i >> 1);
-      if (co < a.Cout) atomicAdd(a.stats + ((size_t)img * a.Cout + co) * 2 + (i & 1), sred[i]);
+      if (co < a.Cout) a.stats[(((size_t)img * a.stats_P + slot) * a.Cout + co) * 2 + (i & 1)] = s;
     }
   }
 }
@@ -570,6 +572,7 @@ static int launch_cfg(ConvKArgs& a, hipStream_t stream, ConvKArgs* more = nullpt
   if ((long long)a.N * a.IH * a.IW * a.Cin >= (1LL << 31) || (long long)a.N * a.FOH * a.FOW * a.Cout >= (1LL << 31))
     return fsr_fail(-2, "conv3x3: tensors with 2^31 or more elements are not supported");
   if (G == 3 && (a.ntaps % 3 != 0 || nmore > 0)) return fsr_fail(-2, "conv3x3: three-tap stages need a multiple of 3 taps");
+  if (a.stats && nmore > 0) return fsr_fail(-2, "conv3x3: statistics are not available for multi-class launches");
   ConvKClasses cls = {};
   long long nwg = 0;
   for (int k = 0; k <= nmore; ++k) {
@@ -586,6 +589,8 @@ static int launch_cfg(ConvKArgs& a, hipStream_t stream, ConvKArgs* more = nullpt
     c.wg_end = (int)nwg;
   }
   cls.n = nmore + 1;
+  a.stats_P = a.tiles_x * a.tiles_y;   // one partial slot per tile of an image (one-tile workgroups)
+  a.stats_tpi = a.stats_per = 0;
   const size_t lds = ((size_t)a.HH * a.HW * PITCHX + (DMA ? 2 * G * (size_t)BN * KC : (G == 1 ? 2 : G) * (size_t)BN * PITCHW)) * sizeof(T);
   auto kern = conv_igemm_kernel<T, TH, BN, WM, WN, KC, S, G, DMA>;
   static bool attr_set = false;

@@ -225,35 +225,42 @@ __global__ __launch_bounds__((BM == 64 && BN == 64) ? 512 : 256) void conv_wgrad
 }
 
 // dw[co][ci][tap] += sum_slab ws[slab][tap][row(co)][ci]; row(co) undoes the pixel-shuffle row order.
-// Thread = one (tap, co, ci) element (coalesced along ci); blockIdx.y = a group of slabs.  With one group the
-// result is added with a plain read-modify-write, with several groups (small filters, hundreds of slabs) each
-// group adds its share with one float atomic per element.
+// Block = 32 consecutive (tap, co, ci) elements (coalesced along ci) x 8 slab lanes: lane j adds slabs j, j+8, ... in
+// order, the eight lane sums are added in order and ONE thread adds the result to dw -- no atomics, so the weight
+// gradient is bit-reproducible (the split-K partials themselves are plain stores of the weight-gradient kernel).
 __global__ __launch_bounds__(256) void conv_wgrad_reduce_kernel(const float* __restrict__ ws, float* __restrict__ dw, int nslab,
-                                                                int cout, int cin, int cout_pad, int cin_pad, int ps,
-                                                                int slabs_per_group) {
+                                                                int cout, int cin, int cout_pad, int cin_pad, int ps) {
+  __shared__ float red[8][32];
   const int total = 9 * cout * cin;
   const size_t sstride = (size_t)9 * cout_pad * cin_pad;
-  const int k0 = blockIdx.y * slabs_per_group;
-  const int k1 = (k0 + slabs_per_group < nslab) ? k0 + slabs_per_group : nslab;
-  for (int i = blockIdx.x * 256 + threadIdx.x; i < total; i += gridDim.x * 256) {
-    const int ci = i % cin;
-    const int co = (i / cin) % cout;
-    const int t = i / (cin * cout);
-    const int row = ps ? (co & 3) * (cout_pad >> 2) + (co >> 2) : co;
-    const float* p = ws + ((size_t)t * cout_pad + row) * cin_pad + ci;
-    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-    int k = k0;
-    for (; k + 4 <= k1; k += 4) {   // four independent loads in flight per lane
-      s0 += p[(size_t)k * sstride];
-      s1 += p[(size_t)(k + 1) * sstride];
-      s2 += p[(size_t)(k + 2) * sstride];
-      s3 += p[(size_t)(k + 3) * sstride];
+  const int oi = threadIdx.x & 31, pl = threadIdx.x >> 5;
+  for (int i0 = blockIdx.x * 32; i0 < total; i0 += gridDim.x * 32) {
+    const int i = i0 + oi;
+    float s = 0.f;
+    int co = 0, ci = 0, t = 0;
+    if (i < total) {
+      ci = i % cin;
+      co = (i / cin) % cout;
+      t = i / (cin * cout);
+      const int row = ps ? (co & 3) * (cout_pad >> 2) + (co >> 2) : co;
+      const float* p = ws + ((size_t)t * cout_pad + row) * cin_pad + ci;
+      int k = pl;
+      for (; k + 24 < nslab; k += 32) {   // four independent loads in flight per lane, added in order
+        const float v0 = p[(size_t)k * sstride], v1 = p[(size_t)(k + 8) * sstride];
+        const float v2 = p[(size_t)(k + 16) * sstride], v3 = p[(size_t)(k + 24) * sstride];
+        s = ((s + v0) + v1) + v2 + v3;
+      }
+      for (; k < nslab; k += 8) s += p[(size_t)k * sstride];
     }
-    for (; k < k1; ++k) s0 += p[(size_t)k * sstride];
-    const float s = (s0 + s1) + (s2 + s3);
-    float* o = dw + ((size_t)co * cin + ci) * 9 + t;
-    if (gridDim.y == 1) *o += s;
-    else atomicAdd(o, s);
+    red[pl][oi] = s;
+    __syncthreads();
+    if (pl == 0 && i < total) {
+      float r = red[0][oi];
+#pragma unroll
+      for (int j = 1; j < 8; ++j) r += red[j][oi];
+      dw[((size_t)co * cin + ci) * 9 + t] += r;
+    }
+    __syncthreads();
   }
 }
 
@@ -369,14 +376,9 @@ extern "C" int fsr_conv3x3_wgrad(const fsr_wgrad_desc* d, const void* x, const v
   int rc = d->dtype == FSR_BF16 ? dispatch_wgrad<bf16_t, 8>(p, a, stream) : dispatch_wgrad<float, 4>(p, a, stream);
   if (rc) return rc;
   const int total = 9 * d->cout * d->cin;
-  int blocks = (total + 255) / 256;
-  if (blocks > 2048) blocks = 2048;
-  int groups = p.nslab / 16;   // >= 16 slabs per group; big filters (few slabs) use one group and no atomics
-  if (groups < 1) groups = 1;
-  if (groups > 16) groups = 16;
-  const int spg = (p.nslab + groups - 1) / groups;
-  groups = (p.nslab + spg - 1) / spg;
-  hipLaunchKernelGGL(conv_wgrad_reduce_kernel, dim3(blocks, groups), dim3(256), 0, stream, (const float*)workspace, dw_oihw,
-                     p.nslab, d->cout, d->cin, d->cout_pad, d->cin_pad, d->dy_pixel_shuffled, spg);
+  int blocks = (total + 31) / 32;
+  if (blocks > 8192) blocks = 8192;
+  hipLaunchKernelGGL(conv_wgrad_reduce_kernel, dim3(blocks), dim3(256), 0, stream, (const float*)workspace, dw_oihw,
+                     p.nslab, d->cout, d->cin, d->cout_pad, d->cin_pad, d->dy_pixel_shuffled);
   return fsr_check_launch("conv_wgrad_reduce_kernel");
 }

@@ -105,8 +105,9 @@ __global__ __launch_bounds__(256) void instnorm_act_fwd_kernel(const T* __restri
 }
 
 // Backward phase 1.  Workgroup = one image x a slab of pixels x all channels: thread t owns channel
-// unit t % cu and walks pixels t / cu, t / cu + 256 / cu, ...; partial sums meet in LDS, then one
-// atomic per (workgroup, channel, quantity).
+// unit t % cu and walks pixels t / cu, t / cu + 256 / cu, ...; partial sums meet in LDS (added in a fixed
+// order) and the workgroup's vector goes to its slot [n][slab][c][2] of the scratch buffer (reduce.hip adds the
+// slabs in order); the PReLU-slope partial goes to pp[n * slabs + slab].
 template <typename T>
 __global__ __launch_bounds__(256) void instnorm_act_bwd_reduce_kernel(const T* __restrict__ g, const T* __restrict__ x,
                                                                       const float* __restrict__ stats, int act,
@@ -166,9 +167,9 @@ __global__ __launch_bounds__(256) void instnorm_act_bwd_reduce_kernel(const T* _
     const int q = t / cu, un = t % cu;
     float s = 0.f;
     for (int r = 0; r < rows; ++r) s += red[q * 256 + r * cu + un];
-    atomicAdd(sums + ((size_t)n * c + un * E + (q >> 1)) * 2 + (q & 1), s);
+    sums[((size_t)blockIdx.x * c + un * E + (q >> 1)) * 2 + (q & 1)] = s;
   }
-  if (dprelu && tid == 0) atomicAdd(dprelu, red_p[0] + red_p[1] + red_p[2] + red_p[3]);
+  if (dprelu && tid == 0) dprelu[blockIdx.x] = red_p[0] + red_p[1] + red_p[2] + red_p[3];
 }
 
 template <typename T>
@@ -273,16 +274,18 @@ __global__ __launch_bounds__(256) void act_bwd_kernel(const T* __restrict__ g, c
     for (int i = 0; i < E; ++i) red[i * 256 + tid] = s1[i];
   }
   __syncthreads();
+  // one partial vector per (image, slab) in the scratch buffer: [n * slabs][nclass * c] bias sums, [n * slabs * nclass]
+  // slope sums; reduce.hip adds them in order
   if (dbias) {
     for (int t = tid; t < cu * E; t += 256) {
       const int q = t / cu, un = t % cu;
       float s = 0.f;
       for (int r = 0; r < rows; ++r) s += red[q * 256 + r * cu + un];
       const int chn = un * E + q;
-      atomicAdd(dbias + (ps ? 4 * chn + cls : chn), s);
+      dbias[(size_t)(n * slabs + slab) * (nclass * c) + (ps ? 4 * chn + cls : chn)] = s;
     }
   }
-  if (dprelu && tid == 0) atomicAdd(dprelu, red_p[0] + red_p[1] + red_p[2] + red_p[3]);
+  if (dprelu && tid == 0) dprelu[blockIdx.x] = red_p[0] + red_p[1] + red_p[2] + red_p[3];
 }
 
 // ------------------------------------------------------------------ 3-channel images <-> padded NHWC
@@ -357,7 +360,8 @@ __global__ __launch_bounds__(256) void tanh_bwd_to_nhwc_kernel(const float* __re
       red[2][threadIdx.x >> 6] = b2;
     }
     __syncthreads();
-    if (threadIdx.x < 3) atomicAdd(dbias + threadIdx.x, red[threadIdx.x][0] + red[threadIdx.x][1] + red[threadIdx.x][2] + red[threadIdx.x][3]);
+    if (threadIdx.x < 3)   // this workgroup's slot of the scratch buffer (reduce.hip adds the slots in order)
+      dbias[(blockIdx.y * gridDim.x + blockIdx.x) * 3 + threadIdx.x] = red[threadIdx.x][0] + red[threadIdx.x][1] + red[threadIdx.x][2] + red[threadIdx.x][3];
   }
 }
 
@@ -471,17 +475,28 @@ extern "C" int fsr_instnorm_act_fwd(int dtype, const void* x, const float* stats
   return fsr_check_launch("instnorm_act_fwd_kernel");
 }
 
+extern "C" size_t fsr_instnorm_act_bwd_scratch(int n, int hw, int c) {
+  if (n <= 0 || hw <= 0 || c <= 0) return 0;
+  return (size_t)n * slabs_for(n, hw) * ((size_t)c * 2 + 1) * sizeof(float);
+}
+
 extern "C" int fsr_instnorm_act_bwd_reduce(int dtype, const void* g, const void* x, const float* stats, int act,
-                                           float slope, const float* prelu_weight, float* sums, float* dprelu, int n,
-                                           int hw, int c, fsr_stream_t stream_) {
+                                           float slope, const float* prelu_weight, float* sums, float* dprelu, void* scratch,
+                                           int n, int hw, int c, fsr_stream_t stream_) {
   hipStream_t stream = (hipStream_t)stream_;
-  if (!g || !x || !stats || !sums) return fsr_fail(-1, "fsr_instnorm_act_bwd_reduce: null argument");
+  if (!g || !x || !stats || !sums || !scratch) return fsr_fail(-1, "fsr_instnorm_act_bwd_reduce: null argument");
   if (act == FSR_ACT_PRELU && !prelu_weight) return fsr_fail(-1, "fsr_instnorm_act_bwd_reduce: PReLU needs its weight");
   if (int rc = check_reduce_c("fsr_instnorm_act_bwd_reduce", dtype, c)) return rc;
   const int slabs = slabs_for(n, hw);
+  float* part = (float*)scratch;                         // [n][slabs][c][2]
+  float* part_p = part + (size_t)n * slabs * c * 2;      // [n * slabs]
   FSR_DISPATCH_T(dtype, hipLaunchKernelGGL(instnorm_act_bwd_reduce_kernel<T>, dim3(n * slabs), dim3(256), 0, stream,
-                                           P<T>(g), P<T>(x), stats, act, slope, prelu_weight, sums, dprelu, hw, c, slabs);)
-  return fsr_check_launch("instnorm_act_bwd_reduce_kernel");
+                                           P<T>(g), P<T>(x), stats, act, slope, prelu_weight, part, dprelu ? part_p : nullptr,
+                                           hw, c, slabs);)
+  if (int rc = fsr_check_launch("instnorm_act_bwd_reduce_kernel")) return rc;
+  if (int rc = fsr_launch_reduce_partials(part, sums, n, slabs, c * 2, c * 2, 0, 0, 1.f, 0, stream)) return rc;
+  if (dprelu) return fsr_launch_reduce_partials(part_p, dprelu, 1, n * slabs, 1, 1, 0, 0, 1.f, 0, stream);
+  return 0;
 }
 
 extern "C" int fsr_instnorm_act_bwd_apply(int dtype, const void* g, const void* x, const float* stats, const float* sums,
@@ -498,11 +513,19 @@ extern "C" int fsr_instnorm_act_bwd_apply(int dtype, const void* g, const void* 
   return fsr_check_launch("instnorm_act_bwd_apply_kernel");
 }
 
+extern "C" size_t fsr_act_bwd_scratch(int n, int h, int w, int c, int pixel_shuffled) {
+  if (n <= 0 || h <= 0 || w <= 0 || c <= 0) return 0;
+  const int nclass = pixel_shuffled ? 4 : 1;
+  const size_t rows = (size_t)n * slabs_for(n * nclass, h * w / nclass);
+  return rows * ((size_t)nclass * c + nclass) * sizeof(float);
+}
+
 extern "C" int fsr_act_bwd(int dtype, const void* g, const void* saved, int act, float slope, const float* prelu_weight,
-                           void* dz, float* dbias, float* dprelu, int n, int h, int w, int c, int pixel_shuffled,
-                           fsr_stream_t stream_) {
+                           void* dz, float* dbias, float* dprelu, void* scratch, int n, int h, int w, int c,
+                           int pixel_shuffled, fsr_stream_t stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   if (!g) return fsr_fail(-1, "fsr_act_bwd: null argument");
+  if ((dbias || dprelu) && !scratch) return fsr_fail(-1, "fsr_act_bwd: reductions need the scratch buffer");
   if (!dz && !dbias && !dprelu) return fsr_fail(-1, "fsr_act_bwd: nothing to compute");
   if (act != FSR_ACT_NONE && !saved) return fsr_fail(-1, "fsr_act_bwd: the activation needs the saved tensor");
   if (act == FSR_ACT_PRELU && !prelu_weight) return fsr_fail(-1, "fsr_act_bwd: PReLU needs its weight");
@@ -512,10 +535,17 @@ extern "C" int fsr_act_bwd(int dtype, const void* g, const void* saved, int act,
   if (!saved) saved = g;  // FSR_ACT_NONE: only the bias gradient is wanted; act_dz ignores the value
   const int nclass = pixel_shuffled ? 4 : 1;
   const int slabs = slabs_for(n * nclass, h * w / nclass);
+  const int rows = n * slabs;
+  float* part_b = (float*)scratch;                                   // [rows][nclass * c]
+  float* part_p = part_b + (size_t)rows * nclass * c;                // [rows * nclass]
   FSR_DISPATCH_T(dtype, hipLaunchKernelGGL(act_bwd_kernel<T>, dim3(n * slabs * nclass), dim3(256), 0, stream, P<T>(g),
-                                           P<T>(saved), act, slope, prelu_weight, P<T>(dz), dbias, dprelu, h, w, c,
-                                           pixel_shuffled, slabs);)
-  return fsr_check_launch("act_bwd_kernel");
+                                           P<T>(saved), act, slope, prelu_weight, P<T>(dz), dbias ? part_b : nullptr,
+                                           dprelu ? part_p : nullptr, h, w, c, pixel_shuffled, slabs);)
+  if (int rc = fsr_check_launch("act_bwd_kernel")) return rc;
+  if (dbias)
+    if (int rc = fsr_launch_reduce_partials(part_b, dbias, 1, rows, nclass * c, nclass * c, 0, 0, 1.f, 0, stream)) return rc;
+  if (dprelu) return fsr_launch_reduce_partials(part_p, dprelu, 1, rows * nclass, 1, 1, 0, 0, 1.f, 0, stream);
+  return 0;
 }
 
 extern "C" int fsr_image_to_nhwc(int dtype, const float* img, long long sn, long long sc, long long sh, long long sw,
@@ -531,16 +561,23 @@ extern "C" int fsr_image_to_nhwc(int dtype, const float* img, long long sn, long
   return fsr_check_launch("image_to_nhwc_kernel");
 }
 
+extern "C" size_t fsr_tanh_bwd_scratch(void) { return (size_t)512 * 64 * 3 * sizeof(float); }
+
 extern "C" int fsr_tanh_bwd_to_nhwc(int dtype, const float* g, long long sn, long long sc, long long sh, long long sw,
                                     const float* y_nhwc3, int n, int h, int w, void* dz, int cpad, float* dbias,
-                                    fsr_stream_t stream_) {
+                                    void* scratch, fsr_stream_t stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   if (!g || !y_nhwc3 || !dz) return fsr_fail(-1, "fsr_tanh_bwd_to_nhwc: null argument");
+  if (dbias && !scratch) return fsr_fail(-1, "fsr_tanh_bwd_to_nhwc: the bias gradient needs the scratch buffer");
   if (int rc = check_c("fsr_tanh_bwd_to_nhwc", dtype, cpad)) return rc;
   const int rowunits = w * (cpad / (dtype == FSR_BF16 ? 8 : 4));
-  FSR_DISPATCH_T(dtype, hipLaunchKernelGGL(tanh_bwd_to_nhwc_kernel<T>, dim3(n * h < 512 ? n * h : 512, row_blocks(rowunits)), dim3(256), 0,
-                                           stream, g, sn, sc, sh, sw, y_nhwc3, h, w, P<T>(dz), cpad, n * h, dbias);)
-  return fsr_check_launch("tanh_bwd_to_nhwc_kernel");
+  const int gx = n * h < 512 ? n * h : 512, gy = row_blocks(rowunits);   // <= 512 x 64 workgroups
+  FSR_DISPATCH_T(dtype, hipLaunchKernelGGL(tanh_bwd_to_nhwc_kernel<T>, dim3(gx, gy), dim3(256), 0,
+                                           stream, g, sn, sc, sh, sw, y_nhwc3, h, w, P<T>(dz), cpad, n * h,
+                                           dbias ? (float*)scratch : nullptr);)
+  if (int rc = fsr_check_launch("tanh_bwd_to_nhwc_kernel")) return rc;
+  if (dbias) return fsr_launch_reduce_partials((const float*)scratch, dbias, 1, gx * gy, 3, 3, 0, 0, 1.f, 0, stream);
+  return 0;
 }
 
 extern "C" int fsr_maxpool2_fwd(int dtype, const void* x, void* y, int n, int h, int w, int c, fsr_stream_t stream_) {

@@ -36,11 +36,26 @@ extern "C" int fsr_device_info(char* buf, size_t buflen) {
   return 0;
 }
 
+// Upper bound of the partial slots per image over every kernel configuration the dispatch may pick: one slot per
+// 8x16-pixel tile (the smallest tile), plus one (tile ranges of the persistent kernels straddle image borders).
+static size_t stats_slots_bound(const fsr_conv_desc* d) {
+  const int gh = d->mode == FSR_CONV_FWD ? d->oh : d->oh, gw = d->ow;
+  return (size_t)((gh + 7) / 8) * ((gw + 15) / 16) + 1;
+}
+
+extern "C" size_t fsr_conv3x3_scratch(const fsr_conv_desc* d) {
+  if (!d || d->n <= 0 || d->oh <= 0 || d->ow <= 0 || d->cout <= 0) return 0;
+  return (size_t)d->n * stats_slots_bound(d) * d->cout * 2 * sizeof(float);
+}
+
+static int conv3x3_enqueue(const fsr_conv_desc* d, ConvKArgs& a, hipStream_t stream);
+
 extern "C" int fsr_conv3x3(const fsr_conv_desc* d, const void* in, const void* packed_w, const float* bias,
                            const float* prelu_weight, const float* oscale, const void* dact_mask, float dact_slope,
-                           void* out, void* preact, float* stats, fsr_stream_t stream_) {
+                           void* out, void* preact, float* stats, void* scratch, fsr_stream_t stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   if (!d || !in || !packed_w || !out) return fsr_fail(-1, "fsr_conv3x3: null argument");
+  if (stats && !scratch) return fsr_fail(-1, "fsr_conv3x3: statistics need the scratch buffer (fsr_conv3x3_scratch bytes)");
   if (d->stride != 1 && d->stride != 2) return fsr_fail(-2, "fsr_conv3x3: stride must be 1 or 2");
   if (d->act == FSR_ACT_PRELU && !prelu_weight) return fsr_fail(-1, "fsr_conv3x3: PReLU needs its weight");
   if (d->n <= 0 || d->ih <= 0 || d->iw <= 0 || d->oh <= 0 || d->ow <= 0) return fsr_fail(-2, "fsr_conv3x3: bad dims");
@@ -56,7 +71,7 @@ extern "C" int fsr_conv3x3(const fsr_conv_desc* d, const void* in, const void* p
   a.oscale = oscale;
   a.dmask = dact_mask;
   a.dmask_slope = dact_slope;
-  a.stats = stats;
+  a.stats = stats ? (float*)scratch : nullptr;   // the kernels write per-workgroup partials; finished below
   a.N = d->n;
   a.IH = d->ih;
   a.IW = d->iw;
@@ -75,7 +90,19 @@ extern "C" int fsr_conv3x3(const fsr_conv_desc* d, const void* in, const void* p
     return fsr_fail(-2, "fsr_conv3x3: statistics / pre-activation / mask tensors need cout %% 16 == 0 and a `dtype` output");
   if (a.ps && (d->cout % 16 != 0)) return fsr_fail(-2, "fsr_conv3x3: pixel shuffle needs cout %% 16 == 0");
   if (a.in_ps && (d->cin % 4 != 0)) return fsr_fail(-2, "fsr_conv3x3: in_pixel_shuffled needs cin %% 4 == 0");
+  if (stats && d->mode == FSR_CONV_DGRAD && d->stride != 1)
+    return fsr_fail(-2, "fsr_conv3x3: statistics are not available for stride-2 data gradients");
 
+  if (int rc = conv3x3_enqueue(d, a, stream)) return rc;
+  if (stats) {
+    // second level: the image's slots added in a fixed order into stats[n][cout][2]
+    if ((size_t)a.stats_P > stats_slots_bound(d)) return fsr_fail(-3, "fsr_conv3x3: internal error (partial slots %d)", a.stats_P);
+    return fsr_launch_reduce_partials((const float*)scratch, stats, d->n, a.stats_P, d->cout * 2, d->cout * 2, a.stats_tpi, a.stats_per, 1.f, 0, stream);
+  }
+  return 0;
+}
+
+static int conv3x3_enqueue(const fsr_conv_desc* d, ConvKArgs& a, hipStream_t stream) {
   if (d->mode == FSR_CONV_FWD) {
     if (d->oh != (d->ih - 1) / d->stride + 1 || d->ow != (d->iw - 1) / d->stride + 1)
       return fsr_fail(-2, "fsr_conv3x3: output dims do not match k=3,p=1,stride=%d", d->stride);

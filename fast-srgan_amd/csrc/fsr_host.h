@@ -18,3 +18,8 @@ int fsr_conv_stage_mode();   // FSR_CONV_STAGE tuning / test switch, see conv_ig
 // 1 = launched, 0 = shape not handled by the LDS-resident-filter kernel, < 0 = error
 int fsr_conv64_persistent_try(int dtype, ConvKArgs& a, int S, hipStream_t stream);
 int fsr_conv64_s2dgrad_try(int dtype, ConvKArgs& a, hipStream_t stream);   // stride-2 data gradient, 64 -> 64, all parity classes
+// Second level of every cross-workgroup reduction (reduce.hip): out[b][i] (+)= scale * sum_p part[(b*P + p)*stride + i]
+// for i < len, p in a fixed order.  per > 0: batch b owns only the slots of the tile ranges [w*per, (w+1)*per) that
+// intersect its tpi tiles.
+int fsr_launch_reduce_partials(const float* part, float* out, int batches, int P, int len, int stride, int tpi, int per,
+                               float scale, int accumulate, hipStream_t stream);

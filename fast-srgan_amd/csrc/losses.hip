@@ -6,8 +6,9 @@
 //   AdamW(lr, fused=True)           /root/reference/trainer.py:33-38
 //
 // Reductions are wavefront-level: each lane accumulates a grid-stride partial, the 64 lanes are
-// summed with DPP/shuffle steps, the 4 waves of a workgroup meet in LDS and one float atomic per
-// workgroup lands in HBM.
+// summed with DPP/shuffle steps, the 4 waves of a workgroup meet in LDS and the workgroup's sum goes to
+// its slot of a scratch buffer; reduce.hip adds the slots in a fixed order (bit-reproducible losses and
+// gradients, no float atomics).
 #include "fsr_common.h"
 #include "fsr_host.h"
 
@@ -27,7 +28,7 @@ inline int red_blocks(long long items) {
 }
 
 __global__ __launch_bounds__(256) void bce_logits_fwd_kernel(const float* __restrict__ x, const float* __restrict__ t,
-                                                             float* __restrict__ loss, long long count, float inv) {
+                                                             float* __restrict__ loss, long long count) {
   __shared__ float red4[4];
   float s = 0.f;
   for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < count; i += (long long)gridDim.x * 256) {
@@ -35,7 +36,7 @@ __global__ __launch_bounds__(256) void bce_logits_fwd_kernel(const float* __rest
     s += fmaxf(xv, 0.f) - xv * t[i] + log1pf(expf(-fabsf(xv)));
   }
   s = block_sum_256(s, red4);
-  if (threadIdx.x == 0) atomicAdd(loss, s * inv);
+  if (threadIdx.x == 0) loss[blockIdx.x] = s;   // partial slot; the mean is finished by reduce.hip
 }
 
 __global__ __launch_bounds__(256) void bce_logits_bwd_kernel(const float* __restrict__ x, const float* __restrict__ t,
@@ -78,7 +79,7 @@ template <> struct LV<bf16_t> {
 
 template <typename T>
 __global__ __launch_bounds__(256) void smooth_l1_fwd_kernel(const T* __restrict__ a, const T* __restrict__ b,
-                                                            float* __restrict__ loss, long long units, float inv) {
+                                                            float* __restrict__ loss, long long units) {
   constexpr int E = LV<T>::N;
   __shared__ float red4[4];
   float s = 0.f;
@@ -93,7 +94,7 @@ __global__ __launch_bounds__(256) void smooth_l1_fwd_kernel(const T* __restrict_
     }
   }
   s = block_sum_256(s, red4);
-  if (threadIdx.x == 0) atomicAdd(loss, s * inv);
+  if (threadIdx.x == 0) loss[blockIdx.x] = s;   // partial slot; the mean is finished by reduce.hip
 }
 
 template <typename T>
@@ -137,8 +138,7 @@ __global__ __launch_bounds__(256) void conv1x1_c1_fwd_kernel(const T* __restrict
 template <typename T>
 __global__ __launch_bounds__(256) void conv1x1_c1_bwd_kernel(const float* __restrict__ g, const T* __restrict__ x,
                                                              const float* __restrict__ w, T* __restrict__ dx,
-                                                             float* __restrict__ dw, float* __restrict__ db, int npix,
-                                                             int c) {
+                                                             float* __restrict__ dw, int npix, int c) {
   constexpr int E = LV<T>::N;
   __shared__ float red[256 * E];
   const int cu = c / E, rows = 256 / cu;
@@ -169,7 +169,7 @@ __global__ __launch_bounds__(256) void conv1x1_c1_bwd_kernel(const float* __rest
     const int q = t / cu, un = t % cu;
     float s = 0.f;
     for (int r = 0; r < rows; ++r) s += red[q * 256 + r * cu + un];
-    atomicAdd(dw + un * E + q, s);
+    dw[(size_t)blockIdx.x * (c + 1) + un * E + q] = s;   // partial slot [block][c + 1] (reduce.hip adds the blocks in order)
   }
   __syncthreads();
   red[tid] = gsum;
@@ -177,7 +177,7 @@ __global__ __launch_bounds__(256) void conv1x1_c1_bwd_kernel(const float* __rest
   if (tid == 0) {
     float s = 0.f;
     for (int r = 0; r < rows; ++r) s += red[r * cu];
-    atomicAdd(db, s);
+    dw[(size_t)blockIdx.x * (c + 1) + c] = s;
   }
 }
 
@@ -208,11 +208,15 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const
 
 }  // namespace
 
-extern "C" int fsr_bce_logits_fwd(const float* x, const float* t, float* loss, long long count, fsr_stream_t stream_) {
-  if (!x || !t || !loss || count <= 0) return fsr_fail(-1, "fsr_bce_logits_fwd: bad argument");
-  hipLaunchKernelGGL(bce_logits_fwd_kernel, dim3(red_blocks(count)), dim3(256), 0, (hipStream_t)stream_, x, t, loss, count,
-                     1.f / (float)count);
-  return fsr_check_launch("bce_logits_fwd_kernel");
+extern "C" size_t fsr_loss_scratch(void) { return 1024 * sizeof(float); }   // red_blocks() caps the grid at 1024 workgroups
+
+extern "C" int fsr_bce_logits_fwd(const float* x, const float* t, float* loss, void* scratch, long long count,
+                                  fsr_stream_t stream_) {
+  if (!x || !t || !loss || !scratch || count <= 0) return fsr_fail(-1, "fsr_bce_logits_fwd: bad argument");
+  const int blocks = red_blocks(count);
+  hipLaunchKernelGGL(bce_logits_fwd_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream_, x, t, (float*)scratch, count);
+  if (int rc = fsr_check_launch("bce_logits_fwd_kernel")) return rc;
+  return fsr_launch_reduce_partials((const float*)scratch, loss, 1, blocks, 1, 1, 0, 0, 1.f / (float)count, 0, (hipStream_t)stream_);
 }
 extern "C" int fsr_bce_logits_bwd(const float* x, const float* t, const float* gscale, float* dx, long long count,
                                   fsr_stream_t stream_) {
@@ -222,21 +226,23 @@ extern "C" int fsr_bce_logits_bwd(const float* x, const float* t, const float* g
   return fsr_check_launch("bce_logits_bwd_kernel");
 }
 
-extern "C" int fsr_smooth_l1_fwd(int dtype, const void* a, const void* b, float* loss, long long count,
+extern "C" int fsr_smooth_l1_fwd(int dtype, const void* a, const void* b, float* loss, void* scratch, long long count,
                                  fsr_stream_t stream_) {
-  if (!a || !b || !loss || count <= 0) return fsr_fail(-1, "fsr_smooth_l1_fwd: bad argument");
+  if (!a || !b || !loss || !scratch || count <= 0) return fsr_fail(-1, "fsr_smooth_l1_fwd: bad argument");
   const int e = dtype == FSR_BF16 ? 8 : 4;
   if (count % e) return fsr_fail(-2, "fsr_smooth_l1_fwd: count %lld is not a multiple of %d", count, e);
   const long long units = count / e;
+  const int blocks = red_blocks(units * 4);
   if (dtype == FSR_BF16)
-    hipLaunchKernelGGL(smooth_l1_fwd_kernel<bf16_t>, dim3(red_blocks(units * 4)), dim3(256), 0, (hipStream_t)stream_,
-                       (const bf16_t*)a, (const bf16_t*)b, loss, units, 1.f / (float)count);
+    hipLaunchKernelGGL(smooth_l1_fwd_kernel<bf16_t>, dim3(blocks), dim3(256), 0, (hipStream_t)stream_,
+                       (const bf16_t*)a, (const bf16_t*)b, (float*)scratch, units);
   else if (dtype == FSR_F32)
-    hipLaunchKernelGGL(smooth_l1_fwd_kernel<float>, dim3(red_blocks(units * 4)), dim3(256), 0, (hipStream_t)stream_,
-                       (const float*)a, (const float*)b, loss, units, 1.f / (float)count);
+    hipLaunchKernelGGL(smooth_l1_fwd_kernel<float>, dim3(blocks), dim3(256), 0, (hipStream_t)stream_,
+                       (const float*)a, (const float*)b, (float*)scratch, units);
   else
     return fsr_fail(-2, "fsr_smooth_l1_fwd: unknown dtype %d", dtype);
-  return fsr_check_launch("smooth_l1_fwd_kernel");
+  if (int rc = fsr_check_launch("smooth_l1_fwd_kernel")) return rc;
+  return fsr_launch_reduce_partials((const float*)scratch, loss, 1, blocks, 1, 1, 0, 0, 1.f / (float)count, 0, (hipStream_t)stream_);
 }
 extern "C" int fsr_smooth_l1_bwd(int dtype, const void* a, const void* b, const float* gscale, void* da, long long count,
                                  fsr_stream_t stream_) {
@@ -277,9 +283,11 @@ extern "C" int fsr_conv1x1_c1_fwd(int dtype, const void* x, const float* w, cons
   return fsr_check_launch("conv1x1_c1_fwd_kernel");
 }
 
+extern "C" size_t fsr_conv1x1_c1_bwd_scratch(int c) { return c > 0 ? (size_t)512 * (c + 1) * sizeof(float) : 0; }
+
 extern "C" int fsr_conv1x1_c1_bwd(int dtype, const float* g, const void* x, const float* w, void* dx, float* dw, float* db,
-                                  int npix, int c, fsr_stream_t stream_) {
-  if (!g || !x || !w || !dw || !db || npix <= 0) return fsr_fail(-1, "fsr_conv1x1_c1_bwd: bad argument");
+                                  void* scratch, int npix, int c, fsr_stream_t stream_) {
+  if (!g || !x || !w || !dw || !db || !scratch || npix <= 0) return fsr_fail(-1, "fsr_conv1x1_c1_bwd: bad argument");
   if (int rc = c1_check("fsr_conv1x1_c1_bwd", dtype, c)) return rc;
   const int cu = c / (dtype == FSR_BF16 ? 8 : 4);
   if (cu > 256 || 256 % cu) return fsr_fail(-2, "fsr_conv1x1_c1_bwd: %d channels do not tile a 256-thread workgroup", c);
@@ -287,13 +295,17 @@ extern "C" int fsr_conv1x1_c1_bwd(int dtype, const float* g, const void* x, cons
   int blocks = (npix + rows * 8 - 1) / (rows * 8);
   if (blocks > 512) blocks = 512;
   if (blocks < 1) blocks = 1;
+  float* part = (float*)scratch;   // [blocks][c + 1]: weight-gradient partials, then the bias-gradient partial
   if (dtype == FSR_BF16)
     hipLaunchKernelGGL(conv1x1_c1_bwd_kernel<bf16_t>, dim3(blocks), dim3(256), 0, (hipStream_t)stream_, g, (const bf16_t*)x,
-                       w, (bf16_t*)dx, dw, db, npix, c);
+                       w, (bf16_t*)dx, part, npix, c);
   else
     hipLaunchKernelGGL(conv1x1_c1_bwd_kernel<float>, dim3(blocks), dim3(256), 0, (hipStream_t)stream_, g, (const float*)x, w,
-                       (float*)dx, dw, db, npix, c);
-  return fsr_check_launch("conv1x1_c1_bwd_kernel");
+                       (float*)dx, part, npix, c);
+  if (int rc = fsr_check_launch("conv1x1_c1_bwd_kernel")) return rc;
+  // dw[c] and db[0] from the same partial rows (row stride c + 1)
+  if (int rc = fsr_launch_reduce_partials(part, dw, 1, blocks, c, c + 1, 0, 0, 1.f, 0, (hipStream_t)stream_)) return rc;
+  return fsr_launch_reduce_partials(part + c, db, 1, blocks, 1, c + 1, 0, 0, 1.f, 0, (hipStream_t)stream_);
 }
 
 extern "C" int fsr_adamw_step(float* p, const float* g, float* m, float* v, long long count, float lr, float beta1,

@@ -55,7 +55,12 @@ PACK_C3 = "c3"   # packed_filter mode of the first-layer (image-input) kernels
 
 def packed_filter(cd, weight, mode, k_pad):
     """[9][rows_pad][k_pad] image of an OIHW float weight (fsr_pack_conv3x3), cached per weight OBJECT and version.
-    Entries die with the weight (weak reference), so a recycled id()/address can never serve a stale filter."""
+    Entries die with the weight (weak reference), so a recycled id()/address can never serve a stale filter.
+
+    The image of a (weight, mode, dtype, k_pad) lives in ONE buffer for the lifetime of the weight: a newer weight
+    version is re-packed IN PLACE.  A captured hipGraph therefore bakes in addresses that stay valid, and the re-pack
+    launches it contains (the optimizer step inside the graph bumps the version, so the next use re-packs) refresh
+    exactly the memory the next replay reads -- no replay can see the filters of capture time."""
     ver = (weight._version, getattr(weight, "_fsr_epoch", 0), weight.data_ptr())
     slot = _pack_cache.get(id(weight))
     if slot is None or slot[0]() is not weight:
@@ -74,13 +79,14 @@ def packed_filter(cd, weight, mode, k_pad):
     if w.dtype != torch.float32 or not w.is_contiguous():
         w = w.float().contiguous()
     _check_dev(w)
+    numel = ((cout + 15) // 16 * 16) * 32 if mode == PACK_C3 else 9 * rows_pad * k_pad
+    out = hit[1] if (hit is not None and hit[1].device == w.device) else None
+    if out is None:
+        out = torch.empty(numel, dtype=cd.torch_dtype, device=w.device)
     if mode == PACK_C3:     # first-layer kernels: [rows_pad][32]
-        out = torch.empty(((cout + 15) // 16 * 16) * 32, dtype=cd.torch_dtype, device=w.device)
         L.check(L.lib().fsr_pack_conv3x3_c3(cd.code, _p(w), cout, _p(out), _stream()), "fsr_pack_conv3x3_c3")
-        slot[1][key] = (ver, out)
-        return out
-    out = torch.empty(9 * rows_pad * k_pad, dtype=cd.torch_dtype, device=w.device)
-    L.check(L.lib().fsr_pack_conv3x3(cd.code, mode, _p(w), cout, cin, k_pad, _p(out), _stream()), "fsr_pack_conv3x3")
+    else:
+        L.check(L.lib().fsr_pack_conv3x3(cd.code, mode, _p(w), cout, cin, k_pad, _p(out), _stream()), "fsr_pack_conv3x3")
     slot[1][key] = (ver, out)
     return out
 
@@ -161,12 +167,19 @@ USE_C3_KERNELS = True   # tests flip this to compare the first-layer kernels wit
 PROFILE_CONV = None
 
 
+_ws_retired = []    # outgrown scratch buffers: captured hipGraphs may still hold their addresses, so they are never freed
+
+
 def _workspace(nbytes, device):
-    """Split-K scratch, one buffer per (device, stream): launches on different streams may overlap."""
-    key = (device, _stream())
+    """Scratch (split-K partials of the weight gradients, per-workgroup partials of the reductions), one buffer per
+    (device, stream): launches on different streams may overlap; on one stream a producer and the kernel that finishes
+    its partials are enqueued back to back by the same C-ABI call, so the next call may reuse the buffer."""
+    key = (str(device), _stream())
     buf = _ws.get(key)
     if buf is None or buf.numel() * 4 < nbytes:
-        buf = torch.empty((nbytes + 3) // 4, dtype=torch.float32, device=device)
+        if buf is not None:
+            _ws_retired.append(buf)
+        buf = torch.empty((max(nbytes, 1 << 20) + 3) // 4, dtype=torch.float32, device=device)
         _ws[key] = buf
     return buf
 
@@ -247,12 +260,13 @@ def conv3x3_raw(cd, x, wpk, cout, *, mode=L.CONV_FWD, out_hw=None, stride=1, bia
     stats = _zeros((n, cout, 2), x.device) if want_stats else None
     d = L.ConvDesc(cd.code, mode, n, ih, iw, cin, oh, ow, cout, stride, act, float(slope), int(pixel_shuffle),
                    int(in_pixel_shuffled), int(out_f32))
+    scratch = _workspace(L.lib().fsr_conv3x3_scratch(ctypes.byref(d)), x.device) if want_stats else None
     prof = PROFILE_CONV
     if prof is not None:
         ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         ev0.record()
     L.check(L.lib().fsr_conv3x3(ctypes.byref(d), _p(x), _p(wpk), _p(bias), _p(prelu), _p(oscale), _p(dact_mask),
-                                float(dact_slope), _p(out), _p(pre), _p(stats), _stream()), "fsr_conv3x3")
+                                float(dact_slope), _p(out), _p(pre), _p(stats), _p(scratch), _stream()), "fsr_conv3x3")
     if prof is not None:
         ev1.record()
         k = cin if alg_k is None else alg_k
@@ -421,7 +435,7 @@ class Conv3x3Fn(torch.autograd.Function):
             dz = torch.empty((n, h, w, cd.cpad), dtype=cd.torch_dtype, device=xin.device)
             sn, sc, sh, sw = g.stride()
             L.check(lib.fsr_tanh_bwd_to_nhwc(cd.code, _p(g), sn, sc, sh, sw, _p(saved), n, h, w, _p(dz), cd.cpad, _p(dbias),
-                                             st), "fsr_tanh_bwd_to_nhwc")
+                                             _p(_workspace(lib.fsr_tanh_bwd_scratch(), xin.device)), st), "fsr_tanh_bwd_to_nhwc")
         else:
             g = g if g.is_contiguous() else g.contiguous()
             # first-layer kernels with arena gradients: the weight-gradient launch also produces the bias gradient (a column
@@ -433,15 +447,17 @@ class Conv3x3Fn(torch.autograd.Function):
                 dz = g          # already multiplied by this layer's act'() in the consumer's data-gradient epilogue
                 if ctx.has_bias and ctx.needs_input_grad[2] and not fused_dbias:    # bias gradient: column sums of dz, one read pass
                     _, h, w, c = g.shape
-                    L.check(lib.fsr_act_bwd(cd.code, _p(g), None, L.ACT_NONE, 0.0, None, None, _p(dbias), None, n, h, w, c,
-                                            int(cfg.pixel_shuffle), st), "fsr_act_bwd")
+                    scr = _workspace(lib.fsr_act_bwd_scratch(n, h, w, c, int(cfg.pixel_shuffle)), xin.device)
+                    L.check(lib.fsr_act_bwd(cd.code, _p(g), None, L.ACT_NONE, 0.0, None, None, _p(dbias), None, _p(scr), n, h, w,
+                                            c, int(cfg.pixel_shuffle), st), "fsr_act_bwd")
             elif act != L.ACT_NONE or ctx.has_bias:
                 if act == L.ACT_PRELU:
                     dprelu = _zeros((1,), xin.device)
                 dz = torch.empty_like(g)
                 _, h, w, c = g.shape
+                scr = _workspace(lib.fsr_act_bwd_scratch(n, h, w, c, int(cfg.pixel_shuffle)), xin.device)
                 L.check(lib.fsr_act_bwd(cd.code, _p(g), _p(saved), act, float(cfg.slope), _p(prelu), _p(dz), _p(dbias),
-                                        _p(dprelu), n, h, w, c, int(cfg.pixel_shuffle), st), "fsr_act_bwd")
+                                        _p(dprelu), _p(scr), n, h, w, c, int(cfg.pixel_shuffle), st), "fsr_act_bwd")
             else:
                 dz = g
         dx = None
@@ -519,8 +535,9 @@ class InstNormActFn(torch.autograd.Function):
         lib, st = L.lib(), _stream()
         sums = _zeros((n, c, 2), x.device)
         dprelu = _zeros((1,), x.device) if act == L.ACT_PRELU else None
+        scr = _workspace(lib.fsr_instnorm_act_bwd_scratch(n, h * w, c), x.device)
         L.check(lib.fsr_instnorm_act_bwd_reduce(cd.code, _p(g), _p(x), _p(stats), act, float(slope), _p(prelu), _p(sums),
-                                                _p(dprelu), n, h * w, c, st), "fsr_instnorm_act_bwd_reduce")
+                                                _p(dprelu), _p(scr), n, h * w, c, st), "fsr_instnorm_act_bwd_reduce")
         dx = torch.empty_like(x)
         L.check(lib.fsr_instnorm_act_bwd_apply(cd.code, _p(g), _p(x), _p(stats), _p(sums), act, float(slope), _p(prelu),
                                                _p(dx), n, h * w, c, st), "fsr_instnorm_act_bwd_apply")
@@ -585,8 +602,9 @@ class Conv1x1ToLogitsFn(torch.autograd.Function):
         dx = torch.empty_like(x) if ctx.needs_input_grad[0] else None
         dw = _zeros(tuple(weight.shape), x.device)
         db = _zeros((1,), x.device)
+        scr = _workspace(L.lib().fsr_conv1x1_c1_bwd_scratch(c), x.device)
         L.check(L.lib().fsr_conv1x1_c1_bwd(ctx.cd.code, _p(g), _p(x), _p(weight.detach().reshape(-1)), _p(dx), _p(dw), _p(db),
-                                           n * h * w, c, _stream()), "fsr_conv1x1_c1_bwd")
+                                           _p(scr), n * h * w, c, _stream()), "fsr_conv1x1_c1_bwd")
         return dx, dw, db, None
 
 
@@ -604,7 +622,8 @@ class BCEWithLogitsFn(torch.autograd.Function):
         x = x.contiguous().float()
         t = t.contiguous().float()
         loss = _zeros((1,), x.device).view(())
-        L.check(L.lib().fsr_bce_logits_fwd(_p(x), _p(t), _p(loss), x.numel(), _stream()), "fsr_bce_logits_fwd")
+        scr = _workspace(L.lib().fsr_loss_scratch(), x.device)
+        L.check(L.lib().fsr_bce_logits_fwd(_p(x), _p(t), _p(loss), _p(scr), x.numel(), _stream()), "fsr_bce_logits_fwd")
         ctx.save_for_backward(x, t)
         return loss
 
@@ -642,7 +661,8 @@ class SmoothL1Fn(torch.autograd.Function):
         if code == L.FSR_F32 and a.dtype != torch.float32:
             raise L.FsrError("SmoothL1: unsupported dtype %s" % a.dtype)
         loss = _zeros((1,), a.device).view(())
-        L.check(L.lib().fsr_smooth_l1_fwd(code, _p(a), _p(b), _p(loss), a.numel(), _stream()), "fsr_smooth_l1_fwd")
+        scr = _workspace(L.lib().fsr_loss_scratch(), a.device)
+        L.check(L.lib().fsr_smooth_l1_fwd(code, _p(a), _p(b), _p(loss), _p(scr), a.numel(), _stream()), "fsr_smooth_l1_fwd")
         ctx.code = code
         ctx.save_for_backward(a, b)
         return loss

@@ -16,8 +16,14 @@
  *     accumulate); parameters, biases, statistics, parameter gradients and losses are float;
  *   - channel counts of NHWC activations are multiples of FSR_CPAD(dtype) = 16 (f32) / 32 (bf16);
  *     3-channel images are stored zero-padded to that width;
- *   - "accumulates into" outputs (statistics, parameter gradients, losses) must be zeroed by the
- *     caller; they are updated with float atomics (summation order is not reproducible bit for bit);
+ *   - reductions over pixels (InstanceNorm statistics, backward sums, bias / PReLU-slope gradients, loss
+ *     means) are two-level and ORDER-FIXED: the producing kernel stores one partial vector per workgroup into
+ *     the caller's `scratch` buffer (size from the matching fsr_*_scratch query; contents are don't-care before
+ *     and after the call, the buffer may be reused by the next call on the same stream), and a second
+ *     kernel enqueued by the same call adds the partials in a fixed order and ASSIGNS the result.  There are
+ *     no float atomics anywhere: the same inputs give the same bits on every run.  Only the weight gradients
+ *     (`dw_oihw`, and the `dbias` of fsr_conv3x3_c3_wgrad) ACCUMULATE into their outputs ("+=", one thread
+ *     per element): the caller zeroes them once per optimizer step;
  *   - return value 0 = enqueued, < 0 = rejected (nothing enqueued); fsr_last_error() gives the
  *     reason for the calling thread.  The functions are thread-compatible.
  */
@@ -31,7 +37,7 @@
 extern "C" {
 #endif
 
-#define FSR_ABI_VERSION 5
+#define FSR_ABI_VERSION 6
 
 enum { FSR_F32 = 0, FSR_BF16 = 1 };
 enum { FSR_ACT_NONE = 0, FSR_ACT_RELU = 1, FSR_ACT_LEAKY = 2, FSR_ACT_PRELU = 3, FSR_ACT_TANH = 4 };
@@ -74,8 +80,8 @@ int fsr_pack_conv3x3(int dtype, int mode, const float* w_oihw, int cout, int cin
  * pixel_shuffle (FWD): out is [n,2oh,2ow,cout/4]; filters packed FSR_PACK_FWD_PS.
  * in_pixel_shuffled (DGRAD): in is [n,2ih,2iw,cin/4]; filters packed FSR_PACK_DGRAD_PS.
  * out_f32: store float whatever `dtype` is (3-channel outputs: head images, image gradients).
- * stats (optional): float [n][cout][2]; accumulates the sum and sum of squares of the
- *   pre-activation over pixels.
+ * stats (optional): float [n][cout][2]; receives the sum and the sum of squares of the pre-activation
+ *   over pixels (needs `scratch` of fsr_conv3x3_scratch(desc) bytes; FWD and stride-1 DGRAD launches).
  * preact (optional): tensor like out; receives the pre-activation (training: PReLU backward
  *   needs its sign, which the output of a negative-slope PReLU does not reveal).
  * oscale (optional): float [cout] multiplied into the result before bias/activation (the
@@ -96,9 +102,10 @@ typedef struct fsr_conv_desc {
   int out_f32;
 } fsr_conv_desc;
 
+size_t fsr_conv3x3_scratch(const fsr_conv_desc* desc);
 int fsr_conv3x3(const fsr_conv_desc* desc, const void* in, const void* packed_w, const float* bias,
                 const float* prelu_weight, const float* oscale, const void* dact_mask, float dact_slope, void* out,
-                void* preact, float* stats, fsr_stream_t stream);
+                void* preact, float* stats, void* scratch, fsr_stream_t stream);
 
 /* Weight gradient of the same convolutions: dW[co][ci][ky][kx] (OIHW float, torch .grad layout)
  *   += sum_{n,y,x} dy[n,y,x,co] * x[n, y*stride+ky-1, x*stride+kx-1, ci]      (autograd of model.py convs)
@@ -123,11 +130,13 @@ int fsr_conv3x3_wgrad(const fsr_wgrad_desc* desc, const void* x, const void* dy,
  *   out = act((x - mean) * rstd) + res.          x, res, out: [n,hw,c] `dtype`; stats [n][c][2]. */
 int fsr_instnorm_act_fwd(int dtype, const void* x, const float* stats, const void* res, int act, float slope,
                          const float* prelu_weight, void* out, int n, int hw, int c, fsr_stream_t stream);
-/* Backward, phase 1: sums[n][c][2] += (sum gz, sum gz*xhat) with gz = g * act'(xhat);
- * dprelu[0] += sum g*min(xhat,0).   Phase 2: dx = rstd*(gz - mean(gz) - xhat*mean(gz*xhat)). */
+/* Backward, phase 1: sums[n][c][2] = (sum gz, sum gz*xhat) with gz = g * act'(xhat);
+ * dprelu[0] = sum g*min(xhat,0) (optional); scratch: fsr_instnorm_act_bwd_scratch(n,hw,c) bytes.
+ * Phase 2: dx = rstd*(gz - mean(gz) - xhat*mean(gz*xhat)). */
+size_t fsr_instnorm_act_bwd_scratch(int n, int hw, int c);
 int fsr_instnorm_act_bwd_reduce(int dtype, const void* g, const void* x, const float* stats, int act, float slope,
-                                const float* prelu_weight, float* sums, float* dprelu, int n, int hw, int c,
-                                fsr_stream_t stream);
+                                const float* prelu_weight, float* sums, float* dprelu, void* scratch, int n, int hw,
+                                int c, fsr_stream_t stream);
 int fsr_instnorm_act_bwd_apply(int dtype, const void* g, const void* x, const float* stats, const float* sums,
                                int act, float slope, const float* prelu_weight, void* dx, int n, int hw, int c,
                                fsr_stream_t stream);
@@ -135,12 +144,14 @@ int fsr_instnorm_act_bwd_apply(int dtype, const void* g, const void* x, const fl
 /* ------------------------------------------------------------------ activation backward of a fused conv epilogue
  * dz = g * act'(.) for the activations fsr_conv3x3 fuses; `saved` is the conv OUTPUT for
  * ReLU / LeakyReLU(slope > 0) and the saved PRE-activation for PReLU.  Tensors [n,h,w,c] `dtype`.
- * dbias (optional, float [cb]) += per-channel sums of dz; with pixel_shuffled != 0 the tensors are
+ * dbias (optional, float [cb]) = per-channel sums of dz; with pixel_shuffled != 0 the tensors are
  * the depth-to-space outputs of a cb = 4c channel conv and dbias index = 4*ch + 2*(y&1) + (x&1).
- * dprelu (optional) += sum g*min(saved,0).  dz may be null when only the reductions are wanted (bias gradient of a
- * layer whose activation backward was already applied by its consumer's data-gradient epilogue). */
+ * dprelu (optional) = sum g*min(saved,0).  dz may be null when only the reductions are wanted (bias gradient of a
+ * layer whose activation backward was already applied by its consumer's data-gradient epilogue).
+ * scratch (needed with dbias / dprelu): fsr_act_bwd_scratch(n,h,w,c,pixel_shuffled) bytes. */
+size_t fsr_act_bwd_scratch(int n, int h, int w, int c, int pixel_shuffled);
 int fsr_act_bwd(int dtype, const void* g, const void* saved, int act, float slope, const float* prelu_weight,
-                void* dz, float* dbias, float* dprelu, int n, int h, int w, int c, int pixel_shuffled,
+                void* dz, float* dbias, float* dprelu, void* scratch, int n, int h, int w, int c, int pixel_shuffled,
                 fsr_stream_t stream);
 
 /* ------------------------------------------------------------------ 3-channel images <-> padded NHWC
@@ -151,9 +162,11 @@ int fsr_image_to_nhwc(int dtype, const float* img, long long sn, long long sc, l
                       int h, int w, float scale0, float scale1, float scale2, float shift0, float shift1,
                       float shift2, void* out, int cpad, fsr_stream_t stream);
 /* Head backward (model.py:102-110): dz = g * (1 - y^2) for y = tanh(z), written zero-padded NHWC;
- * g has element strides (sn,sc,sh,sw), y is the head output [n,h,w,3] float.  dbias[3] += sums. */
+ * g has element strides (sn,sc,sh,sw), y is the head output [n,h,w,3] float.  dbias[3] (optional) = sums;
+ * scratch (with dbias): fsr_tanh_bwd_scratch() bytes. */
+size_t fsr_tanh_bwd_scratch(void);
 int fsr_tanh_bwd_to_nhwc(int dtype, const float* g, long long sn, long long sc, long long sh, long long sw,
-                         const float* y_nhwc3, int n, int h, int w, void* dz, int cpad, float* dbias,
+                         const float* y_nhwc3, int n, int h, int w, void* dz, int cpad, float* dbias, void* scratch,
                          fsr_stream_t stream);
 
 /* ------------------------------------------------------------------ first-layer convolutions straight from the image
@@ -187,22 +200,27 @@ int fsr_maxpool2_bwd(int dtype, const void* g, const void* x, const void* y, voi
 
 /* ------------------------------------------------------------------ Discriminator head: Conv2d(512 -> 1, k=1) (model.py:184-186)
  * logits[p] = b + sum_c x[p][c]*w[c]; x [npix,c] `dtype`, logits float.
- * Backward: dx[p][c] = g[p]*w[c]; dw[c] += sum_p g[p]*x[p][c]; db[0] += sum_p g[p]. */
+ * Backward: dx[p][c] = g[p]*w[c]; dw[c] = sum_p g[p]*x[p][c]; db[0] = sum_p g[p];
+ * scratch: fsr_conv1x1_c1_bwd_scratch(c) bytes. */
 int fsr_conv1x1_c1_fwd(int dtype, const void* x, const float* w, const float* b, float* logits, int npix, int c,
                        fsr_stream_t stream);
+size_t fsr_conv1x1_c1_bwd_scratch(int c);
 int fsr_conv1x1_c1_bwd(int dtype, const float* g, const void* x, const float* w, void* dx, float* dw, float* db,
-                       int npix, int c, fsr_stream_t stream);
+                       void* scratch, int npix, int c, fsr_stream_t stream);
 
 /* ------------------------------------------------------------------ losses (trainer.py:41,43,177,178,188,192,109)
- * BCEWithLogitsLoss (mean): loss[0] += mean(max(x,0) - x*t + log1p(exp(-|x|))); x, t float [count].
+ * BCEWithLogitsLoss (mean): loss[0] = mean(max(x,0) - x*t + log1p(exp(-|x|))); x, t float [count];
+ * scratch (both loss forwards): fsr_loss_scratch() bytes.
  * Backward: dx = gscale[0] * (sigmoid(x) - t) / count   (gscale: device scalar, the upstream grad). */
-int fsr_bce_logits_fwd(const float* x, const float* t, float* loss, long long count, fsr_stream_t stream);
+size_t fsr_loss_scratch(void);
+int fsr_bce_logits_fwd(const float* x, const float* t, float* loss, void* scratch, long long count, fsr_stream_t stream);
 int fsr_bce_logits_bwd(const float* x, const float* t, const float* gscale, float* dx, long long count,
                        fsr_stream_t stream);
 /* SmoothL1Loss (beta 1, mean) between `a` and `b` (`dtype` tensors, or float when dtype_is_f32_io):
- * loss[0] += mean(huber(a-b)).  Backward: da = gscale[0]*clamp(a-b,-1,1)/count (db = -da not produced:
+ * loss[0] = mean(huber(a-b)).  Backward: da = gscale[0]*clamp(a-b,-1,1)/count (db = -da not produced:
  * the target branch of trainer.py:191/:109 needs no gradient). */
-int fsr_smooth_l1_fwd(int dtype, const void* a, const void* b, float* loss, long long count, fsr_stream_t stream);
+int fsr_smooth_l1_fwd(int dtype, const void* a, const void* b, float* loss, void* scratch, long long count,
+                      fsr_stream_t stream);
 int fsr_smooth_l1_bwd(int dtype, const void* a, const void* b, const float* gscale, void* da, long long count,
                       fsr_stream_t stream);
 

@@ -25,7 +25,7 @@ def test_library_exports_every_declared_symbol():
     assert lib.fsr_version() == L.ABI_VERSION
     # argument validation works without a device: nothing is launched for a rejected call
     lib.fsr_last_error.restype = ctypes.c_char_p
-    assert lib.fsr_conv3x3(None, None, None, None, None, None, None, ctypes.c_float(0), None, None, None, None) < 0
+    assert lib.fsr_conv3x3(None, None, None, None, None, None, None, ctypes.c_float(0), None, None, None, None, None) < 0
     assert b"null" in lib.fsr_last_error()
 
 

@@ -241,10 +241,10 @@ def test_c_abi_rejects_malformed_calls(dev):
                                               "pixel_shuffle", "in_pixel_shuffled", "out_f32")])
 
     def conv(d, **kw):
-        a = dict(inp=p, w=p, bias=None, prelu=None, oscale=None, mask=None, out=p, pre=None, stats=None)
+        a = dict(inp=p, w=p, bias=None, prelu=None, oscale=None, mask=None, out=p, pre=None, stats=None, scratch=p)
         a.update(kw)
         return lib.fsr_conv3x3(ctypes.byref(d), a["inp"], a["w"], a["bias"], a["prelu"], a["oscale"], a["mask"], 0.0, a["out"],
-                               a["pre"], a["stats"], None)
+                               a["pre"], a["stats"], a["scratch"], None)
 
     assert conv(desc()) == 0                                        # the well-formed call goes through
     bad = [desc(n=0), desc(oh=7), desc(cin=12), desc(dtype=7), desc(mode=5), desc(stride=3), desc(act=L.ACT_PRELU),
@@ -254,6 +254,9 @@ def test_c_abi_rejects_malformed_calls(dev):
     assert conv(desc(), inp=None) < 0 and conv(desc(), out=None) < 0
     assert conv(desc(pixel_shuffle=1, cout=64), stats=p) < 0          # statistics + pixel shuffle
     assert conv(desc(cout=3), stats=p) < 0                            # statistics need cout % 16 == 0
+    assert conv(desc(), stats=p, scratch=None) < 0                    # statistics need the partial-sum scratch
+    assert conv(desc(mode=L.CONV_DGRAD, stride=2, ih=4, iw=4), stats=p) < 0   # no statistics for stride-2 data gradients
+    assert lib.fsr_conv3x3_scratch(ctypes.byref(desc())) >= 1 * 2 * 16 * 2 * 4
     # weight gradient: dims must match k=3, p=1
     wd = L.WgradDesc(L.FSR_F32, 1, 8, 8, 16, 16, 7, 8, 16, 16, 1, 0)
     assert lib.fsr_conv3x3_wgrad_workspace(ctypes.byref(wd)) == 0
@@ -261,7 +264,10 @@ def test_c_abi_rejects_malformed_calls(dev):
     # elementwise kernels: channel count must be a multiple of the vector width, pointers non-null
     assert lib.fsr_instnorm_act_fwd(L.FSR_BF16, p, p, None, L.ACT_NONE, 0.0, None, p, 1, 64, 12, None) < 0
     assert lib.fsr_instnorm_act_fwd(L.FSR_F32, None, p, None, L.ACT_NONE, 0.0, None, p, 1, 64, 16, None) < 0
-    assert lib.fsr_act_bwd(L.FSR_F32, p, None, L.ACT_RELU, 0.0, None, p, None, None, 1, 8, 8, 16, 0, None) < 0
+    assert lib.fsr_act_bwd(L.FSR_F32, p, None, L.ACT_RELU, 0.0, None, p, None, None, p, 1, 8, 8, 16, 0, None) < 0
+    assert lib.fsr_act_bwd(L.FSR_F32, p, p, L.ACT_RELU, 0.0, None, p, p, None, None, 1, 8, 8, 16, 0, None) < 0   # dbias without scratch
+    assert lib.fsr_bce_logits_fwd(p, p, p, None, 64, None) < 0 and lib.fsr_smooth_l1_fwd(L.FSR_F32, p, p, p, None, 64, None) < 0
+    assert lib.fsr_instnorm_act_bwd_reduce(L.FSR_F32, p, p, p, L.ACT_NONE, 0.0, None, p, None, None, 1, 64, 16, None) < 0
     assert lib.fsr_maxpool2_fwd(L.FSR_F32, p, p, 1, 7, 8, 16, None) < 0
     assert lib.fsr_adamw_step(p, p, p, p, 0, 1e-3, 0.9, 0.999, 1e-8, 0.0, p, 1.0, None) < 0
     assert lib.fsr_pack_conv3x3(L.FSR_F32, 9, p, 16, 16, 16, p, None) < 0
@@ -426,3 +432,56 @@ def test_dgrad_with_fused_activation_mask(dev, cdn, cin, cout, stride):
         dx, _, _ = ops.conv3x3_raw(cd, _nhwc(g, cd, dev), wpk, cin, mode=L.CONV_DGRAD, out_hw=(h, w), stride=stride, dact_mask=xd,
                                    dact_slope=slope)
         assert relerr(_nchw(dx), want) < tol(cdn, 1e-5, 1e-2)
+
+
+@pytest.mark.parametrize("cus", [1, 4, 7, 64])
+def test_persistent_conv_statistics_across_tile_ranges(dev, cus, monkeypatch):
+    """InstanceNorm statistics of the persistent 64-channel kernel when its tile ranges straddle image borders
+    (FSR_PERSIST_CUS sets the number of ranges): every image's partial slots are found and added, whatever the split."""
+    monkeypatch.setenv("FSR_PERSIST_CUS", str(cus))
+    cd = ops.Compute("bf16")
+    torch.manual_seed(11)
+    n, h, w = (5, 40, 72) if _big(dev) else (3, 20, 36)
+    for cout in (64, 128):
+        x = _q(torch.randn(n, 64, h, w), cd)
+        wt = _q(torch.randn(cout, 64, 3, 3) * 0.1, cd)
+        wpk = ops.packed_filter(cd, wt.to(dev), L.PACK_FWD, 64)
+        y, _, stats = ops.conv3x3_raw(cd, _nhwc(x, cd, dev), wpk, cout, want_stats=True)
+        ref = F.conv2d(x, wt, None, 1, 1)
+        assert relerr(_nchw(y), ref) < 1e-2
+        s = stats.cpu()
+        assert relerr(s[..., 0], ref.sum((2, 3))) < 1e-3
+        assert relerr(s[..., 1], (ref * ref).sum((2, 3))) < 1e-3
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("cdn", ["f32", "bf16"])
+def test_reductions_are_bit_reproducible(cdn):
+    """No float atomics: statistics, backward sums, bias / slope / weight gradients and losses of repeated launches on the
+    same inputs are IDENTICAL bit for bit (per-workgroup partials added in a fixed order, csrc/reduce.hip)."""
+    dev = select("hip")
+    cd = ops.Compute(cdn)
+    torch.manual_seed(12)
+    n, nf, h, w = 6, 64, 96, 96
+
+    def run():
+        torch.manual_seed(13)
+        x = leaf(_nhwc(_q(torch.randn(n, nf, h, w), cd), cd, dev))
+        wt, a = leaf(_q(torch.randn(nf, nf, 3, 3) * 0.05, cd), dev), leaf(torch.tensor([0.25]), dev)
+        wu, bu, au = leaf(_q(torch.randn(4 * nf, nf, 3, 3) * 0.05, cd), dev), leaf(torch.randn(4 * nf) * 0.1, dev), leaf(torch.tensor([-0.2]), dev)
+        t, st = ops.conv3x3(x, wt, None, None, ops.ConvCfg(cd, stats=True))
+        y = ops.instnorm_act(t, st, x, a, cd, L.ACT_PRELU)
+        u, _ = ops.conv3x3(y, wu, bu, au, ops.ConvCfg(cd, act=L.ACT_PRELU, pixel_shuffle=True))
+        wl, bl = leaf(torch.randn(1, nf, 1, 1) * 0.1, dev), leaf(torch.randn(1), dev)
+        lg = ops.conv1x1_to_logits(u, wl, bl, cd)
+        tgt = torch.rand(lg.shape, generator=torch.Generator().manual_seed(3)).to(dev)
+        loss = ops.bce_with_logits(lg, tgt) + ops.smooth_l1(u, torch.zeros_like(u))
+        loss.backward()
+        torch.cuda.synchronize()
+        outs = [st, loss.detach(), x.grad, wt.grad, a.grad, wu.grad, bu.grad, au.grad, wl.grad, bl.grad]
+        return [o.detach().clone() for o in outs]
+
+    first = run()
+    for _ in range(4):
+        for a, b in zip(first, run()):
+            assert torch.equal(a, b)

@@ -29,7 +29,7 @@ for (n, hw, c) in ((64, 192 * 192, 128), (64, 192 * 192, 64), (64, 96 * 96, 256)
                 m = min(chunk, n - i0)
                 gp, xp, dp = g.data_ptr() + i0 * per_img, x.data_ptr() + i0 * per_img, dx.data_ptr() + i0 * per_img
                 sp, qp = stats.data_ptr() + i0 * c * 8, sums.data_ptr() + i0 * c * 8
-                L.check(lib.fsr_instnorm_act_bwd_reduce(cd.code, gp, xp, sp, L.ACT_LEAKY, 0.01, None, qp, None, m, hw, c, st))
+                L.check(lib.fsr_instnorm_act_bwd_reduce(cd.code, gp, xp, sp, L.ACT_LEAKY, 0.01, None, qp, None, ops._workspace(lib.fsr_instnorm_act_bwd_scratch(m, hw, c), dev).data_ptr(), m, hw, c, st))
                 L.check(lib.fsr_instnorm_act_bwd_apply(cd.code, gp, xp, sp, qp, L.ACT_LEAKY, 0.01, None, dp, m, hw, c, st))
             e1.record()
             torch.cuda.synchronize()
