@@ -47,6 +47,7 @@ P = c_void_p
 SIGNATURES = {
     "fsr_version": (c_int, []),
     "fsr_last_error": (ctypes.c_char_p, []),
+    "fsr_last_kernel": (ctypes.c_char_p, []),
     "fsr_device_info": (c_int, [ctypes.c_char_p, c_size_t]),
     "fsr_pack_conv3x3": (c_int, [c_int, c_int, P, c_int, c_int, c_int, P, P]),
     "fsr_conv3x3_scratch": (c_size_t, [ctypes.POINTER(ConvDesc)]),
@@ -79,6 +80,8 @@ SIGNATURES = {
     "fsr_bce_logits_bwd": (c_int, [P, P, P, P, c_ll, P]),
     "fsr_smooth_l1_fwd": (c_int, [c_int, P, P, P, P, c_ll, P]),
     "fsr_smooth_l1_bwd": (c_int, [c_int, P, P, P, P, c_ll, P]),
+    "fsr_ssim_sse_scratch": (c_size_t, [c_int, c_int, c_int]),
+    "fsr_ssim_sse": (c_int, [P, c_ll, c_ll, c_ll, c_ll, P, c_ll, c_ll, c_ll, c_ll, c_int, c_int, c_int, P, P, P]),
     "fsr_adamw_step": (c_int, [P, P, P, P, c_ll, c_float, c_float, c_float, c_float, c_float, P, c_float, P]),
     "fsr_crop_resize": (c_int, [P, P, P, P, P, c_int, c_int, c_int, P, P, P, c_int, P, P, P, P]),
 }

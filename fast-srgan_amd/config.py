@@ -1,8 +1,9 @@
 """configs/config.yaml loader with hydra-style `a.b=c` overrides (/root/reference/train.py:46, README.md:45).
 
 hydra / omegaconf are not dependencies; PyYAML reads the same file and the result is an attribute tree with
-the reference's 20 keys (configs/config.yaml:1-25) plus `generator.n_upsample` (default 2) and
-`training.compute_dtype` (default bf16).
+the reference's 20 keys (configs/config.yaml:1-25) plus `generator.n_upsample` (default 2),
+`training.compute_dtype` (default bf16), `training.vgg19_weights` (path of torchvision's vgg19 checkpoint) and
+`training.allow_random_vgg` (tests / benchmarks only).
 """
 import os
 import types
@@ -16,7 +17,8 @@ DEFAULTS = {
     "discriminator": {"n_filters": 64, "n_layers": 7},
     "training": {"compiled": False, "pretrain_iterations": 100, "iterations": 100, "device": "cuda", "log_iter": 5000,
                  "checkpoint_iter": 5000, "batch_size": 24, "num_workers": 16, "generator_lr": 1e-4,
-                 "discriminator_lr": 1e-4, "compute_dtype": "bf16"},
+                 "discriminator_lr": 1e-4, "compute_dtype": "bf16", "vgg19_weights": "", "allow_random_vgg": False,
+                 "hip_graph": True},
 }
 
 
@@ -51,6 +53,8 @@ def load_config(path=None, overrides=()):
         node[parts[-1]] = _parse_scalar(val)
     for k in ("generator_lr", "discriminator_lr"):      # YAML 1.1 reads "1e-4" as a string
         cfg["training"][k] = float(cfg["training"][k])
-    if cfg["training"]["device"] in ("mps", "cpu"):
-        cfg["training"]["device"] = "cuda"              # the only backend of this framework is the MI355X
+    if cfg["training"]["device"] in ("mps", "cpu"):     # the shipped config names mps (configs/config.yaml:19)
+        import warnings
+        warnings.warn("training.device=%s: this framework runs on the MI355X only, using 'cuda'" % cfg["training"]["device"])
+        cfg["training"]["device"] = "cuda"
     return _to_node(cfg)

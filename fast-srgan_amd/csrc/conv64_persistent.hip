@@ -484,6 +484,7 @@ int fsr_conv64_s2dgrad_try(int dtype, ConvKArgs& a, hipStream_t stream) {
   a.nblk_n = per;
   const int grid = (int)((ntiles + per - 1) / per);
   hipLaunchKernelGGL(conv64_s2dgrad_kernel, dim3(grid), dim3(NTHR64), LDS64, stream, a);
+  fsr_note_kernel("conv64_s2dgrad_kernel");
   int rc = fsr_check_launch("conv64_s2dgrad_kernel");
   return rc ? rc : 1;
 }
@@ -533,6 +534,7 @@ int fsr_conv64_persistent_try(int dtype, ConvKArgs& a, int S, hipStream_t stream
   const int grid = (int)((ntiles + per - 1) / per) * nblk;
   if (thin) hipLaunchKernelGGL(conv64_persistent_kernel<1>, dim3(grid), dim3(NTHR64), 9 * 16 * P64 * 2 + H_BYTES + 16, stream, a);
   else hipLaunchKernelGGL(conv64_persistent_kernel<4>, dim3(grid), dim3(NTHR64), LDS64, stream, a);
+  fsr_note_kernel(thin ? "conv64_persistent_kernel<1>" : "conv64_persistent_kernel<4>");
   int rc = fsr_check_launch("conv64_persistent_kernel");
   return rc ? rc : 1;
 }

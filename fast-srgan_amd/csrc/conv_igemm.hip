@@ -599,6 +599,7 @@ static int launch_cfg(ConvKArgs& a, hipStream_t stream, ConvKArgs* more = nullpt
     attr_set = true;
   }
   hipLaunchKernelGGL(kern, dim3((unsigned)nwg), dim3(WM * WN * 64), lds, stream, a, cls);
+  fsr_note_kernel("conv_igemm_kernel<%s,%d,%d,%d,%d,%d,%d,%d,%d>", sizeof(T) == 2 ? "bf16" : "f32", TH, BN, WM, WN, KC, S, G, DMA);
   return fsr_check_launch("conv_igemm_kernel");
 }
 

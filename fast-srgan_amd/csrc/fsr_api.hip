@@ -22,8 +22,18 @@ int fsr_check_launch(const char* what) {
   return 0;
 }
 
+static thread_local char g_kernel[160] = "";
+
+void fsr_note_kernel(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_kernel, sizeof(g_kernel), fmt, ap);
+  va_end(ap);
+}
+
 extern "C" int fsr_version(void) { return FSR_ABI_VERSION; }
 extern "C" const char* fsr_last_error(void) { return g_err; }
+extern "C" const char* fsr_last_kernel(void) { return g_kernel; }
 
 extern "C" int fsr_device_info(char* buf, size_t buflen) {
   if (!buf || buflen == 0) return fsr_fail(-1, "fsr_device_info: null buffer");

@@ -10,6 +10,8 @@ struct ConvKArgs;
 int fsr_fail(int code, const char* fmt, ...);
 // Returns 0 if the most recent launch was accepted by the runtime, else records and returns -3.
 int fsr_check_launch(const char* what);
+// Records the name of the kernel configuration a dispatch picked (fsr_last_kernel(): per-kernel attribution in bench.py).
+void fsr_note_kernel(const char* fmt, ...);
 
 int fsr_conv_igemm_dispatch(int dtype, ConvKArgs& a, int S, hipStream_t stream);
 // `n` launches that differ only in output grid / taps / output offset (stride-2 data-gradient classes) as ONE launch

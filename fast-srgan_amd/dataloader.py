@@ -79,17 +79,26 @@ class NumpyImagesDataset(torch.utils.data.Dataset):
         return rng.randint(0, h - self.hr_image_size), rng.randint(0, w - self.hr_image_size)
 
     def batch(self, indices, crops):
-        """(lr, hr) float32 NCHW device batches for image `indices` cropped at `crops` [(y, x), ...]."""
+        """(lr, hr) float32 NCHW device batches for image `indices` cropped at `crops` [(y, x), ...].
+        The per-sample descriptors (image pointer, height, width, crop origin) travel as ONE pinned, non-blocking
+        host-to-device copy; nothing here waits for the device."""
         n = len(indices)
         imgs = [self._image(i) for i in indices]
-        ptrs = torch.tensor([im.data_ptr() for im in imgs], dtype=torch.int64).to(self.device)
-        meta = torch.tensor([[im.shape[1] for im in imgs], [im.shape[2] for im in imgs],
-                             [c[0] for c in crops], [c[1] for c in crops]], dtype=torch.int32).to(self.device)
+        # [n int64 pointers][4 x n int32: heights, widths, crop_y, crop_x]  (viewed as int64 words for one copy)
+        desc = np.empty(3 * n, dtype=np.int64)
+        desc[:n] = [im.data_ptr() for im in imgs]
+        desc[n:].view(np.int32)[:] = ([im.shape[1] for im in imgs] + [im.shape[2] for im in imgs]
+                                      + [c[0] for c in crops] + [c[1] for c in crops])
+        host = torch.from_numpy(desc)
+        if self.device.type == "cuda":
+            host = host.pin_memory()
+        dev_desc = host.to(self.device, non_blocking=True)
+        meta = dev_desc[n:].view(torch.int32).view(4, n)
         hr, lr = self.hr_image_size, self.lr_image_size
         hr_out = torch.empty((n, 3, hr, hr), dtype=torch.float32, device=self.device)
         lr_out = torch.empty((n, 3, lr, lr), dtype=torch.float32, device=self.device)
         tmp = torch.empty((n, 3, hr, lr), dtype=torch.float32, device=self.device)
-        L.check(L.lib().fsr_crop_resize(_p(ptrs), _p(meta[0]), _p(meta[1]), _p(meta[2]), _p(meta[3]), n, hr,
+        L.check(L.lib().fsr_crop_resize(_p(dev_desc), _p(meta[0]), _p(meta[1]), _p(meta[2]), _p(meta[3]), n, hr,
                                         self.scale_factor, _p(self._w), _p(self._xmin), _p(self._xsize), self._kmax,
                                         _p(hr_out), _p(lr_out), _p(tmp), _stream()), "fsr_crop_resize")
         return lr_out, hr_out
@@ -100,12 +109,19 @@ class NumpyImagesDataset(torch.utils.data.Dataset):
 
 
 class DeviceBatchLoader:
-    """Iterable of `iterations` device batches: image indices drawn with replacement from a seeded
-    torch.Generator (train.py:57-80's RandomSampler), crops from a seeded `random.Random` (train.py:40-43
-    seeds python's RNG per worker).  Under data parallelism each rank passes seed + rank."""
+    """Iterable of device batches.
 
-    def __init__(self, dataset, batch_size, iterations, seed=1234):
-        self.dataset, self.batch_size, self.iterations = dataset, batch_size, iterations
+    Default (training, train.py:69-80,92-113): `iterations` batches whose image indices are drawn with replacement from a
+    seeded torch.Generator (RandomSampler(replacement=True)), crops from a seeded `random.Random` (train.py:40-43 seeds
+    python's RNG per worker).  sequential=True (validation, train.py:81-91: shuffle=False, drop_last=True): ONE pass over
+    the data set in order, len(dataset) // batch_size batches, fresh random crops.  Under data parallelism each rank
+    passes seed + rank."""
+
+    def __init__(self, dataset, batch_size, iterations=None, seed=1234, sequential=False):
+        self.dataset, self.batch_size, self.sequential = dataset, batch_size, sequential
+        self.iterations = len(dataset) // batch_size if sequential else iterations
+        if self.iterations is None:
+            raise ValueError("DeviceBatchLoader needs `iterations` unless sequential=True")
         self.gen = torch.Generator().manual_seed(seed)
         self.rng = random.Random(seed)
 
@@ -113,7 +129,10 @@ class DeviceBatchLoader:
         return self.iterations
 
     def __iter__(self):
-        for _ in range(self.iterations):
-            idx = torch.randint(len(self.dataset), (self.batch_size,), generator=self.gen).tolist()
+        for it in range(self.iterations):
+            if self.sequential:
+                idx = list(range(it * self.batch_size, (it + 1) * self.batch_size))
+            else:
+                idx = torch.randint(len(self.dataset), (self.batch_size,), generator=self.gen).tolist()
             crops = [self.dataset.draw_crop(i, self.rng) for i in idx]
             yield self.dataset.batch(idx, crops)

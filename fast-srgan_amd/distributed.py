@@ -19,7 +19,10 @@ def init_from_env(backend=None):
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1 and not dist.is_initialized():
+    # FSR_FORCE_DIST=1: initialise the process group even for ONE process, so that the RCCL path (all-reduce of the gradient
+    # arenas, phase graphs around it) can be exercised on a single-GPU box
+    force = os.environ.get("FSR_FORCE_DIST", "0") == "1"
+    if (world > 1 or force) and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         if backend is None:
@@ -38,6 +41,11 @@ def rank():
     return dist.get_rank() if dist.is_available() and dist.is_initialized() else 0
 
 
+def is_distributed():
+    """True when gradients go through a collective (a process group exists, whatever its size)."""
+    return dist.is_available() and dist.is_initialized()
+
+
 class GradSync:
     """Gradient exchange for one optimizer's flat gradient buffer."""
 
@@ -48,8 +56,12 @@ class GradSync:
 
     def start(self):
         """Launch the all-reduce (asynchronously where the backend allows); call wait() before step()."""
-        if world_size() > 1:
+        if is_distributed():
             self.work = dist.all_reduce(self.optimizer.flat_grad, op=dist.ReduceOp.SUM, async_op=True)
+
+    def run(self):
+        self.start()
+        self.wait()
 
     def wait(self):
         if self.work is not None:
@@ -59,5 +71,5 @@ class GradSync:
 
 def broadcast_parameters(optimizer, src=0):
     """All ranks start from rank `src`'s parameters (one broadcast of the parameter arena)."""
-    if world_size() > 1:
+    if is_distributed():
         dist.broadcast(optimizer.flat_param, src=src)

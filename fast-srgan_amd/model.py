@@ -160,12 +160,14 @@ class VGG19(torch.nn.Module):
 
     torchvision is not a dependency: the feature stack is rebuilt with the same module indices (state_dict
     keys vgg.{0,2,5,...,32}.{weight,bias} + buffers mean/std).  Pretrained weights: pass `weights=` a path
-    to torchvision's vgg19 checkpoint (keys features.N.*) or set FSR_VGG19_WEIGHTS; without one the stack
-    is initialised like torchvision's weights=None (kaiming-normal fan_out) and a warning is issued --
-    the ImageNet file cannot be downloaded from an offline machine.
+    to torchvision's vgg19 checkpoint (keys features.N.*) or set FSR_VGG19_WEIGHTS; when torchvision is
+    installed and has the ImageNet file cached, it is used as the reference does (model.py:8).  WITHOUT ImageNet
+    weights the constructor RAISES: a perceptual loss against random features trains a silently different model.
+    The random stand-in (torchvision's weights=None initialisation, kaiming-normal fan_out) is an explicit opt-in
+    for tests and benchmarks: `seed=` or `allow_random=True`.
     """
 
-    def __init__(self, weights=None, compute_dtype=None, width_div=1, seed=None):
+    def __init__(self, weights=None, compute_dtype=None, width_div=1, seed=None, allow_random=False):
         super().__init__()
         self.compute = ops.Compute(compute_dtype or _DEFAULT_DTYPE)
         layers, cin = [], 3
@@ -181,10 +183,9 @@ class VGG19(torch.nn.Module):
             sd = torch.load(path, map_location="cpu")
             self.vgg.load_state_dict({k[len("features."):]: v for k, v in sd.items()
                                       if k.startswith("features.") and int(k.split(".")[1]) < 34})
-        else:
+        elif seed is not None or allow_random:
             if seed is None:
-                warnings.warn("VGG19: no ImageNet weights given (weights= / FSR_VGG19_WEIGHTS); using a random "
-                              "kaiming-normal stand-in of the same architecture")
+                warnings.warn("VGG19: random kaiming-normal stand-in instead of the ImageNet weights (allow_random=True)")
             gen = torch.Generator().manual_seed(1234 if seed is None else seed)
             for m in self.vgg:
                 if isinstance(m, torch.nn.Conv2d):
@@ -192,6 +193,17 @@ class VGG19(torch.nn.Module):
                         std = (2.0 / (m.out_channels * 9)) ** 0.5
                         m.weight.copy_(torch.randn(m.weight.shape, generator=gen) * std)
                         m.bias.zero_()
+        else:
+            try:        # what the reference does (model.py:8); needs torchvision and its cached / downloadable checkpoint
+                from torchvision.models.vgg import VGG19_Weights, vgg19
+                tv = vgg19(weights=VGG19_Weights.IMAGENET1K_V1).features[:34]
+                self.vgg.load_state_dict(tv.state_dict())
+            except Exception as exc:
+                raise L.FsrError(
+                    "VGG19: no ImageNet weights. Pass weights=<torchvision vgg19 checkpoint>, set FSR_VGG19_WEIGHTS or the "
+                    "config key training.vgg19_weights; the reference uses vgg19(IMAGENET1K_V1) (model.py:8) and a random "
+                    "feature network would silently train a different model. For tests / benchmarks opt in to the random "
+                    "stand-in with VGG19(seed=...) or training.allow_random_vgg=true. (torchvision: %s)" % (exc,)) from exc
         for param in self.vgg.parameters():
             param.requires_grad = False
         self.register_buffer("mean", torch.tensor([0.485, 0.456, 0.406], requires_grad=False).view(1, 3, 1, 1))

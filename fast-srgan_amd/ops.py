@@ -163,8 +163,14 @@ def _const_vec(values, device):
 
 USE_C3_KERNELS = True   # tests flip this to compare the first-layer kernels with the padded-tensor path
 
-# bench.py sets this to a list to collect (start_event, end_event, algorithmic_flops, algorithmic_bytes) per conv launch
+# bench.py sets this to a list to collect (start_event, end_event, algorithmic_flops, algorithmic_bytes, kernel name, kind)
+# per convolution launch; kind is "fwd", "dgrad" or "wgrad"
 PROFILE_CONV = None
+
+
+def _last_kernel():
+    name = L.lib().fsr_last_kernel()
+    return name.decode() if name else "?"
 
 
 _ws_retired = []    # outgrown scratch buffers: captured hipGraphs may still hold their addresses, so they are never freed
@@ -272,7 +278,7 @@ def conv3x3_raw(cd, x, wpk, cout, *, mode=L.CONV_FWD, out_hw=None, stride=1, bia
         k = cin if alg_k is None else alg_k
         pix = oh * ow if mode == L.CONV_FWD else ih * iw      # dgrad: one MAC per forward MAC
         nbytes = x.numel() * x.element_size() + out.numel() * out.element_size() + wpk.numel() * wpk.element_size()
-        prof.append((ev0, ev1, 2.0 * n * pix * cout * k * 9, nbytes))
+        prof.append((ev0, ev1, 2.0 * n * pix * cout * k * 9, nbytes, _last_kernel(), "fwd" if mode == L.CONV_FWD else "dgrad"))
     return out, pre, stats
 
 
@@ -289,7 +295,15 @@ def conv3x3_wgrad_raw(cd, x, dy, cout, cin, stride, dy_pixel_shuffled=False, out
         L.check(-2, "fsr_conv3x3_wgrad_workspace")
     ws = _workspace(need, x.device)
     dw = out if out is not None else torch.zeros((cout, cin, 3, 3), dtype=torch.float32, device=x.device)
+    prof = PROFILE_CONV
+    if prof is not None:
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        ev0.record()
     L.check(L.lib().fsr_conv3x3_wgrad(ctypes.byref(d), _p(x), _p(dy), _p(dw), _p(ws), _stream()), "fsr_conv3x3_wgrad")
+    if prof is not None:
+        ev1.record()
+        nbytes = x.numel() * x.element_size() + dy.numel() * dy.element_size() + cout * cin * 9 * 4
+        prof.append((ev0, ev1, 2.0 * n * oh * ow * cout * cin * 9, nbytes, "conv_wgrad_kernel", "wgrad"))
     return dw
 
 
@@ -401,7 +415,7 @@ class Conv3x3Fn(torch.autograd.Function):
         if prof is not None:
             ev1.record()
             nbytes = x.numel() * 4 + out.numel() * out.element_size() * (2 if want_pre else 1) + wpk.numel() * wpk.element_size()
-            prof.append((ev0, ev1, 2.0 * n * h * w * cout * 27, nbytes))
+            prof.append((ev0, ev1, 2.0 * n * h * w * cout * 27, nbytes, "conv_c3_fwd_kernel", "fwd"))
         ctx.cfg = cfg
         ctx.c3 = True
         ctx.bias_param = bias
@@ -682,3 +696,19 @@ def bce_with_logits(x, t):
 
 def smooth_l1(a, b):
     return SmoothL1Fn.apply(a, b)
+
+
+# ---------------------------------------------------------------------------------- validation metrics
+def ssim_sse(a, b):
+    """Per-image (sum of the SSIM map, sum of squared errors) of two (N,3,H,W) float32 batches in [-1,1], any strides
+    (fsr_ssim_sse; torchmetrics' SSIM / PSNR defaults on (1+x)/2, trainer.py:46-69).  Returns a float32 (N,2) tensor."""
+    _check_dev(a, b)
+    if a.shape != b.shape or a.dim() != 4 or a.shape[1] != 3:
+        raise ValueError("ssim_sse expects two (N,3,H,W) batches of one shape, got %s and %s" % (tuple(a.shape), tuple(b.shape)))
+    a = a if a.dtype == torch.float32 else a.float()
+    b = b if b.dtype == torch.float32 else b.float()
+    n, _, h, w = a.shape
+    out = torch.empty((n, 2), dtype=torch.float32, device=a.device)
+    scr = _workspace(L.lib().fsr_ssim_sse_scratch(n, h, w), a.device)
+    L.check(L.lib().fsr_ssim_sse(_p(a), *a.stride(), _p(b), *b.stride(), n, h, w, _p(out), _p(scr), _stream()), "fsr_ssim_sse")
+    return out

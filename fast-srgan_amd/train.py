@@ -51,7 +51,7 @@ def main(argv=None):
     numpy_files = sorted(os.path.join(config.data.numpy_dir, x) for x in os.listdir(config.data.numpy_dir) if x.endswith(".npy"))
     dataset = NumpyImagesDataset(numpy_files, config.data.lr_image_size, config.data.scale_factor, device=config.training.device)
     bs = config.training.batch_size
-    val = DeviceBatchLoader(dataset, bs, max(1, len(dataset) // bs), seed=config.experiment.seed + 7919 * (rank + 1))
+    val = DeviceBatchLoader(dataset, bs, seed=config.experiment.seed + 7919 * (rank + 1), sequential=True)   # train.py:81-91
     pre = DeviceBatchLoader(dataset, bs, config.training.pretrain_iterations, seed=config.experiment.seed + rank)
     trn = DeviceBatchLoader(dataset, bs, config.training.iterations, seed=config.experiment.seed + 104729 * (rank + 1))
     trainer = Trainer(config)

@@ -48,6 +48,8 @@ typedef void* fsr_stream_t; /* hipStream_t */
 
 int fsr_version(void);
 const char* fsr_last_error(void);
+/* Name of the kernel configuration the calling thread's most recent fsr_conv3x3 dispatched (profiling aid). */
+const char* fsr_last_kernel(void);
 /* "name=<marketing name>;arch=<gcnArchName>;cus=<n>;hbm_bytes=<n>" of the current device. */
 int fsr_device_info(char* buf, size_t buflen);
 
@@ -223,6 +225,19 @@ int fsr_smooth_l1_fwd(int dtype, const void* a, const void* b, float* loss, void
                       fsr_stream_t stream);
 int fsr_smooth_l1_bwd(int dtype, const void* a, const void* b, const float* gscale, void* da, long long count,
                       fsr_stream_t stream);
+
+/* ------------------------------------------------------------------ validation metrics (trainer.py:46-69)
+ * torchmetrics' SSIM (gaussian 11x11, sigma 1.5, data_range 1.0, k1 .01, k2 .03; reflect padding + crop = only windows
+ * entirely inside the image) and the squared error PSNR needs, for images a, b given in [-1,1] (the kernel applies
+ * trainer.py:63-65's (1 + x) / 2): float tensors of logical shape [n,3,h,w] with element strides (sn,sc,sh,sw) each --
+ * the generator's NHWC head output and the NCHW HR batch are both read in place.
+ * out[n][2] = (sum over channels and valid pixels of the SSIM map, sum of squared errors over all pixels):
+ *   SSIM_i = out[i][0] / (3 (h-10)(w-10));  PSNR = 10 log10(1 / (sum_i out[i][1] / (3 n h w))).
+ * scratch: fsr_ssim_sse_scratch(n,h,w) bytes.  h, w > 10. */
+size_t fsr_ssim_sse_scratch(int n, int h, int w);
+int fsr_ssim_sse(const float* a, long long asn, long long asc, long long ash, long long asw, const float* b,
+                 long long bsn, long long bsc, long long bsh, long long bsw, int n, int h, int w, float* out,
+                 void* scratch, fsr_stream_t stream);
 
 /* ------------------------------------------------------------------ AdamW (trainer.py:33-38, torch defaults)
  * One fused step over a flat float parameter arena: g' = g*grad_scale (1/world_size after a SUM all-reduce);

@@ -245,3 +245,38 @@ def postprocess_u8(sr):
     y = (sr + 1.0) / 2.0
     y = y.permute(0, 2, 3, 1).squeeze()
     return (y * 255).numpy().astype(np.uint8)
+
+
+# ---------------------------------------------------------------------------------- validation metrics (trainer.py:46-69)
+# torchmetrics (pinned 1.4.0 in the reference's Pipfile) is NOT installed here and cannot be fetched: the two metrics are
+# restated from its published algorithm (functional/image/ssim.py::_ssim_update, functional/image/psnr.py) -- parity
+# UNPINNED at the torchmetrics boundary (no golden vector of the real package exists in the reference or here).
+def ssim_per_image(preds, target, data_range=1.0, sigma=1.5, k1=0.01, k2=0.03):
+    """StructuralSimilarityIndexMeasure(data_range=1.0, reduction="none") on (N,C,H,W) batches in [0,1] (trainer.py:46-48):
+    gaussian window of size int(3.5 sigma + .5) * 2 + 1 = 11, reflect padding by 5, five depthwise convolutions, clamped
+    variances, crop by 5, mean over (C, H-10, W-10) per image."""
+    c1, c2 = (k1 * data_range) ** 2, (k2 * data_range) ** 2
+    ks = int(3.5 * sigma + 0.5) * 2 + 1
+    pad = (ks - 1) // 2
+    dist = torch.arange((1 - ks) / 2, (1 + ks) / 2, 1, dtype=preds.dtype)
+    g = torch.exp(-torch.pow(dist / sigma, 2) / 2)
+    g = (g / g.sum()).unsqueeze(0)
+    ch = preds.shape[1]
+    kernel = torch.matmul(g.t(), g).expand(ch, 1, ks, ks)
+    p = F.pad(preds, (pad, pad, pad, pad), mode="reflect")
+    t = F.pad(target, (pad, pad, pad, pad), mode="reflect")
+    outs = F.conv2d(torch.cat((p, t, p * p, t * t, p * t)), kernel, groups=ch).split(preds.shape[0])
+    mu_pp, mu_tt, mu_pt = outs[0].pow(2), outs[1].pow(2), outs[0] * outs[1]
+    s_pp = torch.clamp(outs[2] - mu_pp, min=0.0)
+    s_tt = torch.clamp(outs[3] - mu_tt, min=0.0)
+    s_pt = outs[4] - mu_pt
+    full = ((2 * mu_pt + c1) * (2 * s_pt + c2)) / ((mu_pp + mu_tt + c1) * (s_pp + s_tt + c2))
+    return full[..., pad:-pad, pad:-pad].reshape(preds.shape[0], -1).mean(-1)
+
+
+def psnr_global(batches, data_range=1.0):
+    """PeakSignalNoiseRatio(data_range=1.0, reduction="none"), dim=None (trainer.py:49-51): the squared error and the
+    element count accumulate over every update; one global 10 log10(range^2 / mse).  `batches`: [(preds, target), ...]."""
+    sse = sum(float(((p.double() - t.double()) ** 2).sum()) for p, t in batches)
+    n = sum(t.numel() for _, t in batches)
+    return 10.0 * math.log10(data_range ** 2 / (sse / n))

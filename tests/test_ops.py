@@ -485,3 +485,28 @@ def test_reductions_are_bit_reproducible(cdn):
     for _ in range(4):
         for a, b in zip(first, run()):
             assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize("shape", [(2, 23, 37), (1, 45, 64), (3, 12, 12)])
+def test_ssim_and_squared_error_vs_torchmetrics_restatement(dev, shape):
+    """fsr_ssim_sse (trainer.py:46-69's SSIM / PSNR inputs in one kernel) vs the oracle's restatement of torchmetrics'
+    defaults; `a` is an NHWC-strided view like the generator's output, `b` plain NCHW."""
+    n, h, w = shape
+    if _big(dev):
+        n, h, w = n + 2, h * 5 + 3, w * 4 + 1
+    torch.manual_seed(21)
+    b = torch.rand(n, 3, h, w) * 2 - 1
+    a = (b + 0.2 * torch.randn(n, 3, h, w)).clamp(-1, 1)
+    a_nhwc = a.permute(0, 2, 3, 1).contiguous().to(dev).permute(0, 3, 1, 2)
+    r = ops.ssim_sse(a_nhwc, b.to(dev)).cpu()
+    pa, pb = (1 + a) / 2, (1 + b) / 2
+    want_ssim = O.ssim_per_image(pa, pb)
+    got_ssim = r[:, 0] / (3 * (h - 10) * (w - 10))
+    assert (got_ssim - want_ssim).abs().max() < 2e-5, (got_ssim, want_ssim)
+    want_sse = ((pa.double() - pb.double()) ** 2).sum((1, 2, 3))
+    assert ((r[:, 1].double() - want_sse).abs() / want_sse).max() < 1e-5
+    psnr = 10 * torch.log10(1.0 / (r[:, 1].double().sum() / b.numel()))
+    assert abs(float(psnr) - O.psnr_global([(pa, pb)])) < 1e-4
+    # identical images: SSIM exactly 1 (the clamped variances keep the ratio at (x)(y)/((x)(y)))
+    r1 = ops.ssim_sse(b.to(dev), b.to(dev)).cpu()
+    assert (r1[:, 0] / (3 * (h - 10) * (w - 10)) - 1).abs().max() < 1e-6 and float(r1[:, 1].abs().max()) == 0.0
