@@ -8,19 +8,27 @@ A "step" is one full GAN training iteration (/root/reference/trainer.py:171-196:
 perceptual loss and both AdamW updates) over one synthetic batch that is already resident in HBM
 (BASELINE.json configs[2]: 8 residual blocks / 64 filters, batch 32 per GPU, 96x96 -> 384x384, bf16 MFMA with
 f32 accumulation, random-init weights, kaiming-normal VGG19 stand-in).  N > 1 shards by batch (weak scaling):
-one process per GPU, two RCCL gradient all-reduces per step.  Rank 0 prints ONE JSON line.
+one process per GPU, two RCCL gradient all-reduces per step; `python bench.py --gpus N` without a launcher
+re-executes itself under torch.distributed.run.  Rank 0 prints ONE JSON line.
 
 Extra keys of that line:
-  roofline      the dominant kernel (the implicit-GEMM 3x3 convolution, forward + data-gradient launches):
-                algorithmic FLOPs per launch / average launch duration measured with HIP events on the launch
-                stream during an instrumented step, against the dense bf16 MFMA peak (2.5 PFLOP/s);
+  roofline      the implicit-GEMM 3x3 convolution family (forward + data-gradient launches): algorithmic FLOPs per launch /
+                average launch duration measured with HIP events on the launch stream during an instrumented step, against
+                the dense MFMA peak; `dominant` repeats that for the single kernel configuration with the largest share
+                of the time; `traffic` = HBM bytes per launch from the rocprofv3 PMC passes recorded in
+                profiles/conv_traffic.json (null when that file does not belong to the kernel sources being run);
+  f32_mode      the same iteration in the exact-f32 MFMA parity mode (short run): the precision the reference computes in;
   cpu_baseline  the oracle's CPU restatement of the same iteration, timed on the host cores (N=1, rank 0);
-  inference     generator-only FPS at 90x160 and 180x320 (BASELINE.json configs[1]), batch 1 and batch 32.
+  inference     generator-only FPS at 90x160 and 180x320 (BASELINE.json configs[1]), batch 1 and batch 32, plus the
+                end-to-end rate of the uint8 frame pipeline (host bytes -> H2D -> G -> uint8 epilogue -> D2H).
 """
 import argparse
+import hashlib
 import importlib
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 import types
@@ -32,10 +40,8 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 MFMA_PEAK_TFLOPS = {"bf16": 2500.0, "f32": 157.3}   # /opt/skills/guides/MI355X_MICROARCH.md, dense
-STEP_GFLOP_PER_IMAGE = 686.71                         # BASELINE.md section 2, as the reference graph executes it
-# HBM bytes per conv launch (forward + data-gradient calls of one iteration, batch 32, bf16) from the PMC counters:
-# 117 launches per iteration x (2 x 114777 KB FETCH_SIZE + 198516 KB WRITE_SIZE) (tools/gpu_pmc_step.sh, tools/pmc_traffic.py)
-CONV_HBM_BYTES_PER_LAUNCH = 4.38e8
+STEP_GFLOP_PER_IMAGE = 686.71                         # BASELINE.md section 2, as the REFERENCE graph executes it
+TRAFFIC_FILE = os.path.join(ROOT, "profiles", "conv_traffic.json")
 
 
 def ns(**k):
@@ -49,9 +55,20 @@ def make_config(batch, dtype, device):
                           discriminator_lr=1e-4, batch_size=batch, compute_dtype=dtype))
 
 
+def kernel_sources_hash():
+    """sha256 over the kernel sources: ties profiles/conv_traffic.json (PMC passes) to the code being benchmarked."""
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "fast-srgan_amd", "csrc")
+    for f in sorted(os.listdir(d)):
+        if f.endswith((".hip", ".h")):
+            h.update(f.encode())
+            h.update(open(os.path.join(d, f), "rb").read())
+    return h.hexdigest()[:16]
+
+
 def conv_profile(ops, fn):
-    """Runs fn() with every conv3x3 forward/dgrad launch bracketed by HIP events on the launch stream.
-    Returns (launches, total_ms, total_flops, total_algorithmic_bytes)."""
+    """Runs fn() with every convolution launch bracketed by HIP events on the launch stream.
+    Returns the records (ms, flops, algorithmic bytes, kernel name, kind)."""
     rec = []
     ops.PROFILE_CONV = rec
     try:
@@ -59,8 +76,7 @@ def conv_profile(ops, fn):
         torch.cuda.synchronize()
     finally:
         ops.PROFILE_CONV = None
-    ms = sum(r[0].elapsed_time(r[1]) for r in rec)
-    return len(rec), ms, sum(r[2] for r in rec), sum(r[3] for r in rec)
+    return [(r[0].elapsed_time(r[1]), r[2], r[3], r[4], r[5]) for r in rec]
 
 
 def cpu_baseline():
@@ -97,6 +113,55 @@ def cpu_baseline():
                       "1 warm-up + %d timed iterations, %.2f s each" % (b, iters, dt)}
 
 
+def respawn_under_launcher(args):
+    """`python bench.py --gpus N` (N > 1) without RANK/WORLD_SIZE: run the same command under torch.distributed.run, one
+    process per GPU, and relay rank 0's JSON line."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    return subprocess.call(cmd, env=env)
+
+
+def time_steps(step_fn, lr, hr, steps, warmup, world, device):
+    def barrier():
+        if world > 1:
+            torch.distributed.barrier()
+
+    for _ in range(warmup):
+        step_fn(lr, hr)
+    torch.cuda.synchronize()
+    barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step_fn(lr, hr)
+    torch.cuda.synchronize()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], device=device, dtype=torch.float64)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        elapsed = float(t.item())
+    return elapsed
+
+
+def build_step(pkg, trainer, lr, hr, use_graph):
+    """(step function, launch description)."""
+    if use_graph:
+        try:
+            trainer.capture_train_step(lr, hr)
+            n = len(trainer._graphs)
+            return trainer.graphed_train_step, ("hipGraph replay" if n == 1 else "%d phase hipGraphs + 2 RCCL all-reduces" % n)
+        except Exception as exc:  # noqa: BLE001 -- fall back to eager launches and say so in the JSON line
+            print("bench: hipGraph capture failed (%s: %s); running eager" % (type(exc).__name__, exc), file=sys.stderr)
+            torch.cuda.synchronize()
+    return trainer.train_step, "eager"
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -106,8 +171,12 @@ def main():
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-inference", action="store_true")
-    ap.add_argument("--no-graph", action="store_true", help="eager launches instead of one hipGraph replay per step (N=1)")
+    ap.add_argument("--no-f32", action="store_true", help="skip the short exact-f32 run")
+    ap.add_argument("--no-graph", action="store_true", help="eager launches instead of hipGraph replays")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(respawn_under_launcher(args))
 
     pkg = importlib.import_module("fast-srgan_amd")
     ops = importlib.import_module("fast-srgan_amd.ops")
@@ -119,67 +188,70 @@ def main():
     device = "cuda:%d" % local_rank
     pkg._lib.lib()  # fail loudly if the HIP extension is missing
     if world != args.gpus:
-        raise SystemExit("--gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run)" % (args.gpus, world))
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
 
     torch.manual_seed(1234)
-    with warnings.catch_warnings():
-        warnings.simplefilter("ignore")
-        trainer = pkg.Trainer(make_config(args.batch, args.dtype, device))
+    trainer = pkg.Trainer(make_config(args.batch, args.dtype, device), perceptual_network=pkg.VGG19(compute_dtype=args.dtype, seed=1234))
     torch.manual_seed(100 + rank)
     B = args.batch
     lr = torch.rand(B, 3, 96, 96, device=device) * 2 - 1
     hr = torch.rand(B, 3, 384, 384, device=device) * 2 - 1
 
-    def barrier():
-        if world > 1:
-            torch.distributed.barrier()
-
-    step_fn, graphed = trainer.train_step, False
-    if world == 1 and not args.no_graph:
-        try:
-            trainer.capture_train_step(lr, hr)
-            step_fn, graphed = trainer.graphed_train_step, True
-        except Exception as exc:  # noqa: BLE001 -- fall back to eager launches and say so in the JSON line
-            print("bench: hipGraph capture failed (%s: %s); running eager" % (type(exc).__name__, exc), file=sys.stderr)
-            torch.cuda.synchronize()
-    for _ in range(args.warmup):
-        step_fn(lr, hr)
-    torch.cuda.synchronize()
-    barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step_fn(lr, hr)
-    torch.cuda.synchronize()
-    barrier()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([elapsed], device=device, dtype=torch.float64)
-        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
-        elapsed = float(t.item())
+    step_fn, launch = build_step(pkg, trainer, lr, hr, not args.no_graph)
+    elapsed = time_steps(step_fn, lr, hr, args.steps, args.warmup, world, device)
     ms_per_step = elapsed / args.steps * 1e3
     value = world * B * args.steps / elapsed
 
-    # ---- roofline of the dominant kernel: one instrumented iteration (outside the timed region)
+    # ---- roofline of the dominant kernel family: one instrumented iteration (outside the timed region)
     # (single-stream: with the perceptual branch and the weight gradients on their own streams, kernels of several
     # streams share the GPU and an event pair around one launch would also time its neighbours)
     side, wstream = trainer.use_side_stream, ops.USE_WGRAD_STREAM
     trainer.use_side_stream = False
     ops.USE_WGRAD_STREAM = False
     trainer.train_step(lr, hr)
-    launches, conv_ms, conv_flops, conv_bytes = conv_profile(ops, lambda: trainer.train_step(lr, hr))
+    rec = conv_profile(ops, lambda: trainer.train_step(lr, hr))
     trainer.use_side_stream, ops.USE_WGRAD_STREAM = side, wstream
-    achieved = conv_flops / (conv_ms * 1e-3) / 1e12 if conv_ms > 0 else 0.0
     peak = MFMA_PEAK_TFLOPS[args.dtype]
-    roofline = {"bound": "mfma", "kernel": "conv_igemm_kernel / conv64_persistent_kernel (3x3 conv forward + data-gradient launches)",
+    conv = [r for r in rec if r[4] in ("fwd", "dgrad")]
+    wgr = [r for r in rec if r[4] == "wgrad"]
+    launches = len(conv)
+    conv_ms, conv_flops, conv_bytes = sum(r[0] for r in conv), sum(r[1] for r in conv), sum(r[2] for r in conv)
+    achieved = conv_flops / (conv_ms * 1e-3) / 1e12 if conv_ms > 0 else 0.0
+    by_kernel = {}
+    for ms, fl, by, name, _ in conv:
+        e = by_kernel.setdefault(name, [0, 0.0, 0.0, 0.0])
+        e[0] += 1
+        e[1] += ms
+        e[2] += fl
+        e[3] += by
+    dom_name, dom = max(by_kernel.items(), key=lambda kv: kv[1][1]) if by_kernel else ("?", [0, 1.0, 0.0, 0.0])
+    dom_tf = dom[2] / (dom[1] * 1e-3) / 1e12 if dom[1] > 0 else 0.0
+    traffic, traffic_src = None, "no PMC record for these kernel sources (profiles/conv_traffic.json)"
+    if os.path.exists(TRAFFIC_FILE):
+        try:
+            t = json.load(open(TRAFFIC_FILE))
+            if t.get("kernel_sources_sha16") == kernel_sources_hash() and t.get("dtype") == args.dtype and t.get("batch") == B:
+                traffic = t["bytes_per_launch"]
+                traffic_src = ("rocprofv3 --pmc FETCH_SIZE (x2, gfx950 correction) + WRITE_SIZE over one iteration (%s), "
+                               "recorded in profiles/conv_traffic.json for kernel sources %s" % (t.get("files", "?"), t["kernel_sources_sha16"]))
+            else:
+                traffic_src = "profiles/conv_traffic.json was recorded for other kernel sources / another workload: not quoted"
+        except (OSError, ValueError, KeyError):
+            pass
+    roofline = {"bound": "mfma", "kernel": "3x3 convolution forward + data-gradient launches (conv_igemm_kernel / conv64_persistent_kernel family)",
                 "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(achieved / peak, 4),
-                "traffic": CONV_HBM_BYTES_PER_LAUNCH if (args.dtype == "bf16" and B == 32) else None,
-                "traffic_source": "rocprofv3 --pmc FETCH_SIZE (x2, gfx950 correction) + WRITE_SIZE over one iteration, "
-                                  "profiles/r01_pmc_*_train_step.csv",
+                "traffic": traffic, "traffic_source": traffic_src,
                 "algorithmic_bytes_per_launch": round(conv_bytes / max(launches, 1)), "launches_per_step": launches,
                 "avg_launch_us": round(conv_ms * 1e3 / max(launches, 1), 2),
                 "algorithmic_gflop_per_launch": round(conv_flops / max(launches, 1) / 1e9, 3),
-                "share_of_step_time": round(conv_ms / ms_per_step, 3)}
+                "share_of_step_time": round(conv_ms / ms_per_step, 3),
+                "dominant": {"kernel": dom_name, "launches_per_step": dom[0], "avg_launch_us": round(dom[1] * 1e3 / max(dom[0], 1), 2),
+                             "achieved": round(dom_tf, 2), "frac": round(dom_tf / peak, 4),
+                             "share_of_conv_time": round(dom[1] / conv_ms, 3) if conv_ms > 0 else None,
+                             "algorithmic_bytes_per_launch": round(dom[3] / max(dom[0], 1))},
+                "weight_gradient": {"launches_per_step": len(wgr), "achieved": round(sum(r[1] for r in wgr) / max(sum(r[0] for r in wgr), 1e-9) / 1e9, 2),
+                                    "unit": "TFLOP/s", "ms_per_step": round(sum(r[0] for r in wgr), 3)}}
+    executed_gflop_per_image = sum(r[1] for r in rec) / B / 1e9
 
     out = {"metric": "SR train-step images/sec (96->384 4x, full GAN step: G+D+VGG perceptual loss)",
            "value": round(value, 3), "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -187,11 +259,27 @@ def main():
            "dtype": args.dtype, "data": "synthetic (uniform [-1,1) LR/HR tensors resident in HBM; random-init G/D, kaiming-normal VGG19 stand-in)",
            "config": {"workload": "BASELINE configs[2]: full GAN training step, 8 residual blocks / 64 filters, 96x96->384x384",
                       "per_gpu_batch": B, "global_batch": B * world, "parallelism": "dp%d" % world,
-                      "launch": "hipGraph replay" if graphed else "eager"},
-           "step_tflops_equiv": round(value * STEP_GFLOP_PER_IMAGE / 1e3, 2),
+                      "collectives": ("rccl world %d" % torch.distributed.get_world_size()) if dist_mod.is_distributed() else "none",
+                      "launch": launch},
+           "step_gflop_executed_per_image": round(executed_gflop_per_image, 2),
+           "step_tflops_executed": round(value * executed_gflop_per_image / 1e3, 2),
+           "step_gflop_reference_graph_per_image": STEP_GFLOP_PER_IMAGE,
            "roofline": roofline}
 
+    if rank == 0 and world == 1 and not args.no_f32 and args.dtype != "f32":
+        # the same iteration at the reference's own precision (exact-f32 MFMA: the 1e-3 parity mode), short run
+        del step_fn
+        torch.manual_seed(1234)
+        t32 = pkg.Trainer(make_config(B, "f32", device), perceptual_network=pkg.VGG19(compute_dtype="f32", seed=1234))
+        fn32, launch32 = build_step(pkg, t32, lr, hr, not args.no_graph)
+        el = time_steps(fn32, lr, hr, 2, 1, 1, device)
+        out["f32_mode"] = {"value": round(B * 2 / el, 3), "unit": "images/s", "ms_per_step": round(el / 2 * 1e3, 2), "steps": 2,
+                           "warmup": 1, "launch": launch32, "dtype": "f32 (v_mfma_f32_16x16x4_f32, exact fmaf chains)"}
+        del t32, fn32
+        torch.cuda.empty_cache()
+
     if rank == 0 and not args.no_inference:
+        import numpy as np
         inf = {}
         with torch.no_grad():
             G = trainer.generator.eval()
@@ -213,10 +301,24 @@ def main():
                     torch.cuda.synchronize()
                     inf["fps_%s_b%d" % (name, bsz)] = round(bsz * iters / (time.perf_counter() - t0), 2)
             inf["launch"] = "hipGraph replay" if run is not G else "eager"
+            # end to end: uint8 frames in host memory -> H2D -> generator (uint8 head epilogue) -> D2H -> host arrays
+            rng = np.random.default_rng(0)
+            for name, (h, w) in (("90x160", (90, 160)), ("180x320", (180, 320))):
+                for bsz in (1, 8):
+                    frames = [rng.integers(0, 256, size=(h, w, 3), dtype=np.uint8) for _ in range(16 if bsz == 1 else 64)]
+                    pipe = pkg.InferencePipeline(G, device, batch=bsz, depth=2)
+                    for _ in pipe.run(frames[:2 * bsz]):
+                        pass
+                    reps = 4
+                    t0 = time.perf_counter()
+                    count = 0
+                    for _ in range(reps):
+                        for _y in pipe.run(frames):
+                            count += 1
+                    inf["e2e_fps_%s_b%d" % (name, bsz)] = round(count / (time.perf_counter() - t0), 2)
+            inf["e2e"] = "InferencePipeline: pinned uint8 frames -> H2D -> hipGraph(u8->[-1,1], G, uint8 head) -> D2H -> numpy, depth 2"
         out["inference"] = inf
-    if rank == 0 and not args.no_inference:
         # device crop pipeline (dataloader.py:24-38 replacement): 96 -> 384 crops cut from a resident uint8 pool
-        import numpy as np
         import tempfile
         with tempfile.TemporaryDirectory() as td:
             rng = np.random.default_rng(0)
@@ -242,7 +344,7 @@ def main():
         torch.distributed.barrier()
     if rank == 0:
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if dist_mod.is_distributed():
         torch.distributed.destroy_process_group()
 
 

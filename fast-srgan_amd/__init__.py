@@ -6,9 +6,10 @@ The directory name carries a hyphen (it mirrors the upstream repository name), s
 from . import _lib  # noqa: F401
 from .config import load_config  # noqa: F401
 from .dataloader import DeviceBatchLoader, NumpyImagesDataset  # noqa: F401
+from .inference import InferencePipeline  # noqa: F401
 from .model import VGG19, Discriminator, Generator, GraphedGenerator  # noqa: F401
 from .optim import ArenaAdamW  # noqa: F401
 from .trainer import Trainer  # noqa: F401
 
 __all__ = ["Generator", "GraphedGenerator", "Discriminator", "VGG19", "Trainer", "NumpyImagesDataset", "DeviceBatchLoader", "ArenaAdamW",
-           "load_config"]
+           "load_config", "InferencePipeline"]

@@ -16,6 +16,7 @@ FSR_F32, FSR_BF16 = 0, 1
 ACT_NONE, ACT_RELU, ACT_LEAKY, ACT_PRELU, ACT_TANH = 0, 1, 2, 3, 4
 CONV_FWD, CONV_DGRAD = 0, 1
 PACK_FWD, PACK_FWD_PS, PACK_DGRAD, PACK_DGRAD_PS = 0, 1, 2, 3
+OUT_DTYPE, OUT_F32, OUT_U8 = 0, 1, 2
 ABI_VERSION = 6
 
 c_int, c_float, c_void_p, c_size_t, c_ll = ctypes.c_int, ctypes.c_float, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_longlong
@@ -62,6 +63,7 @@ SIGNATURES = {
     "fsr_act_bwd": (c_int, [c_int, P, P, c_int, c_float, P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, P]),
     "fsr_image_to_nhwc": (c_int, [c_int, P, c_ll, c_ll, c_ll, c_ll, c_int, c_int, c_int, c_float, c_float, c_float,
                                   c_float, c_float, c_float, P, c_int, P]),
+    "fsr_u8_to_image": (c_int, [P, P, c_ll, P]),
     "fsr_pack_conv3x3_c3": (c_int, [c_int, P, c_int, P, P]),
     "fsr_conv3x3_c3_fwd": (c_int, [c_int, P, c_ll, c_ll, c_ll, c_ll, c_int, c_int, c_int, c_float, c_float, c_float, c_float,
                                    c_float, c_float, P, P, c_int, c_float, P, c_int, P, P, P]),

@@ -200,7 +200,8 @@ __global__ __launch_bounds__(NTHR64, 2) void conv64_persistent_kernel(const Conv
             if (lg * 4 + r < a.Cout) {
               float v = acc[m][0][r] * oscale[r] + bias[0][r];
               v = (a.act == FSR_ACT_TANH) ? tanhf(v) : (v > 0.f ? v : v * slope);
-              ((float*)a.out)[off + r] = v;
+              if (a.out_f32 == FSR_OUT_U8) ((unsigned char*)a.out)[off + r] = image_u8(v);   // HWC uint8 image (inference)
+              else ((float*)a.out)[off + r] = v;
             }
         }
       }

@@ -408,7 +408,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv_igemm_kernel(const ConvK
   const int gyb = gy0 + wm * MT;            // first grid row of this wave
   const int cob = nb * BN + wn * NT * 16 + lg * 4;  // first of this lane's channels (tile n adds 16 n)
   const bool col_ok = gx < a.GW;
-  if (BN == 16 && ((a.out_f32 && sizeof(T) == 2) || a.Cout % 16 != 0)) {  // only the 16-wide configs carry this code
+  if (BN == 16 && ((a.out_f32 && sizeof(T) == 2) || a.Cout % 16 != 0 || a.out_f32 == FSR_OUT_U8)) {  // only the 16-wide configs carry this code
     // ---- thin / float path (memory-bound layers): per-element guards, optional scale, tanh
     static_for<0, NT>([&](auto nc) {
       constexpr int n = decltype(nc)::value;
@@ -425,7 +425,8 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv_igemm_kernel(const ConvK
               if (a.oscale) v *= a.oscale[co + r];
               if (a.bias) v += a.bias[co + r];
               v = (a.act == FSR_ACT_TANH) ? tanhf(v) : (v > 0.f ? v : v * slope);
-              if (a.out_f32 || sizeof(T) == 4) ((float*)a.out)[off + r] = v;
+              if (a.out_f32 == FSR_OUT_U8) ((unsigned char*)a.out)[off + r] = image_u8(v);
+              else if (a.out_f32 || sizeof(T) == 4) ((float*)a.out)[off + r] = v;
               else ((bf16_t*)a.out)[off + r] = f2bf(v);
             }
         }

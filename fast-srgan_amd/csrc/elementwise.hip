@@ -365,6 +365,12 @@ __global__ __launch_bounds__(256) void tanh_bwd_to_nhwc_kernel(const float* __re
   }
 }
 
+// uint8 frames -> float in [-1,1]: x / 127.5 - 1 (inference.py:48; correctly rounded f32 division, as torch's)
+__global__ __launch_bounds__(256) void u8_to_image_kernel(const unsigned char* __restrict__ src, float* __restrict__ dst, long long count) {
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < count; i += (long long)gridDim.x * 256)
+    dst[i] = (float)src[i] / 127.5f - 1.0f;
+}
+
 // ------------------------------------------------------------------ MaxPool2d(2,2)
 // Grid = (output rows n*oh, column blocks); 32-bit index arithmetic per row.
 template <typename T>
@@ -559,6 +565,14 @@ extern "C" int fsr_image_to_nhwc(int dtype, const float* img, long long sn, long
                                            img, sn, sc, sh, sw, h, w, scale0, scale1, scale2, shift0, shift1, shift2,
                                            P<T>(out), cpad);)
   return fsr_check_launch("image_to_nhwc_kernel");
+}
+
+extern "C" int fsr_u8_to_image(const uint8_t* frames, float* img, long long count, fsr_stream_t stream_) {
+  if (!frames || !img || count <= 0) return fsr_fail(-1, "fsr_u8_to_image: bad argument");
+  long long blocks = (count + 1023) / 1024;
+  if (blocks > 2048) blocks = 2048;
+  hipLaunchKernelGGL(u8_to_image_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream_, frames, img, count);
+  return fsr_check_launch("u8_to_image_kernel");
 }
 
 extern "C" size_t fsr_tanh_bwd_scratch(void) { return (size_t)512 * 64 * 3 * sizeof(float); }

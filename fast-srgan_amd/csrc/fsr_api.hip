@@ -95,6 +95,9 @@ extern "C" int fsr_conv3x3(const fsr_conv_desc* d, const void* in, const void* p
   a.ps = d->pixel_shuffle;
   a.in_ps = d->in_pixel_shuffled;
   a.out_f32 = d->out_f32;
+  if (d->out_f32 < 0 || d->out_f32 > FSR_OUT_U8) return fsr_fail(-2, "fsr_conv3x3: unknown output kind %d", d->out_f32);
+  if (d->out_f32 == FSR_OUT_U8 && (d->act != FSR_ACT_TANH || d->cout > 16 || d->pixel_shuffle || d->mode != FSR_CONV_FWD))
+    return fsr_fail(-2, "fsr_conv3x3: uint8 image output is for tanh heads (forward, cout <= 16)");
   if (a.ps && stats) return fsr_fail(-2, "fsr_conv3x3: statistics are not available together with pixel shuffle");
   if ((stats || preact || dact_mask) && (d->cout % 16 != 0 || (d->out_f32 && d->dtype != FSR_F32)))
     return fsr_fail(-2, "fsr_conv3x3: statistics / pre-activation / mask tensors need cout %% 16 == 0 and a `dtype` output");

@@ -80,6 +80,13 @@ __device__ __forceinline__ float act_apply(float v, int act, float slope) {
   }
 }
 
+// inference.py:53-56 on one head output y = tanh(z) in (-1,1): ((y + 1) / 2) * 255 in f32, then the C cast to uint8
+// (truncation toward zero; the value lies in [0, 255))
+__device__ __forceinline__ unsigned char image_u8(float y) {
+  const float w = ((y + 1.f) / 2.f) * 255.f;
+  return (unsigned char)w;
+}
+
 // sum over the 64 lanes of a wave; every lane gets the total
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll

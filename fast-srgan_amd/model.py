@@ -63,8 +63,20 @@ class Generator(torch.nn.Module):
         self._cfg_in = ops.ConvCfg(cd, stats=True)
         self._cfg_up = ops.ConvCfg(cd, act=L.ACT_PRELU, pixel_shuffle=True)
         self._cfg_head = ops.ConvCfg(cd, tanh_head=True)
+        self._cfg_head_u8 = ops.ConvCfg(cd, tanh_head=True, u8_head=True)
+
+    def forward_u8(self, frames):
+        """Inference on raw frames (inference.py:47-57 without the host round trips): (N,H,W,3) uint8 in, (N,4H,4W,3) uint8
+        out.  The [-1,1] mapping (:48) is one small kernel in front of the neck; the head's epilogue applies :53-56
+        ((y+1)/2 * 255, truncating cast) and stores bytes -- a 720p frame leaves the device as 2.8 MB instead of 11 MB of
+        floats."""
+        with torch.no_grad():
+            return self._forward(ops.u8_to_image(frames), self._cfg_head_u8)
 
     def forward(self, x):
+        return self._forward(x, self._cfg_head)
+
+    def _forward(self, x, cfg_head):
         cd = self.compute
         r, _ = ops.conv3x3(x, self.neck[0].weight, self.neck[0].bias, self.neck[1].weight, self._cfg_neck)  # :113
         y = r
@@ -77,7 +89,7 @@ class Generator(torch.nn.Module):
         y = ops.instnorm_act(u, st, r, None, cd)
         for up in self.upsampling:                                                                      # :116
             y, _ = ops.conv3x3(y, up.conv.weight, up.conv.bias, up.relu.weight, self._cfg_up)
-        out, _ = ops.conv3x3(y, self.head[0].weight, self.head[0].bias, None, self._cfg_head)           # :117
+        out, _ = ops.conv3x3(y, self.head[0].weight, self.head[0].bias, None, cfg_head)                # :117
         return out
 
 

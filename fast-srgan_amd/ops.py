@@ -247,8 +247,9 @@ class _on_wgrad_stream:
 # ---------------------------------------------------------------------------------- raw launches
 def conv3x3_raw(cd, x, wpk, cout, *, mode=L.CONV_FWD, out_hw=None, stride=1, bias=None, act=L.ACT_NONE, slope=0.0,
                 prelu=None, oscale=None, pixel_shuffle=False, in_pixel_shuffled=False, out_f32=False, want_stats=False,
-                want_preact=False, alg_k=None, dact_mask=None, dact_slope=0.0):
-    """One fsr_conv3x3 launch.  x: (N,IH,IW,Cin) [or its depth-to-space form when in_pixel_shuffled]."""
+                want_preact=False, alg_k=None, dact_mask=None, dact_slope=0.0, out_u8=False):
+    """One fsr_conv3x3 launch.  x: (N,IH,IW,Cin) [or its depth-to-space form when in_pixel_shuffled].
+    out_u8 (tanh heads): the output is the finished uint8 HWC image of inference.py:53-56."""
     _check_dev(x)
     n = x.shape[0]
     if in_pixel_shuffled:
@@ -259,13 +260,13 @@ def conv3x3_raw(cd, x, wpk, cout, *, mode=L.CONV_FWD, out_hw=None, stride=1, bia
         oh, ow = (ih - 1) // stride + 1, (iw - 1) // stride + 1
     else:
         oh, ow = out_hw
-    odt = torch.float32 if out_f32 else cd.torch_dtype
+    odt = torch.uint8 if out_u8 else (torch.float32 if out_f32 else cd.torch_dtype)
     oshape = (n, 2 * oh, 2 * ow, cout // 4) if pixel_shuffle else (n, oh, ow, cout)
     out = torch.empty(oshape, dtype=odt, device=x.device)
     pre = torch.empty(oshape, dtype=odt, device=x.device) if want_preact else None
     stats = _zeros((n, cout, 2), x.device) if want_stats else None
     d = L.ConvDesc(cd.code, mode, n, ih, iw, cin, oh, ow, cout, stride, act, float(slope), int(pixel_shuffle),
-                   int(in_pixel_shuffled), int(out_f32))
+                   int(in_pixel_shuffled), L.OUT_U8 if out_u8 else int(out_f32))
     scratch = _workspace(L.lib().fsr_conv3x3_scratch(ctypes.byref(d)), x.device) if want_stats else None
     prof = PROFILE_CONV
     if prof is not None:
@@ -328,7 +329,8 @@ class ConvCfg:
 
     def __init__(self, cd, *, stride=1, act=L.ACT_NONE, slope=0.0, pixel_shuffle=False, stats=False, image_in=False,
                  in_scale=(1.0, 1.0, 1.0), in_shift=(0.0, 0.0, 0.0), tanh_head=False, input_act_bwd=None,
-                 act_bwd_by_consumer=False):
+                 act_bwd_by_consumer=False, u8_head=False):
+        # u8_head (inference only, with tanh_head): the head stores the finished uint8 HWC frame instead of float
         # input_act_bwd = slope: the data-gradient launch also applies the backward of the ReLU (0.0) / LeakyReLU
         #   that produced this conv's input (the mask is the saved input itself), so the tensor it returns is
         #   already the producer's pre-activation gradient;
@@ -339,6 +341,7 @@ class ConvCfg:
         self.cd, self.stride, self.act, self.slope = cd, stride, act, slope
         self.pixel_shuffle, self.stats, self.image_in = pixel_shuffle, stats, image_in
         self.in_scale, self.in_shift, self.tanh_head = in_scale, in_shift, tanh_head
+        self.u8_head = u8_head and tanh_head
 
 
 class Conv3x3Fn(torch.autograd.Function):
@@ -351,7 +354,11 @@ class Conv3x3Fn(torch.autograd.Function):
     """
 
     @staticmethod
-    def forward(ctx, x, weight, bias, prelu, cfg):
+    def forward(ctx, x, weight, bias, prelu, cfg, grad_on=True):
+        # grad_on: torch.is_grad_enabled() at the call site (grad mode is always off INSIDE Function.forward, and
+        # ctx.needs_input_grad reports the parameters' requires_grad even under no_grad): inference must not pay for the
+        # tensors only a backward pass reads (the pre-activation copy of the PReLU layers)
+        ctx.grad_on = grad_on
         cd = cfg.cd
         cout, cin = weight.shape[0], weight.shape[1]
         if (cfg.image_in and cfg.stride == 1 and cout % 16 == 0 and not (cfg.pixel_shuffle or cfg.stats or cfg.tanh_head)
@@ -366,13 +373,15 @@ class Conv3x3Fn(torch.autograd.Function):
                 raise L.FsrError("activation dtype %s does not match the module's compute dtype %s" % (xin.dtype, cd.name))
         cin_pad = xin.shape[3]
         wpk = packed_filter(cd, weight, L.PACK_FWD_PS if cfg.pixel_shuffle else L.PACK_FWD, cin_pad)
-        training = any(ctx.needs_input_grad)  # (grad mode is off inside Function.forward)
+        training = ctx.grad_on and any(ctx.needs_input_grad)
+        if cfg.u8_head and training:
+            raise L.FsrError("the uint8 head is an inference epilogue: it has no gradient")
         act = L.ACT_TANH if cfg.tanh_head else cfg.act
         want_pre = training and act == L.ACT_PRELU
         b32 = bias if bias is None or bias.dtype == torch.float32 else bias.float()
         out, pre, stats = conv3x3_raw(cd, xin, wpk, cout, stride=cfg.stride, bias=b32, act=act, slope=cfg.slope,
                                       prelu=prelu, pixel_shuffle=cfg.pixel_shuffle, out_f32=cfg.tanh_head,
-                                      want_stats=cfg.stats, want_preact=want_pre, alg_k=cin)
+                                      want_stats=cfg.stats, want_preact=want_pre, alg_k=cin, out_u8=cfg.u8_head)
         ctx.cfg = cfg
         ctx.dims = (cout, cin, tuple(xin.shape))
         ctx.has_bias = bias is not None
@@ -383,6 +392,8 @@ class Conv3x3Fn(torch.autograd.Function):
             stats = torch.empty(0, device=out.device)
         ctx.mark_non_differentiable(stats)
         ctx.set_materialize_grads(False)    # no zero-filled gradient tensor for the statistics output per backward call
+        if cfg.u8_head:
+            return out, stats               # (N,H,W,3) uint8: already the frame layout inference.py:55 permutes to
         if cfg.tanh_head:
             return out.permute(0, 3, 1, 2), stats
         return out, stats
@@ -399,7 +410,7 @@ class Conv3x3Fn(torch.autograd.Function):
             raise ValueError("expected a 3-channel image batch, got %s" % (tuple(x.shape),))
         cout = weight.shape[0]
         wpk = packed_filter(cd, weight, PACK_C3, 32)
-        training = any(ctx.needs_input_grad)
+        training = ctx.grad_on and any(ctx.needs_input_grad)
         want_pre = training and cfg.act == L.ACT_PRELU
         b32 = bias if bias is None or bias.dtype == torch.float32 else bias.float()
         out = torch.empty((n, h, w, cout), dtype=cd.torch_dtype, device=x.device)
@@ -432,7 +443,7 @@ class Conv3x3Fn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g, _gstats):
         if g is None:       # (gradients are not materialised: only the statistics output was used downstream)
-            return None, None, None, None, None
+            return None, None, None, None, None, None
         cfg, cd = ctx.cfg, ctx.cfg.cd
         xin, weight, prelu, saved = ctx.saved_tensors
         cout, cin, xshape = ctx.dims
@@ -516,11 +527,11 @@ class Conv3x3Fn(torch.autograd.Function):
         if not cfg.tanh_head and ctx.c3 and fused_dbias:
             db = None       # accumulated in the arena by the weight-gradient launch
         dp = dprelu if (dprelu is not None and ctx.needs_input_grad[3]) else None
-        return dx, dw, db, dp, None
+        return dx, dw, db, dp, None, None
 
 
 def conv3x3(x, weight, bias, prelu, cfg):
-    return Conv3x3Fn.apply(x, weight, bias, prelu, cfg)
+    return Conv3x3Fn.apply(x, weight, bias, prelu, cfg, torch.is_grad_enabled())
 
 
 # ---------------------------------------------------------------------------------- autograd: InstanceNorm + act + residual
@@ -712,3 +723,14 @@ def ssim_sse(a, b):
     scr = _workspace(L.lib().fsr_ssim_sse_scratch(n, h, w), a.device)
     L.check(L.lib().fsr_ssim_sse(_p(a), *a.stride(), _p(b), *b.stride(), n, h, w, _p(out), _p(scr), _stream()), "fsr_ssim_sse")
     return out
+
+
+def u8_to_image(frames):
+    """(N,H,W,3) uint8 frames -> float32 (N,3,H,W) VIEW in [-1,1] (x / 127.5 - 1, inference.py:48) of an NHWC buffer: the
+    first-layer kernels read it in place through its strides."""
+    _check_dev(frames)
+    if frames.dtype != torch.uint8 or frames.dim() != 4 or frames.shape[3] != 3 or not frames.is_contiguous():
+        raise ValueError("u8_to_image expects a contiguous (N,H,W,3) uint8 tensor")
+    img = torch.empty(frames.shape, dtype=torch.float32, device=frames.device)
+    L.check(L.lib().fsr_u8_to_image(_p(frames), _p(img), frames.numel(), _stream()), "fsr_u8_to_image")
+    return img.permute(0, 3, 1, 2)

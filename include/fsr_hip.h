@@ -43,6 +43,7 @@ enum { FSR_F32 = 0, FSR_BF16 = 1 };
 enum { FSR_ACT_NONE = 0, FSR_ACT_RELU = 1, FSR_ACT_LEAKY = 2, FSR_ACT_PRELU = 3, FSR_ACT_TANH = 4 };
 enum { FSR_CONV_FWD = 0, FSR_CONV_DGRAD = 1 };
 enum { FSR_PACK_FWD = 0, FSR_PACK_FWD_PS = 1, FSR_PACK_DGRAD = 2, FSR_PACK_DGRAD_PS = 3 };
+enum { FSR_OUT_DTYPE = 0, FSR_OUT_F32 = 1, FSR_OUT_U8 = 2 };   /* fsr_conv_desc.out_f32 */
 
 typedef void* fsr_stream_t; /* hipStream_t */
 
@@ -81,7 +82,10 @@ int fsr_pack_conv3x3(int dtype, int mode, const float* w_oihw, int cout, int cin
  * cin is the (padded) channel count of `in` and the K_pad of the packed filter.
  * pixel_shuffle (FWD): out is [n,2oh,2ow,cout/4]; filters packed FSR_PACK_FWD_PS.
  * in_pixel_shuffled (DGRAD): in is [n,2ih,2iw,cin/4]; filters packed FSR_PACK_DGRAD_PS.
- * out_f32: store float whatever `dtype` is (3-channel outputs: head images, image gradients).
+ * out_f32: FSR_OUT_DTYPE (0): `dtype` output; FSR_OUT_F32 (1): store float whatever `dtype` is (3-channel outputs:
+ *   head images, image gradients); FSR_OUT_U8 (2, FSR_ACT_TANH heads, forward): store the uint8 HWC image
+ *   (unsigned char)(((tanh(z) + 1) / 2) * 255) -- inference.py:53-56's post-processing with its truncating cast,
+ *   out [n,oh,ow,cout] bytes (cout = 3: the finished RGB frame).
  * stats (optional): float [n][cout][2]; receives the sum and the sum of squares of the pre-activation
  *   over pixels (needs `scratch` of fsr_conv3x3_scratch(desc) bytes; FWD and stride-1 DGRAD launches).
  * preact (optional): tensor like out; receives the pre-activation (training: PReLU backward
@@ -170,6 +174,10 @@ size_t fsr_tanh_bwd_scratch(void);
 int fsr_tanh_bwd_to_nhwc(int dtype, const float* g, long long sn, long long sc, long long sh, long long sw,
                          const float* y_nhwc3, int n, int h, int w, void* dz, int cpad, float* dbias, void* scratch,
                          fsr_stream_t stream);
+
+/* uint8 HWC frames [n,h,w,3] -> float [n,h,w,3], x / 127.5 - 1 (inference.py:48: the first-layer kernels read the result
+ * in place as an NCHW-shaped tensor of strides (3hw, 1, 3w, 3)). */
+int fsr_u8_to_image(const uint8_t* frames, float* img, long long count, fsr_stream_t stream);
 
 /* ------------------------------------------------------------------ first-layer convolutions straight from the image
  * Conv2d(3 -> cout, k3, p1) of Generator.neck (model.py:75-78), Discriminator.neck (model.py:143-146) and

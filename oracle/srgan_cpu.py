@@ -135,10 +135,11 @@ def adamw_step(params, grads, state, lr=1e-4, betas=(0.9, 0.999), eps=1e-8, wd=1
         params[k].addcdiv_(m, denom, value=-lr / bc1)
 
 
-def train_step(g_sd, d_sd, v_sd, lr_images, hr_images, noise, g_state, d_state, g_lr=1e-4, d_lr=1e-4):
+def train_step(g_sd, d_sd, v_sd, lr_images, hr_images, noise, g_state, d_state, g_lr=1e-4, d_lr=1e-4, grads_out=None):
     """One iteration of Trainer.train's loop body, trainer.py:171-196, line for line.  `noise` is the
     three torch.rand_like draws of :175, :176, :187 (injected: device RNG streams differ).
-    g_sd / d_sd are updated in place; returns the four logged losses (:199-218)."""
+    g_sd / d_sd are updated in place; returns the four logged losses (:199-218).  grads_out (optional dict) receives the
+    gradients of the two backward passes under "d.<key>" / "g.<key>"."""
     # ---- discriminator step, :171-181
     dp = {k: v.detach().clone().requires_grad_(True) for k, v in d_sd.items()}
     y_real = discriminator_forward(dp, hr_images)                              # :172
@@ -151,6 +152,8 @@ def train_step(g_sd, d_sd, v_sd, lr_images, hr_images, noise, g_state, d_state, 
     loss_fake = bce_with_logits(y_fake, fake_labels)                           # :178
     d_loss = 0.5 * loss_real + 0.5 * loss_fake                                 # :179
     grads = torch.autograd.grad(d_loss, list(dp.values()))                     # :180
+    if grads_out is not None:
+        grads_out.update({"d." + k: g.detach().clone() for k, g in zip(dp.keys(), grads)})
     adamw_step(d_sd, dict(zip(dp.keys(), grads)), d_state, lr=d_lr)            # :181
     # ---- generator step, :184-196
     gp = {k: v.detach().clone().requires_grad_(True) for k, v in g_sd.items()}
@@ -163,6 +166,8 @@ def train_step(g_sd, d_sd, v_sd, lr_images, hr_images, noise, g_state, d_state, 
     content_loss = smooth_l1(fake_features, real_features)                     # :192
     g_loss = 0.5 * adv_loss + 0.5 * content_loss                               # :194
     grads = torch.autograd.grad(g_loss, list(gp.values()))                     # :195
+    if grads_out is not None:
+        grads_out.update({"g." + k: g.detach().clone() for k, g in zip(gp.keys(), grads)})
     adamw_step(g_sd, dict(zip(gp.keys(), grads)), g_state, lr=g_lr)            # :196
     return {"loss_real": loss_real.detach(), "loss_fake": loss_fake.detach(),
             "adv_loss": adv_loss.detach(), "content_loss": content_loss.detach()}

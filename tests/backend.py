@@ -55,3 +55,15 @@ def relerr2(a, b):
     them; the L2 norm is."""
     a, b = a.detach().double().cpu(), b.detach().double().cpu()
     return float((a - b).norm() / b.norm().clamp_min(1e-30))
+
+
+def report(name, value):
+    """Measured parity errors are appended to gpurun_out/parity_errors.log (the bf16 gates are set to ~2x what this file
+    shows on the MI355X; keep them honest when kernels change)."""
+    try:
+        os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+        with open(os.path.join(ROOT, "gpurun_out", "parity_errors.log"), "a") as f:
+            f.write("%s %.6g\n" % (name, value))
+    except OSError:
+        pass
+    return value

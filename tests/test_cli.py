@@ -1,6 +1,7 @@
 """End-to-end drop-in entry points on the GPU: `train.py a.b=c` and `inference.py --image_dir --output_dir`."""
 import importlib
 import os
+import types
 import warnings
 
 import numpy as np
@@ -67,3 +68,31 @@ def test_inference_entry_point_matches_oracle(tmp_path, monkeypatch):
     assert got.shape == (80, 112, 3)
     diff = np.abs(got.astype(int) - want.astype(int))
     assert diff.max() <= 1 and (diff > 0).mean() < 0.02                    # +-1 only where y*255 sits on an integer boundary
+
+
+@pytest.mark.gpu
+def test_inference_pipeline_batched_frames(tmp_path):
+    """InferencePipeline: a stream of mixed-shape frames, bucketed, batched (ragged tail), replayed as
+    hipGraphs with overlapped uint8 D2H -- every frame byte-identical to the single-frame path, in input order."""
+    dev = select("hip")
+    pkg = importlib.import_module("fast-srgan_amd")
+    z = load_npz("g_model_pt.npz")
+    sd = sd_from(z, "sd.")
+    G = pkg.Generator(types.SimpleNamespace(n_filters=64, n_layers=8), compute_dtype="bf16")
+    G.load_state_dict(sd)
+    G.to(dev).eval()
+    rng = np.random.default_rng(5)
+    shapes = [(24, 40)] * 7 + [(30, 30)] * 3 + [(24, 40)] * 2
+    frames = [rng.integers(0, 256, size=(h, w, 3), dtype=np.uint8) for h, w in shapes]
+    pipe = pkg.InferencePipeline(G, dev, batch=4, depth=2)
+    outs = pipe.run_mixed(frames)
+    assert len(outs) == len(frames)
+    inference = importlib.import_module("fast-srgan_amd.inference")
+    for f, y in zip(frames, outs):
+        assert y.dtype == np.uint8 and y.shape == (4 * f.shape[0], 4 * f.shape[1], 3)
+        one = inference.super_resolve(G, f, dev)
+        assert np.array_equal(y, one)
+    # against the oracle on one frame (fp32 reference; bf16 kernels: a few grey levels)
+    x = (torch.from_numpy(frames[0]) / 127.5 - 1.0).permute(2, 0, 1).unsqueeze(0)
+    want = O.postprocess_u8(O.generator_forward(sd, x))
+    assert np.abs(outs[0].astype(int) - want.astype(int)).mean() < 3.0

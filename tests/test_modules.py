@@ -7,9 +7,13 @@ import warnings
 import pytest
 import torch
 
-from backend import BACKENDS, relerr, relerr2, select
+from backend import BACKENDS, relerr, relerr2, report, select
 from conftest import load_npz, sd_from
 from oracle import srgan_cpu as O
+
+
+# bf16 (bf16 MFMA, f32 accumulate, bf16 activations between layers) against the fp32 oracle: ~2x the measured errors
+BF16_OUT, BF16_GRAD, BF16_SCALAR = 6e-2, 0.3, 0.5
 
 
 @pytest.fixture(params=BACKENDS)
@@ -107,7 +111,9 @@ def test_generator_shipped_weights_kat_gpu(pkg):
     Gb.to(dev).eval()
     with torch.no_grad():
         yb = Gb(x.to(dev)).cpu()
-    assert (yb - y).abs().mean() < 0.02
+    # bf16 against fp32 on the shipped weights (images in (-1,1)): mean and MAX error, ~2x the measured values
+    assert report("kat.bf16.mean_abs", float((yb - y).abs().mean())) < 0.02
+    assert report("kat.bf16.max_abs", float((yb - y).abs().max())) < 0.5
 
 
 @pytest.mark.gpu
@@ -133,21 +139,16 @@ def test_full_size_modules_vs_oracle_gpu(pkg, cdn):
     lg_ref = O.discriminator_forward(dp, sr_ref)
     grads = torch.autograd.grad((lg_ref * r).sum(), list(gp.values()) + list(dp.values()))
     ref = dict(zip([("g", k) for k in gp] + [("d", k) for k in dp], grads))
-    t_out, t_grad = (1e-3, 1e-2) if cdn == "f32" else (6e-2, 0.6)
-    assert relerr(sr, sr_ref) < t_out
-    assert relerr(logits, lg_ref) < t_out * 2
+    # bf16 gates = ~2x the errors measured on the MI355X (gpurun_out/parity_errors.log, see backend.report)
+    t_out, t_grad, t_scalar = (1e-3, 1e-2, 1e-2) if cdn == "f32" else (BF16_OUT, BF16_GRAD, BF16_SCALAR)
+    assert report("modules.%s.sr" % cdn, relerr(sr, sr_ref)) < t_out
+    assert report("modules.%s.logits" % cdn, relerr(logits, lg_ref)) < t_out * 2
     for tag, mod in (("g", G), ("d", D)):   # L2: see backend.relerr2 on why max-norm is meaningless here
         for k, p in mod.named_parameters():
-            if p.numel() < 1000 and cdn == "bf16":
-                continue   # PReLU slopes, biases: a few cancelling sums, their relative error says nothing in bf16
-            if p.numel() == 1:
-                # a PReLU slope's gradient is ONE cancelling sum over every activation of its layer: when the float atomics
-                # of the InstanceNorm statistics land in another order, a sign flip upstream moves it by several per cent
-                # (tests/flake_probe.py: 2e-3 .. 7e-2 over 40 runs of this very check).  The operator tests bound it
-                # against the magnitude of its terms (test_ops.py); here it only has to be finite and of the right size.
-                assert relerr2(p.grad, ref[(tag, k)]) < 0.5, (tag, k)
-                continue
-            assert relerr2(p.grad, ref[(tag, k)]) < t_grad, (tag, k, relerr2(p.grad, ref[(tag, k)]))
+            e = report("modules.%s.grad.%s.%s" % (cdn, tag, k), relerr2(p.grad, ref[(tag, k)]))
+            # every parameter is gated, the single PReLU slopes and the biases included: the statistics and the gradient
+            # sums are order-fixed (csrc/reduce.hip), so these cancelling sums no longer move from run to run
+            assert e < (t_scalar if p.numel() < 1000 else t_grad), (tag, k, e)
 
 
 @pytest.mark.gpu
@@ -163,3 +164,33 @@ def test_generator_8x_extension_gpu(pkg):
         y = G.to(dev)(x.to(dev))
     assert y.shape == (1, 3, 128, 192)
     assert relerr(y, O.generator_forward(sd, x)) < 1e-3
+
+
+def test_generator_uint8_frames_in_and_out(dev, pkg):
+    """Generator.forward_u8 (inference.py:47-57 on the device): uint8 HWC frames in, the head epilogue's truncating
+    ((y+1)/2*255) bytes out -- byte-exact against the oracle except where y*255 sits on an integer boundary (tanh differs
+    by an ulp between the host and the device)."""
+    z = _fx(dev, "g")
+    nl = 2 if dev.type == "cuda" else 1
+    for cdn in (("f32", "bf16") if dev.type == "cuda" else ("f32",)):
+        if cdn == "bf16":
+            continue_ok = z["sd.neck.0.weight"].shape[0] % 32 == 0
+            if not continue_ok:
+                continue
+        G = pkg.Generator(ns(n_filters=16, n_layers=nl), compute_dtype=cdn)
+        sd = sd_from(z, "sd.")
+        G.load_state_dict(sd)
+        G.to(dev).eval()
+        torch.manual_seed(3)
+        h, w = (20, 28) if dev.type == "cuda" else (5, 9)
+        frames = torch.randint(0, 256, (2, h, w, 3), dtype=torch.uint8)
+        got = G.forward_u8(frames.to(dev)).cpu()
+        assert got.dtype == torch.uint8 and got.shape == (2, 4 * h, 4 * w, 3)
+        x = (frames / 127.5 - 1.0).permute(0, 3, 1, 2)
+        want = torch.from_numpy(O.postprocess_u8(O.generator_forward(sd, x)))
+        diff = (got.int() - want.int()).abs()
+        assert int(diff.max()) <= 1 and float((diff > 0).float().mean()) < 0.02
+        # and it is the float path's own output, converted: the same kernel with another store
+        with torch.no_grad():
+            yf = G(x.to(dev)).cpu()
+        assert torch.equal(got, torch.from_numpy(O.postprocess_u8(yf)))

@@ -8,7 +8,7 @@ import numpy as np
 import pytest
 import torch
 
-from backend import BACKENDS, L, ops, relerr, select
+from backend import BACKENDS, L, ops, relerr, report, select
 from conftest import load_npz, sd_from
 from oracle import srgan_cpu as O
 
@@ -72,9 +72,10 @@ def test_full_width_train_step_vs_oracle(pkg, cdt):
     noise = [torch.rand(2, 1, 4, 4) for _ in range(3)]
     got = T.train_step(lr.to(dev), hr.to(dev), [n.to(dev) for n in noise])
     want = O.train_step(g_sd, d_sd, v_sd, lr, hr, noise, {}, {})
-    tl = 1e-3 if cdt == "f32" else 5e-2
+    tl = 1e-3 if cdt == "f32" else 3e-2      # bf16: ~2x the measured error (gpurun_out/parity_errors.log)
     for k in want:
-        assert abs(float(got[k]) - float(want[k])) <= tl * abs(float(want[k])), (k, float(got[k]), float(want[k]))
+        e = report("step16.%s.%s" % (cdt, k), abs(float(got[k]) - float(want[k])) / abs(float(want[k])))
+        assert e <= tl, (k, float(got[k]), float(want[k]))
     if cdt == "f32":   # one AdamW step each: compare the updates in the mean (Adam amplifies tiny-gradient noise)
         for sd_ref, sd0, mod in ((g_sd, g0, T.generator), (d_sd, d0, T.discriminator)):
             for k, p in mod.state_dict().items():
@@ -189,8 +190,8 @@ def test_device_crop_pipeline_full_size_gpu(pkg, tmp_path):
 @pytest.mark.gpu
 def test_graph_replay_of_iteration_and_inference(pkg):
     """hipGraph paths: a captured training iteration keeps stepping the optimizers (device-side step counters,
-    fresh label noise per replay), and GraphedGenerator reproduces eager inference (up to the summation order of the
-    InstanceNorm statistics' float atomics, which differs run to run)."""
+    fresh label noise per replay), and GraphedGenerator reproduces eager inference BIT FOR BIT (same kernels, and the
+    InstanceNorm statistics are order-fixed sums)."""
     dev = select("hip")
     torch.manual_seed(11)
     T = _trainer(pkg, dev, "bf16", nf=32, n_layers=1, width_div=2)
@@ -216,7 +217,63 @@ def test_graph_replay_of_iteration_and_inference(pkg):
     with torch.no_grad():
         want = G(x).clone()
     gg = pkg.GraphedGenerator(G, x)
-    assert (gg(x) - want).abs().max() < 2e-2
+    assert torch.equal(gg(x), want)
     x2 = (torch.rand(1, 3, 20, 24) * 2 - 1).to(dev)
     with torch.no_grad():
-        assert (gg(x2) - G(x2)).abs().max() < 2e-2
+        assert torch.equal(gg(x2), G(x2))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("cdt", ["f32", "bf16"])
+def test_graphed_replays_equal_eager_steps(pkg, cdt):
+    """N replays of the captured iteration == N eager train_steps, bit for bit (injected label noise, new batch every
+    step).  A replay that read filters packed at capture time, or statistics summed in another order, fails this."""
+    dev = select("hip")
+
+    def batches(seed, count):
+        g = torch.Generator().manual_seed(seed)
+        return [((torch.rand(2, 3, 16, 16, generator=g) * 2 - 1).to(dev), (torch.rand(2, 3, 64, 64, generator=g) * 2 - 1).to(dev),
+                 [torch.rand(2, 1, 4, 4, generator=g).to(dev) for _ in range(3)]) for _ in range(count)]
+
+    data = batches(5, 6)
+    torch.manual_seed(21)
+    Te = _trainer(pkg, dev, cdt, nf=32, n_layers=1, width_div=2 if cdt == "bf16" else 4)
+    torch.manual_seed(21)
+    Tg = _trainer(pkg, dev, cdt, nf=32, n_layers=1, width_div=2 if cdt == "bf16" else 4)
+    for a, b in zip(Te.optim_generator.flat_param, Tg.optim_generator.flat_param):
+        assert float(a) == float(b)
+        break
+    # eager: the capture's two warm-up iterations see batch 0 twice, then batches 1..5
+    eager_losses = []
+    for lr, hr, nz in [data[0], data[0]] + data[1:]:
+        eager_losses.append({k: float(v) for k, v in Te.train_step(lr, hr, nz).items()})
+    Tg.capture_train_step(data[0][0], data[0][1], warmup=2, noise=data[0][2])
+    graph_losses = []
+    for lr, hr, nz in data[1:]:
+        graph_losses.append({k: float(v) for k, v in Tg.graphed_train_step(lr, hr, nz).items()})
+    torch.cuda.synchronize()
+    assert graph_losses == eager_losses[2:]
+    for oe, og in ((Te.optim_generator, Tg.optim_generator), (Te.optim_discriminator, Tg.optim_discriminator)):
+        assert torch.equal(oe.flat_param, og.flat_param) and torch.equal(oe.exp_avg_sq, og.exp_avg_sq)
+        assert float(oe.step_dev) == float(og.step_dev) == 7.0
+
+
+@pytest.mark.gpu
+def test_rccl_single_process_group_phase_graphs(pkg, tmp_path):
+    """The data-parallel path on ONE GPU: a 1-rank RCCL process group (FSR_FORCE_DIST=1) runs the gradient all-reduces for
+    real and the iteration is captured as three phase graphs around them; results equal the plain single-process run."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = os.path.join(root, "tools", "dist_check.py")
+    outs = []
+    for force in ("0", "1"):
+        out = str(tmp_path / ("params_%s.pt" % force))
+        env = dict(os.environ, FSR_FORCE_DIST=force, RANK="0", WORLD_SIZE="1", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT="29517")
+        r = subprocess.run([sys.executable, script, out], env=env, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+        outs.append(torch.load(out))
+    assert outs[1]["segments"] == 3 and outs[0]["segments"] == 1 and outs[1]["backend"] == "nccl"
+    assert torch.equal(outs[0]["g"], outs[1]["g"]) and torch.equal(outs[0]["d"], outs[1]["d"])
+    assert outs[0]["losses"] == outs[1]["losses"]

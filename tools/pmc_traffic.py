@@ -1,8 +1,17 @@
 """HBM traffic of the 3x3 conv forward / data-gradient kernels per iteration from two rocprofv3 --pmc passes
-(FETCH_SIZE, WRITE_SIZE; counter_collection.csv) over `bench.py --steps 1 --warmup 1 --no-graph` (= 4 iterations).
-FETCH_SIZE on gfx950 counts half the bytes (MI355X_MICROARCH.md): x2.  Units: KB."""
+(FETCH_SIZE, WRITE_SIZE; counter_collection.csv) over `bench.py --steps 1 --warmup 1 --no-graph --no-f32` (= 4 iterations).
+FETCH_SIZE on gfx950 counts half the bytes (MI355X_MICROARCH.md): x2.  Units: KB.
+
+    python tools/pmc_traffic.py FETCH.csv WRITE.csv ITERS LAUNCHES_PER_ITER [OUT.json]
+
+With OUT.json (profiles/conv_traffic.json) the per-launch figure is recorded together with the hash of the kernel
+sources it was measured on; bench.py quotes it as roofline.traffic only while that hash still matches."""
 import csv
+import json
+import os
 import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 KERNELS = ("conv_igemm_kernel", "conv64_persistent_kernel", "conv64_s2dgrad_kernel", "conv_c3_fwd_kernel")
 
@@ -25,3 +34,12 @@ print("conv kernel dispatches per iteration: %.1f / %.1f" % (n1 / iters, n2 / it
 print("FETCH_SIZE %.0f KB (x2) + WRITE_SIZE %.0f KB per iteration -> %.3e bytes per iteration" % (fetch / iters, write / iters, byt))
 if api:
     print("per API-level conv launch (%d per iteration): %.3e bytes" % (api, byt / api))
+if len(sys.argv) > 5 and api:
+    import bench
+    rec = {"bytes_per_launch": round(byt / api), "bytes_per_iteration": round(byt), "launches_per_step": api, "iterations": iters,
+           "fetch_size_kb_per_iteration": round(fetch / iters), "write_size_kb_per_iteration": round(write / iters),
+           "formula": "2 x FETCH_SIZE (gfx950 counts 64 B per 128-B request) + WRITE_SIZE, conv forward + data-gradient kernels",
+           "dtype": "bf16", "batch": 32, "kernel_sources_sha16": bench.kernel_sources_hash(),
+           "files": "%s, %s" % (os.path.basename(sys.argv[1]), os.path.basename(sys.argv[2]))}
+    json.dump(rec, open(sys.argv[5], "w"), indent=1)
+    print("wrote", sys.argv[5], rec)
