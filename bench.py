@@ -316,6 +316,14 @@ def main():
                         for _y in pipe.run(frames):
                             count += 1
                     inf["e2e_fps_%s_b%d" % (name, bsz)] = round(count / (time.perf_counter() - t0), 2)
+            pipe = pkg.InferencePipeline(G, device, batch=8, depth=3, copy=False)     # zero-copy hand-off of the pinned results
+            for _ in pipe.run(frames[:16]):
+                pass
+            t0, count = time.perf_counter(), 0
+            for _ in range(4):
+                for _y in pipe.run(frames):
+                    count += 1
+            inf["e2e_fps_180x320_b8_zero_copy"] = round(count / (time.perf_counter() - t0), 2)
             inf["e2e"] = "InferencePipeline: pinned uint8 frames -> H2D -> hipGraph(u8->[-1,1], G, uint8 head) -> D2H -> numpy, depth 2"
         out["inference"] = inf
         # device crop pipeline (dataloader.py:24-38 replacement): 96 -> 384 crops cut from a resident uint8 pool

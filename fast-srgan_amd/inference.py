@@ -48,8 +48,11 @@ class InferencePipeline:
                       overlapped with the next batch's compute (`depth` staging slots, each with its own graph)
     Frames are bucketed by shape; one set of graphs per (H, W).  `run` yields results in input order."""
 
-    def __init__(self, model, device="cuda", batch=8, depth=2, use_graph=True):
+    def __init__(self, model, device="cuda", batch=8, depth=2, use_graph=True, copy=True):
+        """copy=False: `run` yields VIEWS of the pinned result buffers (valid until `depth` more batches have been
+        submitted) instead of private arrays -- for consumers that encode / display a frame right away."""
         self.model, self.device, self.batch, self.depth, self.use_graph = model.eval(), torch.device(device), batch, depth, use_graph
+        self.copy = copy
         self._plans = {}
         self._copy_stream = torch.cuda.Stream(device=self.device)
 
@@ -87,6 +90,9 @@ class InferencePipeline:
             sl.y = y
             scale = y.shape[1] // h
             sl.host_out = torch.empty(tuple(y.shape), dtype=torch.uint8).pin_memory()
+            # plain numpy views for the host-side packing / unpacking: one memcpy per frame on this thread (torch's
+            # multi-threaded copy_ pays a thread-pool wake-up per call, milliseconds when the pool has gone to sleep)
+            sl.host_in_np, sl.host_out_np = sl.host_in.numpy(), sl.host_out.numpy()
             sl.done = torch.cuda.Event()
             sl.copied = torch.cuda.Event()
             sl.pending = None
@@ -99,9 +105,9 @@ class InferencePipeline:
         """Enqueue one batch on slot `sl` (its previous results have been collected): nothing here waits for the device."""
         n = len(frames)
         for i, f in enumerate(frames):
-            sl.host_in[i].copy_(torch.from_numpy(np.ascontiguousarray(f)))
+            np.copyto(sl.host_in_np[i], f)
         for i in range(n, self.batch):      # ragged tail: repeat the last frame, results dropped
-            sl.host_in[i].copy_(sl.host_in[n - 1])
+            np.copyto(sl.host_in_np[i], sl.host_in_np[n - 1])
         main = torch.cuda.current_stream()
         sl.x.copy_(sl.host_in, non_blocking=True)
         if sl.graph is not None:
@@ -118,7 +124,7 @@ class InferencePipeline:
 
     def _collect(self, sl):
         sl.copied.synchronize()
-        out = [sl.host_out[i].numpy().copy() for i in range(sl.pending)]
+        out = [sl.host_out_np[i].copy() if self.copy else sl.host_out_np[i] for i in range(sl.pending)]
         sl.pending = None
         return out
 

@@ -20,6 +20,56 @@ VGG_MEAN = (0.485, 0.456, 0.406)  # model.py:13
 VGG_STD = (0.229, 0.224, 0.225)   # model.py:17
 
 
+# ---------------------------------------------------------------------------------- bf16 storage model
+# The benched mode of the HIP path keeps every activation (and activation gradient) tensor in bf16 between kernels and
+# feeds bf16 operands to the matrix cores; accumulation, statistics, parameters and losses stay fp32.  `Q_BF16` restates the
+# reference with exactly those roundings (and nothing else changed), so that the bf16 kernels can be held to TIGHT bounds:
+# against the plain fp32 oracle a bf16 run differs by ~1e-2 per activation, which flips a percent of the ReLU / LeakyReLU /
+# max-pool decisions per layer and moves whole-network gradients by tens of per cent (measured) --
+# a property of bf16 arithmetic on this network, not of any kernel.  q = None everywhere is the reference itself.
+class _StoreBF16(torch.autograd.Function):
+    """A tensor the kernels store in bf16: the value is rounded in the forward pass, its gradient in the backward pass."""
+
+    @staticmethod
+    def forward(ctx, x):
+        return x.bfloat16().float()
+
+    @staticmethod
+    def backward(ctx, g):
+        return g.bfloat16().float()
+
+
+class Q_BF16:
+    """store(x): activation kept in bf16 (gradient too); operand(w): a float tensor rounded on its way into the MFMA (packed
+    filters, the image read by the first layers) -- value only, its gradient stays fp32."""
+
+    @staticmethod
+    def store(x):
+        return _StoreBF16.apply(x)
+
+    @staticmethod
+    def operand(w):
+        return w + (w.detach().bfloat16().float() - w.detach())
+
+
+def _st(q, x):
+    return x if q is None else q.store(x)
+
+
+def _op(q, w):
+    return w if q is None else q.operand(w)
+
+
+def instance_norm_stored(u, q, eps=1e-5):
+    """InstanceNorm2d as the kernels evaluate it in the bf16 mode: statistics from the fp32 accumulators `u` of the
+    producing convolution (its epilogue), normalisation of the STORED (rounded) tensor."""
+    if q is None:
+        return instance_norm(u, eps)
+    mean = u.mean(dim=(2, 3), keepdim=True)
+    var = ((u - mean) ** 2).mean(dim=(2, 3), keepdim=True)
+    return (q.store(u) - mean) / torch.sqrt(var + eps)
+
+
 def instance_norm(x, eps=1e-5):
     """torch.nn.InstanceNorm2d defaults (model.py:55,65,94,132): biased variance over H*W per
     (n, c), eps 1e-5, no affine, no running statistics."""
@@ -40,46 +90,51 @@ def pixel_shuffle2(x):
     return x.reshape(n, c, 2, 2, h, w).permute(0, 1, 4, 2, 5, 3).reshape(n, c, 2 * h, 2 * w)
 
 
-def generator_forward(sd, x):
-    """Generator.forward (model.py:112-117); n_layers / n_upsample inferred from the state_dict."""
-    r = prelu(F.conv2d(x, sd["neck.0.weight"], sd["neck.0.bias"], padding=1), sd["neck.1.weight"])  # :75-78
+def generator_forward(sd, x, q=None):
+    """Generator.forward (model.py:112-117); n_layers / n_upsample inferred from the state_dict.  q: None (the reference)
+    or Q_BF16 (the reference with the bf16 mode's storage roundings)."""
+    r = _st(q, prelu(F.conv2d(_op(q, x), _op(q, sd["neck.0.weight"]), sd["neck.0.bias"], padding=1), sd["neck.1.weight"]))  # :75-78
     y = r
     i = 0
     while f"stem.{i}.conv1.weight" in sd:  # ResidualBlock.forward, model.py:67-69
-        t = prelu(instance_norm(F.conv2d(y, sd[f"stem.{i}.conv1.weight"], None, padding=1)), sd[f"stem.{i}.relu1.weight"])
-        y = instance_norm(F.conv2d(t, sd[f"stem.{i}.conv2.weight"], None, padding=1)) + y
+        t = _st(q, prelu(instance_norm_stored(F.conv2d(y, _op(q, sd[f"stem.{i}.conv1.weight"]), None, padding=1), q), sd[f"stem.{i}.relu1.weight"]))
+        y = _st(q, instance_norm_stored(F.conv2d(t, _op(q, sd[f"stem.{i}.conv2.weight"]), None, padding=1), q) + y)
         i += 1
-    y = instance_norm(F.conv2d(y, sd["bottleneck.0.weight"], None, padding=1)) + r  # :86-95, :115
+    y = _st(q, instance_norm_stored(F.conv2d(y, _op(q, sd["bottleneck.0.weight"]), None, padding=1), q) + r)  # :86-95, :115
     j = 0
     while f"upsampling.{j}.conv.weight" in sd:  # UpSamplingBlock.forward, model.py:39-40
-        y = F.conv2d(y, sd[f"upsampling.{j}.conv.weight"], sd[f"upsampling.{j}.conv.bias"], padding=1)
-        y = prelu(pixel_shuffle2(y), sd[f"upsampling.{j}.relu.weight"])
+        y = F.conv2d(y, _op(q, sd[f"upsampling.{j}.conv.weight"]), sd[f"upsampling.{j}.conv.bias"], padding=1)
+        y = _st(q, prelu(pixel_shuffle2(y), sd[f"upsampling.{j}.relu.weight"]))
         j += 1
-    return torch.tanh(F.conv2d(y, sd["head.0.weight"], sd["head.0.bias"], padding=1))  # :102-110
+    return torch.tanh(F.conv2d(y, _op(q, sd["head.0.weight"]), sd["head.0.bias"], padding=1))  # :102-110
 
 
 D_STRIDES = (2, 1, 2, 1, 2, 1, 2)  # model.py:148-183
 
 
-def discriminator_forward(sd, x):
+def discriminator_forward(sd, x, q=None):
     """Discriminator.forward (model.py:139-193): neck conv + LeakyReLU(0.2); 7 SimpleBlocks
     (conv no-bias, InstanceNorm, LeakyReLU(default 0.01), model.py:120-136); 1x1 conv."""
-    y = F.leaky_relu(F.conv2d(x, sd["neck.0.weight"], sd["neck.0.bias"], padding=1), 0.2)
+    y = _st(q, F.leaky_relu(F.conv2d(_op(q, x), _op(q, sd["neck.0.weight"]), sd["neck.0.bias"], padding=1), 0.2))
     for i, s in enumerate(D_STRIDES):
-        y = F.leaky_relu(instance_norm(F.conv2d(y, sd[f"stem.{i}.conv.weight"], None, stride=s, padding=1)), 0.01)
+        u = F.conv2d(y, _op(q, sd[f"stem.{i}.conv.weight"]), None, stride=s, padding=1)
+        y = _st(q, F.leaky_relu(instance_norm_stored(u, q), 0.01))
     return F.conv2d(y, sd["stem.7.weight"], sd["stem.7.bias"])
 
 
-def vgg_forward(sd, x):
+def vgg_forward(sd, x, q=None):
     """VGG19.forward (model.py:20-23) over vgg19.features[:34] (model.py:8): 15x[conv3x3+ReLU],
     MaxPool2d(2) after convs 2, 4, 8, 12 (torchvision cfg 'E'), ending at the ReLU after conv5_3...
     (index 33)."""
     mean = sd["mean"] if "mean" in sd else torch.tensor(VGG_MEAN).view(1, 3, 1, 1)
     std = sd["std"] if "std" in sd else torch.tensor(VGG_STD).view(1, 3, 1, 1)
-    y = (x + 1.0) / 2.0
-    y = (y - mean) / std
+    if q is None:
+        y = (x + 1.0) / 2.0
+        y = (y - mean) / std
+    else:   # the first-layer kernel folds both lines into one fused multiply-add per channel and rounds the result
+        y = _op(q, x * (0.5 / std) + (0.5 - mean) / std)
     for idx in VGG_CONV_IDX:
-        y = F.relu(F.conv2d(y, sd[f"vgg.{idx}.weight"], sd[f"vgg.{idx}.bias"], padding=1))
+        y = _st(q, F.relu(F.conv2d(y, _op(q, sd[f"vgg.{idx}.weight"]), sd[f"vgg.{idx}.bias"], padding=1)))
         if idx in VGG_POOL_AFTER:
             y = F.max_pool2d(y, 2, 2)
     return y
@@ -135,17 +190,18 @@ def adamw_step(params, grads, state, lr=1e-4, betas=(0.9, 0.999), eps=1e-8, wd=1
         params[k].addcdiv_(m, denom, value=-lr / bc1)
 
 
-def train_step(g_sd, d_sd, v_sd, lr_images, hr_images, noise, g_state, d_state, g_lr=1e-4, d_lr=1e-4, grads_out=None):
+def train_step(g_sd, d_sd, v_sd, lr_images, hr_images, noise, g_state, d_state, g_lr=1e-4, d_lr=1e-4, grads_out=None, q=None):
     """One iteration of Trainer.train's loop body, trainer.py:171-196, line for line.  `noise` is the
     three torch.rand_like draws of :175, :176, :187 (injected: device RNG streams differ).
     g_sd / d_sd are updated in place; returns the four logged losses (:199-218).  grads_out (optional dict) receives the
-    gradients of the two backward passes under "d.<key>" / "g.<key>"."""
+    gradients of the two backward passes under "d.<key>" / "g.<key>".  q = Q_BF16: the same iteration with the bf16
+    mode's storage roundings."""
     # ---- discriminator step, :171-181
     dp = {k: v.detach().clone().requires_grad_(True) for k, v in d_sd.items()}
-    y_real = discriminator_forward(dp, hr_images)                              # :172
+    y_real = discriminator_forward(dp, hr_images, q)                           # :172
     with torch.no_grad():
-        sr = generator_forward(g_sd, lr_images)                                # :173 (.detach())
-    y_fake = discriminator_forward(dp, sr)                                     # :174
+        sr = generator_forward(g_sd, lr_images, q)                             # :173 (.detach())
+    y_fake = discriminator_forward(dp, sr, q)                                  # :174
     real_labels = 0.3 * noise[0] + 0.8                                         # :175
     fake_labels = 0.3 * noise[1]                                               # :176
     loss_real = bce_with_logits(y_real, real_labels)                           # :177
@@ -157,12 +213,12 @@ def train_step(g_sd, d_sd, v_sd, lr_images, hr_images, noise, g_state, d_state, 
     adamw_step(d_sd, dict(zip(dp.keys(), grads)), d_state, lr=d_lr)            # :181
     # ---- generator step, :184-196
     gp = {k: v.detach().clone().requires_grad_(True) for k, v in g_sd.items()}
-    sr = generator_forward(gp, lr_images)                                      # :185
-    y_fake = discriminator_forward(d_sd, sr)                                   # :186 (updated D)
+    sr = generator_forward(gp, lr_images, q)                                   # :185
+    y_fake = discriminator_forward(d_sd, sr, q)                                # :186 (updated D)
     real_labels = 0.3 * noise[2] + 0.7                                         # :187
     adv_loss = 1e-1 * bce_with_logits(y_fake, real_labels)                     # :188
-    fake_features = vgg_forward(v_sd, sr)                                      # :190
-    real_features = vgg_forward(v_sd, hr_images)                               # :191
+    fake_features = vgg_forward(v_sd, sr, q)                                   # :190
+    real_features = vgg_forward(v_sd, hr_images, q)                            # :191
     content_loss = smooth_l1(fake_features, real_features)                     # :192
     g_loss = 0.5 * adv_loss + 0.5 * content_loss                               # :194
     grads = torch.autograd.grad(g_loss, list(gp.values()))                     # :195

@@ -67,3 +67,34 @@ def report(name, value):
     except OSError:
         pass
     return value
+
+
+def check_grads(prefix, named, ref, t_tensor, t_slope=0.25, t_cos=None):
+    """Gradient gates of the network-level tests.  `named`: [(name, gradient)], `ref`: {name: reference gradient}.
+      * tensors (filters, biases): relative L2 error < t_tensor (relerr2 explains why not max-norm);
+      * the single PReLU slopes: each is ONE cancelling sum over a whole layer (the fp32 oracle itself moves some of them by
+        more than 100 % between float32 and float64, tests/conditioning_probe.py), so they are held to |error| < t_slope x
+        the largest slope gradient of the network instead of their own magnitude;
+      * t_cos: lower bound of the cosine between all tensor gradients concatenated and the reference.
+    Every value goes to gpurun_out/parity_errors.log.  Returns the list of violations."""
+    named = list(named)
+    bad = []
+    slopes = [(n, g) for n, g in named if g.numel() == 1]
+    smax = max([abs(float(ref[n])) for n, _ in slopes] + [1e-30])
+    dot = na = nb = 0.0
+    for n, g in named:
+        r = ref[n]
+        if g.numel() == 1:
+            e = report("%s.slope.%s" % (prefix, n), abs(float(g) - float(r)) / smax)
+            if not e < t_slope:
+                bad.append((n, "slope", e))
+            continue
+        e = report("%s.%s" % (prefix, n), relerr2(g, r))
+        if not e < t_tensor:
+            bad.append((n, e))
+        a, b = g.detach().double().cpu().reshape(-1), r.detach().double().cpu().reshape(-1)
+        dot, na, nb = dot + float(a @ b), na + float(a @ a), nb + float(b @ b)
+    cos = report("%s.cosine" % prefix, dot / max((na * nb) ** 0.5, 1e-300))
+    if t_cos is not None and not cos > t_cos:
+        bad.append(("cosine", cos))
+    return bad

@@ -1,0 +1,38 @@
+"""NOT A TEST (not collected): how well conditioned are the gradients the parity tests compare?
+
+Runs the fp32 ORACLE's own training iteration (trainer.py:171-196 restated, BASELINE cfg #1 networks, batch 2) once in
+float32 and once in float64 and prints the relative L2 distance of every gradient.  Measured (8 cores, torch 2.10 CPU):
+discriminator gradients 0.4-0.5 %, generator gradients 8-10 % (single PReLU slopes up to 180 %), VGG image gradient
+0.6 % -- although the forward values agree to 1e-6.  ReLU / LeakyReLU(0.01) / max-pool decisions flip under 1e-7
+perturbations and every flip re-routes a gradient path; the generator's gradient crosses 8 discriminator layers or 15 VGG
+layers plus its own 18.  The gates of tests/test_parity_bench.py are set from these numbers (2x), see DESIGN.md section 5.
+
+    python tests/conditioning_probe.py
+"""
+import sys, types, importlib, time, torch
+sys.path.insert(0, __import__('os').path.dirname(__import__('os').path.dirname(__import__('os').path.abspath(__file__))))
+from oracle import srgan_cpu as O
+pkg = importlib.import_module("fast-srgan_amd")
+ns = types.SimpleNamespace
+torch.manual_seed(6)
+torch.set_num_threads(8)
+G = pkg.Generator(ns(n_filters=64, n_layers=8)); D = pkg.Discriminator(ns(n_filters=64, n_layers=7))
+g_sd = {k: v.detach().clone() for k, v in G.state_dict().items()}
+d_sd = {k: v.detach().clone() for k, v in D.state_dict().items()}
+v_sd = O.vgg_standin_state_dict(1234, 1)
+B = 2
+lr, hr = torch.rand(B, 3, 96, 96) * 2 - 1, torch.rand(B, 3, 384, 384) * 2 - 1
+noise = [torch.rand(B, 1, 24, 24) for _ in range(3)]
+def run(dt):
+    gs = {k: v.to(dt).clone() for k, v in g_sd.items()}; ds = {k: v.to(dt).clone() for k, v in d_sd.items()}
+    vs = {k: v.to(dt) for k, v in v_sd.items()}
+    out = {}
+    t0 = time.time()
+    O.train_step(gs, ds, vs, lr.to(dt), hr.to(dt), [n.to(dt) for n in noise], {}, {}, grads_out=out)
+    print(dt, time.time() - t0, flush=True)
+    return out
+a = run(torch.float32); b = run(torch.float64)
+def l2(x, y): return float((x.double() - y.double()).norm() / y.double().norm())
+for k in a:
+    if k.startswith("d.") and "stem" in k and "conv" in k and k not in ("d.stem.0.conv.weight",): continue
+    print(k, l2(a[k], b[k]))

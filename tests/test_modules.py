@@ -7,13 +7,18 @@ import warnings
 import pytest
 import torch
 
-from backend import BACKENDS, relerr, relerr2, report, select
+from backend import BACKENDS, check_grads, relerr, relerr2, report, select
 from conftest import load_npz, sd_from
 from oracle import srgan_cpu as O
 
 
-# bf16 (bf16 MFMA, f32 accumulate, bf16 activations between layers) against the fp32 oracle: ~2x the measured errors
-BF16_OUT, BF16_GRAD, BF16_SCALAR = 6e-2, 0.3, 0.5
+# bf16 mode (bf16 MFMA, f32 accumulate, bf16 activations between kernels), gates ~2x the errors measured on the MI355X
+# (gpurun_out/parity_errors.log; DESIGN.md section 5 explains the two references):
+#   BF16Q_* : against the oracle WITH the bf16 storage roundings (O.Q_BF16) -- what the kernels are held to;
+#   BF16_*  : against the plain fp32 oracle -- how far bf16 arithmetic itself moves this network (sign flips of
+#             ReLU / LeakyReLU(0.01) / max-pool decisions: tens of per cent on whole-network gradients).
+BF16Q_OUT, BF16Q_LOGITS, BF16Q_GRAD, BF16Q_SLOPE, BF16Q_COS = 1e-2, 3e-2, 0.25, 0.25, 0.97
+BF16_OUT, BF16_GRAD, BF16_SCALAR, BF16_COS = 6e-2, 0.7, 1.0, 0.75
 
 
 @pytest.fixture(params=BACKENDS)
@@ -119,7 +124,9 @@ def test_generator_shipped_weights_kat_gpu(pkg):
 @pytest.mark.gpu
 @pytest.mark.parametrize("cdn", ["f32", "bf16"])
 def test_full_size_modules_vs_oracle_gpu(pkg, cdn):
-    """Full-width G and D (64 filters) at a moderate size against the CPU oracle: forward and gradients."""
+    """Full-width G and D (64 filters) at a moderate size against the CPU oracle: forward and gradients.
+    f32 mode: the plain fp32 oracle.  bf16 mode: the oracle with the bf16 mode's storage roundings (O.Q_BF16) -- and, for
+    the record, the distance to the plain fp32 oracle (reported, loosely bounded)."""
     dev = select("hip")
     torch.manual_seed(3)
     G = pkg.Generator(ns(n_filters=64, n_layers=2), compute_dtype=cdn)
@@ -133,22 +140,33 @@ def test_full_size_modules_vs_oracle_gpu(pkg, cdn):
     logits = D(sr)
     r = torch.randn(logits.shape)
     (logits * r.to(dev)).sum().backward()
-    gp = {k: v.clone().requires_grad_(True) for k, v in gsd.items()}
-    dp = {k: v.clone().requires_grad_(True) for k, v in dsd.items()}
-    sr_ref = O.generator_forward(gp, x)
-    lg_ref = O.discriminator_forward(dp, sr_ref)
-    grads = torch.autograd.grad((lg_ref * r).sum(), list(gp.values()) + list(dp.values()))
-    ref = dict(zip([("g", k) for k in gp] + [("d", k) for k in dp], grads))
-    # bf16 gates = ~2x the errors measured on the MI355X (gpurun_out/parity_errors.log, see backend.report)
-    t_out, t_grad, t_scalar = (1e-3, 1e-2, 1e-2) if cdn == "f32" else (BF16_OUT, BF16_GRAD, BF16_SCALAR)
-    assert report("modules.%s.sr" % cdn, relerr(sr, sr_ref)) < t_out
-    assert report("modules.%s.logits" % cdn, relerr(logits, lg_ref)) < t_out * 2
-    for tag, mod in (("g", G), ("d", D)):   # L2: see backend.relerr2 on why max-norm is meaningless here
-        for k, p in mod.named_parameters():
-            e = report("modules.%s.grad.%s.%s" % (cdn, tag, k), relerr2(p.grad, ref[(tag, k)]))
-            # every parameter is gated, the single PReLU slopes and the biases included: the statistics and the gradient
-            # sums are order-fixed (csrc/reduce.hip), so these cancelling sums no longer move from run to run
-            assert e < (t_scalar if p.numel() < 1000 else t_grad), (tag, k, e)
+    named = [("g." + k, p.grad) for k, p in G.named_parameters()] + [("d." + k, p.grad) for k, p in D.named_parameters()]
+
+    def oracle(q):
+        gp = {k: v.clone().requires_grad_(True) for k, v in gsd.items()}
+        dp = {k: v.clone().requires_grad_(True) for k, v in dsd.items()}
+        sr_ref = O.generator_forward(gp, x, q)
+        lg_ref = O.discriminator_forward(dp, sr_ref, q)
+        grads = torch.autograd.grad((lg_ref * r).sum(), list(gp.values()) + list(dp.values()))
+        return sr_ref, lg_ref, dict(zip(["g." + k for k in gp] + ["d." + k for k in dp], grads))
+
+    if cdn == "f32":
+        sr_ref, lg_ref, ref = oracle(None)
+        assert report("modules.f32.sr", relerr(sr, sr_ref)) < 1e-3
+        assert report("modules.f32.logits", relerr(logits, lg_ref)) < 1e-3
+        bad = check_grads("modules.f32.grad", named, ref, t_tensor=1e-2, t_slope=1e-2, t_cos=0.9999)
+        assert not bad, bad
+        return
+    sr_ref, lg_ref, ref = oracle(O.Q_BF16)
+    assert report("modules.bf16q.sr", relerr(sr, sr_ref)) < BF16Q_OUT
+    assert report("modules.bf16q.logits", relerr(logits, lg_ref)) < BF16Q_LOGITS
+    bad = check_grads("modules.bf16q.grad", named, ref, t_tensor=BF16Q_GRAD, t_slope=BF16Q_SLOPE, t_cos=BF16Q_COS)
+    assert not bad, bad
+    sr32, lg32, ref32 = oracle(None)      # distance of the bf16 arithmetic from the fp32 reference: reported, loosely bounded
+    assert report("modules.bf16.sr", relerr(sr, sr32)) < BF16_OUT
+    assert report("modules.bf16.logits", relerr(logits, lg32)) < 2 * BF16_OUT
+    bad = check_grads("modules.bf16.grad", named, ref32, t_tensor=BF16_GRAD, t_slope=BF16_SCALAR, t_cos=BF16_COS)
+    assert not bad, bad
 
 
 @pytest.mark.gpu
