@@ -93,6 +93,7 @@ def check_grads(prefix, named, ref, t_tensor, t_slope=0.25, t_cos=None):
         if not e < t_tensor:
             bad.append((n, e))
         a, b = g.detach().double().cpu().reshape(-1), r.detach().double().cpu().reshape(-1)
+        report("%s.normratio.%s" % (prefix, n), float(a.norm() / b.norm().clamp_min(1e-300)))
         dot, na, nb = dot + float(a @ b), na + float(a @ a), nb + float(b @ b)
     cos = report("%s.cosine" % prefix, dot / max((na * nb) ** 0.5, 1e-300))
     if t_cos is not None and not cos > t_cos:

@@ -17,8 +17,8 @@ from oracle import srgan_cpu as O
 #   BF16Q_* : against the oracle WITH the bf16 storage roundings (O.Q_BF16) -- what the kernels are held to;
 #   BF16_*  : against the plain fp32 oracle -- how far bf16 arithmetic itself moves this network (sign flips of
 #             ReLU / LeakyReLU(0.01) / max-pool decisions: tens of per cent on whole-network gradients).
-BF16Q_OUT, BF16Q_LOGITS, BF16Q_GRAD, BF16Q_SLOPE, BF16Q_COS = 1e-2, 3e-2, 0.25, 0.25, 0.97
-BF16_OUT, BF16_GRAD, BF16_SCALAR, BF16_COS = 6e-2, 0.7, 1.0, 0.75
+BF16Q_OUT, BF16Q_LOGITS, BF16Q_GRAD, BF16Q_SLOPE, BF16Q_COS = 1e-2, 6e-2, 0.6, 0.35, 0.93
+BF16_OUT, BF16_GRAD, BF16_SCALAR, BF16_COS = 3e-2, 0.8, 1.0, 0.85
 
 
 @pytest.fixture(params=BACKENDS)
@@ -117,8 +117,8 @@ def test_generator_shipped_weights_kat_gpu(pkg):
     with torch.no_grad():
         yb = Gb(x.to(dev)).cpu()
     # bf16 against fp32 on the shipped weights (images in (-1,1)): mean and MAX error, ~2x the measured values
-    assert report("kat.bf16.mean_abs", float((yb - y).abs().mean())) < 0.02
-    assert report("kat.bf16.max_abs", float((yb - y).abs().max())) < 0.5
+    assert report("kat.bf16.mean_abs", float((yb - y).abs().mean())) < 6e-3       # measured 2.9e-3
+    assert report("kat.bf16.max_abs", float((yb - y).abs().max())) < 6e-2         # measured 3.0e-2
 
 
 @pytest.mark.gpu

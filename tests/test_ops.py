@@ -510,3 +510,51 @@ def test_ssim_and_squared_error_vs_torchmetrics_restatement(dev, shape):
     # identical images: SSIM exactly 1 (the clamped variances keep the ratio at (x)(y)/((x)(y)))
     r1 = ops.ssim_sse(b.to(dev), b.to(dev)).cpu()
     assert (r1[:, 0] / (3 * (h - 10) * (w - 10)) - 1).abs().max() < 1e-6 and float(r1[:, 1].abs().max()) == 0.0
+
+
+def _bench_shapes():
+    import importlib.util
+    import os
+    spec = importlib.util.spec_from_file_location("conv_bench", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "conv_bench.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod.SHAPES
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape", _bench_shapes(), ids=lambda s: s[0].replace(" ", "_"))
+def test_conv_at_bench_shapes_gpu(shape):
+    """Every convolution shape of the benched iteration at its FULL spatial size (batch 4..8: thousands of workgroups, many
+    tiles per persistent workgroup, the XCD remap at 10^4 blocks): forward, data gradient and weight gradient of the bf16
+    kernels against torch's fp32 convolution of the same bf16-rounded operands."""
+    name, cin, cout, h, w, stride, ps = shape
+    dev = select("hip")
+    cd = ops.Compute("bf16")
+    torch.manual_seed(17)
+    n = 8 if h * w <= 192 * 192 else 4
+    x = _q(torch.randn(n, cin, h, w), cd)
+    wt = _q(torch.randn(cout, cin, 3, 3) * (2.0 / (9 * cin)) ** 0.5, cd)
+    oh, ow = (h - 1) // stride + 1, (w - 1) // stride + 1
+    xd = _nhwc(x, cd, dev)
+    stats_ok = not ps and cout % 16 == 0
+    wpk = ops.packed_filter(cd, wt.to(dev), L.PACK_FWD_PS if ps else L.PACK_FWD, cd.pad(cin))
+    y, _, stats = ops.conv3x3_raw(cd, xd, wpk, cout, stride=stride, pixel_shuffle=ps, out_f32=(cout == 3), want_stats=stats_ok)
+    xr, wr = leaf(x), leaf(wt)
+    ref = F.conv2d(xr, wr, None, stride, 1)
+    refo = F.pixel_shuffle(ref, 2) if ps else ref
+    assert relerr(_nchw(y)[:, :refo.shape[1]], refo) < (1e-2 if cout != 3 else 1e-4)
+    if stats is not None:
+        s = stats.cpu()
+        assert relerr(s[..., 0], ref.detach().sum((2, 3))) < 1e-3 and relerr(s[..., 1], (ref.detach() ** 2).sum((2, 3))) < 1e-3
+    g = _q(torch.randn_like(refo), cd)
+    refo.backward(g)
+    cpad_out = cd.pad(cout)
+    gd = torch.zeros(n, g.shape[2], g.shape[3], (cpad_out // 4) if ps else cpad_out)
+    gd[..., :g.shape[1]] = g.permute(0, 2, 3, 1)
+    gd = gd.to(cd.torch_dtype).to(dev)
+    wpk_d = ops.packed_filter(cd, wt.to(dev), L.PACK_DGRAD_PS if ps else L.PACK_DGRAD, cpad_out)
+    dx, _, _ = ops.conv3x3_raw(cd, gd, wpk_d, cd.pad(cin) if cin > 3 else 3, mode=L.CONV_DGRAD, out_hw=(h, w), stride=stride,
+                               in_pixel_shuffled=ps, out_f32=(cin == 3))
+    assert relerr(_nchw(dx)[:, :cin], xr.grad) < (1e-2 if cin != 3 else 1e-4)
+    dw = ops.conv3x3_wgrad_raw(cd, xd, gd, cout, cin, stride, dy_pixel_shuffled=ps)
+    assert relerr(dw, wr.grad) < 2e-3

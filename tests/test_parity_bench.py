@@ -28,9 +28,14 @@ def ns(**k):
 #  * the bf16 mode is held to the oracle with the bf16 storage roundings (O.Q_BF16); its distance to the plain fp32 oracle is
 #    reported and loosely bounded.
 F32_VGG_DX, F32_D_GRAD, F32_G_GRAD, F32_G_COS = 2e-2, 2e-2, 0.2, 0.98
-VGGQ_OUT, VGGQ_DX, VGG_BF16_OUT, VGG_BF16_DX = 2e-2, 0.3, 4e-2, 0.7
-STEPQ_LOSS, STEPQ_D_GRAD, STEPQ_G_GRAD, STEPQ_COS = 1e-2, 0.3, 0.5, 0.85
-STEP_BF16_LOSS, STEP_BF16_GRAD, STEP_BF16_COS = 1e-2, 1.0, 0.7
+VGGQ_OUT, VGGQ_DX, VGG_BF16_OUT, VGG_BF16_DX = 1.2e-2, 0.45, 2e-2, 0.7
+#    Measured at cfg #1 (bf16 kernels vs the bf16-storage oracle): the four losses 3e-5, 3e-5, 1.7e-4, 3e-6; gradient tensors
+#    0.15-0.5 relative L2 with norm ratios 0.94-1.01 and cosines 0.995 (D) / 0.90 (G): the forward pass is reproduced to 1e-3,
+#    the gradients are as far apart as two bf16 evaluations of this network that differ in fp32 summation order are (one bf16
+#    ulp in 0.02 % of the activations after the second discriminator block has become a difference in 67 % of them after the
+#    seventh, with 0.1 % LeakyReLU(0.01) sign flips per layer -- tests/conditioning_probe.py).
+STEPQ_LOSS, STEPQ_D_GRAD, STEPQ_G_GRAD, STEPQ_COS_D, STEPQ_COS_G = 1e-3, 0.7, 0.75, 0.98, 0.85
+STEP_BF16_LOSS, STEP_BF16_GRAD, STEP_BF16_COS = 5e-3, 1.0, 0.8
 INF_BF16_MEAN, INF_BF16_MAX = 6e-3, 7e-2
 
 
@@ -112,8 +117,8 @@ def test_train_step_at_baseline_cfg1_size(pkg, cdn):
         return
     want, ref = oracle(O.Q_BF16)
     losses("bf16q", want, STEPQ_LOSS)
-    bad = check_grads("cfg1.bf16q.grad", named_d, ref, t_tensor=STEPQ_D_GRAD, t_cos=STEPQ_COS)
-    bad += check_grads("cfg1.bf16q.grad", named_g, ref, t_tensor=STEPQ_G_GRAD, t_cos=STEPQ_COS)
+    bad = check_grads("cfg1.bf16q.grad", named_d, ref, t_tensor=STEPQ_D_GRAD, t_slope=0.35, t_cos=STEPQ_COS_D)
+    bad += check_grads("cfg1.bf16q.grad", named_g, ref, t_tensor=STEPQ_G_GRAD, t_slope=0.35, t_cos=STEPQ_COS_G)
     assert not bad, bad
     want, ref = oracle(None)
     losses("bf16", want, STEP_BF16_LOSS)
