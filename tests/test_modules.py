@@ -18,7 +18,7 @@ from oracle import srgan_cpu as O
 #   BF16_*  : against the plain fp32 oracle -- how far bf16 arithmetic itself moves this network (sign flips of
 #             ReLU / LeakyReLU(0.01) / max-pool decisions: tens of per cent on whole-network gradients).
 BF16Q_OUT, BF16Q_LOGITS, BF16Q_GRAD, BF16Q_SLOPE, BF16Q_COS = 1e-2, 6e-2, 0.6, 0.35, 0.93
-BF16_OUT, BF16_GRAD, BF16_SCALAR, BF16_COS = 3e-2, 0.8, 1.0, 0.85
+BF16_OUT, BF16_GRAD, BF16_SCALAR, BF16_COS = 3e-2, 1.0, 1.0, 0.9
 
 
 @pytest.fixture(params=BACKENDS)

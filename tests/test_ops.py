@@ -536,6 +536,9 @@ def test_conv_at_bench_shapes_gpu(shape):
     wt = _q(torch.randn(cout, cin, 3, 3) * (2.0 / (9 * cin)) ** 0.5, cd)
     oh, ow = (h - 1) // stride + 1, (w - 1) // stride + 1
     xd = _nhwc(x, cd, dev)
+    if cin == 3:        # the padded-tensor form of a 3-channel input (the product path reads the image directly: test above)
+        xd = torch.zeros(n, h, w, cd.cpad, dtype=cd.torch_dtype, device=dev)
+        xd[..., :3] = _nhwc(x, cd, dev)
     stats_ok = not ps and cout % 16 == 0
     wpk = ops.packed_filter(cd, wt.to(dev), L.PACK_FWD_PS if ps else L.PACK_FWD, cd.pad(cin))
     y, _, stats = ops.conv3x3_raw(cd, xd, wpk, cout, stride=stride, pixel_shuffle=ps, out_f32=(cout == 3), want_stats=stats_ok)
