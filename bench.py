@@ -48,8 +48,21 @@ def ns(**k):
     return types.SimpleNamespace(**k)
 
 
-def make_config(batch, dtype, device):
-    return ns(experiment=ns(name="bench", seed=1234), generator=ns(n_filters=64, n_layers=8),
+WORKLOADS = {
+    # BASELINE.json configs[2] (and [3] per GPU): the headline metric
+    "cfg3": dict(n_layers=8, n_upsample=2, lr=96, batch=32, gflop_ref=686.71,
+                 name="BASELINE configs[2]: full GAN training step, 8 residual blocks / 64 filters, 96x96->384x384",
+                 metric="SR train-step images/sec (96->384 4x, full GAN step: G+D+VGG perceptual loss)"),
+    # BASELINE.json configs[4]: 12 blocks, three pixel-shuffle stages, 128 -> 1024 (16-bit MFMA: bf16 here)
+    "cfg5": dict(n_layers=12, n_upsample=3, lr=128, batch=4, gflop_ref=None,
+                 name="BASELINE configs[4]: full GAN training step, 12 residual blocks / 64 filters, three pixel-shuffle stages, 128x128->1024x1024",
+                 metric="SR train-step images/sec (128->1024 8x, full GAN step: G+D+VGG perceptual loss)"),
+}
+
+
+def make_config(batch, dtype, device, wl=None):
+    wl = wl or WORKLOADS["cfg3"]
+    return ns(experiment=ns(name="bench", seed=1234), generator=ns(n_filters=64, n_layers=wl["n_layers"], n_upsample=wl["n_upsample"]),
               discriminator=ns(n_filters=64, n_layers=7),
               training=ns(compiled=False, device=device, log_iter=10 ** 9, checkpoint_iter=10 ** 9, generator_lr=1e-4,
                           discriminator_lr=1e-4, batch_size=batch, compute_dtype=dtype))
@@ -167,7 +180,8 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=32, help="per-GPU batch")
+    ap.add_argument("--batch", type=int, default=None, help="per-GPU batch (default: 32 for cfg3, 4 for cfg5)")
+    ap.add_argument("--workload", default="cfg3", choices=sorted(WORKLOADS), help="cfg3 = the headline metric; cfg5 = BASELINE configs[4]")
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-inference", action="store_true")
@@ -190,12 +204,18 @@ def main():
     if world != args.gpus:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
 
+    wl = WORKLOADS[args.workload]
+    if args.batch is None:
+        args.batch = wl["batch"]
+    if args.workload != "cfg3":
+        args.no_inference = args.no_f32 = args.no_cpu_baseline = True     # those legs belong to the headline workload
     torch.manual_seed(1234)
-    trainer = pkg.Trainer(make_config(args.batch, args.dtype, device), perceptual_network=pkg.VGG19(compute_dtype=args.dtype, seed=1234))
+    trainer = pkg.Trainer(make_config(args.batch, args.dtype, device, wl), perceptual_network=pkg.VGG19(compute_dtype=args.dtype, seed=1234))
     torch.manual_seed(100 + rank)
     B = args.batch
-    lr = torch.rand(B, 3, 96, 96, device=device) * 2 - 1
-    hr = torch.rand(B, 3, 384, 384, device=device) * 2 - 1
+    hr_size = wl["lr"] * 2 ** wl["n_upsample"]
+    lr = torch.rand(B, 3, wl["lr"], wl["lr"], device=device) * 2 - 1
+    hr = torch.rand(B, 3, hr_size, hr_size, device=device) * 2 - 1
 
     step_fn, launch = build_step(pkg, trainer, lr, hr, not args.no_graph)
     elapsed = time_steps(step_fn, lr, hr, args.steps, args.warmup, world, device)
@@ -253,24 +273,24 @@ def main():
                                     "unit": "TFLOP/s", "ms_per_step": round(sum(r[0] for r in wgr), 3)}}
     executed_gflop_per_image = sum(r[1] for r in rec) / B / 1e9
 
-    out = {"metric": "SR train-step images/sec (96->384 4x, full GAN step: G+D+VGG perceptual loss)",
+    out = {"metric": wl["metric"],
            "value": round(value, 3), "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
            "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
            "dtype": args.dtype, "data": "synthetic (uniform [-1,1) LR/HR tensors resident in HBM; random-init G/D, kaiming-normal VGG19 stand-in)",
-           "config": {"workload": "BASELINE configs[2]: full GAN training step, 8 residual blocks / 64 filters, 96x96->384x384",
+           "config": {"workload": wl["name"],
                       "per_gpu_batch": B, "global_batch": B * world, "parallelism": "dp%d" % world,
                       "collectives": ("rccl world %d" % torch.distributed.get_world_size()) if dist_mod.is_distributed() else "none",
                       "launch": launch},
            "step_gflop_executed_per_image": round(executed_gflop_per_image, 2),
            "step_tflops_executed": round(value * executed_gflop_per_image / 1e3, 2),
-           "step_gflop_reference_graph_per_image": STEP_GFLOP_PER_IMAGE,
+           "step_gflop_reference_graph_per_image": wl["gflop_ref"],
            "roofline": roofline}
 
     if rank == 0 and world == 1 and not args.no_f32 and args.dtype != "f32":
         # the same iteration at the reference's own precision (exact-f32 MFMA: the 1e-3 parity mode), short run
         del step_fn
         torch.manual_seed(1234)
-        t32 = pkg.Trainer(make_config(B, "f32", device), perceptual_network=pkg.VGG19(compute_dtype="f32", seed=1234))
+        t32 = pkg.Trainer(make_config(B, "f32", device, wl), perceptual_network=pkg.VGG19(compute_dtype="f32", seed=1234))
         fn32, launch32 = build_step(pkg, t32, lr, hr, not args.no_graph)
         el = time_steps(fn32, lr, hr, 2, 1, 1, device)
         out["f32_mode"] = {"value": round(B * 2 / el, 3), "unit": "images/s", "ms_per_step": round(el / 2 * 1e3, 2), "steps": 2,

@@ -41,6 +41,13 @@
 #include <stdlib.h>
 #include <utility>
 
+#ifndef FSR_ABL
+#define FSR_ABL 0    // ablation builds (tools/ablate.sh): 1 no filter DMA after the first stage, 2 no halo reloads, 3 neither (WRONG RESULTS)
+#endif
+#ifndef FSR_PIPE
+#define FSR_PIPE 1   // software-pipelined fragment reads (0: A/B builds of the plain main loops, tools/ab_lib.sh)
+#endif
+
 template <typename T> struct Frag;
 template <> struct Frag<bf16_t> { typedef s16x8 type; };
 template <> struct Frag<float> { typedef f32x4 type; };
@@ -262,6 +269,50 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv_igemm_kernel(const ConvK
     }
   };
 
+  // The three taps of one LDS-DMA stage with the fragment reads SOFTWARE-PIPELINED (bf16 tall configuration).  The plain
+  // form above compiles to  {8 or 4 ds_read_b128 -> s_waitcnt lgkmcnt(0) -> 16 MFMAs}  six times per stage: every block of 16
+  // MFMAs (256 matrix-pipe cycles) is preceded by a full LDS round trip during which the wave issues nothing.  Here a stage is
+  // twelve groups of 8 MFMAs (one tap x two 16-channel tiles x four pixel rows); the three reads a group issues -- the next
+  // group's two filter fragments and one of the next tap's four pixel fragments -- go out BEFORE its MFMAs and are waited
+  // for (counted lgkmcnt) only one group later, so LDS latency hides under 128+ cycles of matrix work.  Fragment registers:
+  // 2 x 4 pixel + 2 x 2 filter = 48 (the plain form holds 32).
+  auto stage_mfma3 = [&](const T* wstage, int g) {
+    if constexpr (FSR_PIPE && DMA && G == 3 && MT == 4 && NT == 8 && sizeof(T) == 2 && KC == KSTEP) {
+      int toff[3];
+#pragma unroll
+      for (int j = 0; j < 3; ++j) {
+        const unsigned tc = tap_code(a, g * 3 + j);
+        toff[j] = ((int)(tc & 3u) * HW + (int)((tc >> 2) & 3u)) * PITCHX;
+      }
+      frag_t xf[2][MT], wf[2][2];
+#pragma unroll
+      for (int m = 0; m < MT; ++m) xf[0][m] = *(const frag_t*)(halo + pixbase[m] + toff[0]);
+#pragma unroll
+      for (int n = 0; n < 2; ++n) wf[0][n] = *(const frag_t*)(wstage + wbase[n] + wsw[0]);
+      static_for<0, 12>([&](auto ic) {
+        constexpr int i = decltype(ic)::value;
+        constexpr int t = i / 4, h = i % 4;
+        if constexpr (i + 1 < 12) {
+          constexpr int tn = (i + 1) / 4, hn = (i + 1) % 4;
+#pragma unroll
+          for (int n = 0; n < 2; ++n) wf[(i + 1) & 1][n] = *(const frag_t*)(wstage + (size_t)tn * BN * KC + wbase[hn * 2 + n] + wsw[0]);
+        }
+        if constexpr (t + 1 < 3) xf[(t + 1) & 1][h] = *(const frag_t*)(halo + pixbase[h] + toff[t + 1]);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+#pragma unroll
+          for (int n = 0; n < 2; ++n) acc[m][h * 2 + n] = mfma_bf16_16x16x32(wf[i & 1][n], xf[t & 1][m], acc[m][h * 2 + n]);
+        __builtin_amdgcn_sched_barrier(0);
+      });
+    } else {
+      static_for<0, G>([&](auto jc) {
+        constexpr int j = decltype(jc)::value;
+        tap_mfma(wstage + (size_t)(j * BN) * KC, g * G + j);
+      });
+    }
+  };
+
   auto step_body = [&](auto parity, int c, int t, bool has1, bool has2, int c2, int t2, u32x4 (&mine)[WPT], u32x4 (&other)[WPT]) {
     constexpr int P = decltype(parity)::value;
     if (has2) wload(mine, c2, t2);
@@ -300,7 +351,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv_igemm_kernel(const ConvK
             if (NBLK % NWV == 0 || blk < NBLK) {
               const int row = blk * ROWS + rib;
               const T* g16 = src + (unsigned)(row * a.Cin + ((up ^ swz(row & 15)) * EPB));
-              __builtin_amdgcn_global_load_lds(FSR_GLOBAL_PTR(const void, g16), FSR_LDS_PTR(void, dst + blk * ROWS * KC), 16, 0, 0);
+              FSR_GLDS16(g16, dst + blk * ROWS * KC);
             }
           }
         }
@@ -309,23 +360,33 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv_igemm_kernel(const ConvK
     halo_issue(0);
     dma_stage(0, 0, 0);
     halo_commit();
+    FSR_WAIT_DMA();
     __syncthreads();
     int c = 0, g = 0;
     for (int s = 0; s < nstages; ++s) {
       const int buf = s & 1;
       int cn = c, gn = g + 1;
       if (gn == spc) { gn = 0; ++cn; }
+#if FSR_ABL != 1 && FSR_ABL != 3
       if (s + 1 < nstages) dma_stage(cn, gn, buf ^ 1);   // that buffer was last read in stage s-1, a barrier ago
+#endif
+#if FSR_ABL != 2 && FSR_ABL != 3
       if (g == 0 && c + 1 < nchunks) halo_issue(c + 1);
-      static_for<0, G>([&](auto jc) {
-        constexpr int j = decltype(jc)::value;
-        if (EXACT || g * G + j < a.ntaps) tap_mfma(wl + (size_t)((buf * G + j) * BN) * KC, g * G + j);
-      });
+#endif
+      if constexpr (EXACT) {
+        stage_mfma3(wl + (size_t)(buf * G * BN) * KC, g);
+      } else {
+        static_for<0, G>([&](auto jc) {
+          constexpr int j = decltype(jc)::value;
+          if (g * G + j < a.ntaps) tap_mfma(wl + (size_t)((buf * G + j) * BN) * KC, g * G + j);
+        });
+      }
+      FSR_WAIT_DMA();                          // this wave's pieces of the next stage have landed (issued a stage ago)
       if (gn == 0 && cn < nchunks) {           // the next stage opens a chunk: replace the halo between two barriers
         __syncthreads();
         halo_commit();
       }
-      __syncthreads();                         // (drains the DMA: an LDS-DMA is a pending LDS write on vmcnt)
+      __syncthreads();                         // every wave's pieces are visible
       c = cn;
       g = gn;
     }

@@ -115,11 +115,11 @@ __global__ __launch_bounds__(256) void instnorm_act_bwd_reduce_kernel(const T* _
                                                                       float* __restrict__ sums, float* __restrict__ dprelu,
                                                                       int hw, int c, int slabs) {
   constexpr int E = V16<T>::N;
-  __shared__ float red[256 * 2 * E];
+  __shared__ float red[4][256 / 4 * 2 * E];   // [wave][unit slot][2E]: one value per (wave, channel unit, quantity)
   __shared__ float red_p[4];
   const int cu = c / E;            // <= 256 (host checked)
   const int rows = 256 / cu;       // pixel rows walked in parallel
-  const int tid = threadIdx.x;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int n = blockIdx.x / slabs, slab = blockIdx.x % slabs;
   const int per = (hw + slabs - 1) / slabs;
   const int p0 = slab * per, p1 = (p0 + per < hw) ? p0 + per : hw;
@@ -137,11 +137,7 @@ __global__ __launch_bounds__(256) void instnorm_act_bwd_reduce_kernel(const T* _
       mean[i] = st[2 * i] * inv;
       rstd[i] = rsqrtf(fmaxf(st[2 * i + 1] * inv - mean[i] * mean[i], 0.f) + kEps);
     }
-    for (int p = p0 + row; p < p1; p += rows) {
-      const size_t off = ((size_t)n * hw + p) * c + unit * E;
-      float gv[E], xv[E];
-      V16<T>::ld(g + off, gv);
-      V16<T>::ld(x + off, xv);
+    auto body = [&](const float (&gv)[E], const float (&xv)[E]) {
 #pragma unroll
       for (int i = 0; i < E; ++i) {
         const float xh = (xv[i] - mean[i]) * rstd[i];
@@ -150,24 +146,61 @@ __global__ __launch_bounds__(256) void instnorm_act_bwd_reduce_kernel(const T* _
         s2[i] += gz * xh;
         dp += gv[i] * fminf(xh, 0.f);
       }
+    };
+    int p = p0 + row;
+    for (; p + rows < p1; p += 2 * rows) {     // two pixels per trip: four 16-byte loads in flight per lane
+      const size_t off = ((size_t)n * hw + p) * c + unit * E;
+      float ga[E], xa[E], gb[E], xb[E];
+      V16<T>::ld(g + off, ga);
+      V16<T>::ld(x + off, xa);
+      V16<T>::ld(g + off + (size_t)rows * c, gb);
+      V16<T>::ld(x + off + (size_t)rows * c, xb);
+      body(ga, xa);
+      body(gb, xb);
+    }
+    if (p < p1) {
+      const size_t off = ((size_t)n * hw + p) * c + unit * E;
+      float ga[E], xa[E];
+      V16<T>::ld(g + off, ga);
+      V16<T>::ld(x + off, xa);
+      body(ga, xa);
     }
   }
+  // Lanes of a wave that own the same channel unit (lane % cu equal; cu a power of two <= 64, or every lane its own unit) meet
+  // by a fixed xor butterfly; the four waves then meet in LDS and are added in order.  (The pixel order of a thread and the
+  // butterfly are fixed, so the sums are bit-reproducible.)
+  const int ucu = cu < 64 ? cu : 64;          // distinct units inside one wave
 #pragma unroll
   for (int i = 0; i < E; ++i) {
-    red[(2 * i) * 256 + tid] = s1[i];
-    red[(2 * i + 1) * 256 + tid] = s2[i];
+    for (int o = 32; o >= ucu; o >>= 1) {
+      s1[i] += __shfl_xor(s1[i], o, 64);
+      s2[i] += __shfl_xor(s2[i], o, 64);
+    }
+  }
+  if (lane < ucu) {
+#pragma unroll
+    for (int i = 0; i < E; ++i) {
+      red[wave][lane * 2 * E + 2 * i] = s1[i];
+      red[wave][lane * 2 * E + 2 * i + 1] = s2[i];
+    }
   }
   if (dprelu) {
     dp = wave_sum(dp);
-    if ((tid & 63) == 0) red_p[tid >> 6] = dp;
+    if (lane == 0) red_p[wave] = dp;
   }
   __syncthreads();
-  // thread t < cu*2*E : quantity q = t / cu (0..2E-1), channel unit t % cu
+  // output t: channel unit u = t / (2E), quantity j = t % (2E).  Unit u lives in waves w with (w * 64 + lane) % cu == u:
+  // cu <= 64: lane u of every wave; cu > 64: lane u % 64 of the waves w = u / 64, u / 64 + cu / 64, ...
   for (int t = tid; t < cu * 2 * E; t += 256) {
-    const int q = t / cu, un = t % cu;
+    const int u = t / (2 * E), j = t - u * 2 * E;
     float s = 0.f;
-    for (int r = 0; r < rows; ++r) s += red[q * 256 + r * cu + un];
-    sums[((size_t)blockIdx.x * c + un * E + (q >> 1)) * 2 + (q & 1)] = s;
+    if (cu <= 64) {
+#pragma unroll
+      for (int w = 0; w < 4; ++w) s += red[w][u * 2 * E + j];
+    } else {
+      for (int w = u >> 6; w < 4; w += cu >> 6) s += red[w][(u & 63) * 2 * E + j];
+    }
+    sums[((size_t)blockIdx.x * c + u * E + (j >> 1)) * 2 + (j & 1)] = s;
   }
   if (dprelu && tid == 0) dprelu[blockIdx.x] = red_p[0] + red_p[1] + red_p[2] + red_p[3];
 }

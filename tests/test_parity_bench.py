@@ -148,3 +148,24 @@ def test_generator_inference_shapes_vs_oracle(pkg, hw):
         else:
             assert report("infer.%dx%d.bf16.mean_abs" % hw, float((y - want).abs().mean())) < INF_BF16_MEAN
             assert report("infer.%dx%d.bf16.max_abs" % hw, float((y - want).abs().max())) < INF_BF16_MAX
+
+
+def test_generator_cfg5_full_size_vs_oracle(pkg):
+    """BASELINE configs[4]: 12 residual blocks, three pixel-shuffle stages, 128x128 -> 1024x1024 at FULL size: fp32 mode
+    against the oracle (1e-3), the 16-bit MFMA mode against the same reference (bounded like the inference shapes)."""
+    dev = select("hip")
+    torch.manual_seed(8)
+    G32 = pkg.Generator(ns(n_filters=64, n_layers=12, n_upsample=3), compute_dtype="f32")
+    sd = {k: v.clone() for k, v in G32.state_dict().items()}
+    x = torch.rand(1, 3, 128, 128) * 2 - 1
+    want = O.generator_forward(sd, x)
+    assert want.shape == (1, 3, 1024, 1024)
+    with torch.no_grad():
+        y32 = G32.to(dev).eval()(x.to(dev)).cpu()
+    assert report("cfg5.f32.sr", relerr(y32, want)) < 1e-3
+    G16 = pkg.Generator(ns(n_filters=64, n_layers=12, n_upsample=3), compute_dtype="bf16")
+    G16.load_state_dict(sd)
+    with torch.no_grad():
+        y16 = G16.to(dev).eval()(x.to(dev)).cpu()
+    assert report("cfg5.bf16.mean_abs", float((y16 - want).abs().mean())) < 2e-2
+    assert report("cfg5.bf16.max_abs", float((y16 - want).abs().max())) < 0.3

@@ -41,6 +41,8 @@ def timeit(fn, iters=10):
     torch.cuda.synchronize()
     s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     try:
+        if os.environ.get("FSR_BENCH_EAGER") == "1":    # PMC passes: plain launches
+            raise RuntimeError("eager requested")
         g = torch.cuda.CUDAGraph()
         with torch.cuda.graph(g):
             for _ in range(iters):
