@@ -707,6 +707,8 @@ static int dispatch_T(ConvKArgs& a, int S, hipStream_t stream, ConvKArgs* more =
     // tall tile (256 px x 128 co per workgroup, wave = 64 px x 128 co): 12 fragment reads per 32 MFMAs instead of 16 and
     // half the workgroups; measured +2..7 % on the 128/256-channel layers.  Narrow chunks keep two workgroups per CU.
     if (!th8 && a.Cin >= 128) {
+      // (32-row tiles with 8 waves -- half the filter traffic per FLOP, one workgroup per CU -- measured again with the
+      // pipelined stage: 128-channel layers +-0, 256-channel layers -5 %: not dispatched)
       if (t9 && (sm & 64)) FSR_GO(16, 128, 4, 1, KCN, 1, 3, 1);
       if (t2 && (sm & 64)) FSR_GO(16, 128, 4, 1, KCN, 1, 2, 1);
       FSR_GO(16, 128, 4, 1, KCN, 1);

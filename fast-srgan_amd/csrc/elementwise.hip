@@ -52,6 +52,19 @@ __device__ __forceinline__ float act_dz(float z, int act, float slope) {
   return z > 0.f ? 1.f : slope;
 }
 
+// (sum, sum of squares) pairs of E consecutive channels -> mean / rstd, with 16-byte loads (2E floats, 8E-byte aligned)
+template <int E>
+__device__ __forceinline__ void load_mean_rstd(const float* __restrict__ st, float inv, float (&mean)[E], float (&rstd)[E]) {
+#pragma unroll
+  for (int i = 0; i < E / 2; ++i) {
+    const f32x4 v = *(const f32x4*)(st + 4 * i);
+    mean[2 * i] = v[0] * inv;
+    rstd[2 * i] = rsqrtf(fmaxf(v[1] * inv - mean[2 * i] * mean[2 * i], 0.f) + kEps);
+    mean[2 * i + 1] = v[2] * inv;
+    rstd[2 * i + 1] = rsqrtf(fmaxf(v[3] * inv - mean[2 * i + 1] * mean[2 * i + 1], 0.f) + kEps);
+  }
+}
+
 // blocks along x for a (blocks, images) grid: about 2048 workgroups in total, each thread doing >= 1 unit
 inline int image_blocks(long long units_per_image, int n) {
   long long b = (units_per_image + 255) / 256;
@@ -82,24 +95,37 @@ __global__ __launch_bounds__(256) void instnorm_act_fwd_kernel(const T* __restri
   const int unit = threadIdx.x % cu;
   float mean[E], rstd[E];
   {
-    const float* st = stats + ((size_t)n * c + unit * E) * 2;
-#pragma unroll
-    for (int i = 0; i < E; ++i) {
-      mean[i] = st[2 * i] * inv;
-      rstd[i] = rsqrtf(fmaxf(st[2 * i + 1] * inv - mean[i] * mean[i], 0.f) + kEps);
-    }
+    load_mean_rstd<E>(stats + ((size_t)n * c + unit * E) * 2, inv, mean, rstd);
   }
   const unsigned units = (unsigned)hw * cu;          // per image
   const size_t img = (size_t)n * units * E;
-  for (unsigned u = blockIdx.x * 256 + threadIdx.x; u < units; u += gridDim.x * 256) {
-    float v[E], r[E];
-    V16<T>::ld(x + img + (size_t)u * E, v);
-    if (res) V16<T>::ld(res + img + (size_t)u * E, r);
+  const unsigned step = gridDim.x * 256;
+  auto apply = [&](float (&v)[E], const float (&r)[E]) {
 #pragma unroll
     for (int i = 0; i < E; ++i) {
       const float z = (v[i] - mean[i]) * rstd[i];
       v[i] = fmaxf(z, 0.f) + slope * fminf(z, 0.f) + (res ? r[i] : 0.f);
     }
+  };
+  unsigned u = blockIdx.x * 256 + threadIdx.x;
+  for (; u + step < units; u += 2 * step) {      // two units per trip: up to four 16-byte loads in flight per lane
+    float va[E], ra[E], vb[E], rb[E];
+    V16<T>::ld(x + img + (size_t)u * E, va);
+    V16<T>::ld(x + img + (size_t)(u + step) * E, vb);
+    if (res) {
+      V16<T>::ld(res + img + (size_t)u * E, ra);
+      V16<T>::ld(res + img + (size_t)(u + step) * E, rb);
+    }
+    apply(va, ra);
+    apply(vb, rb);
+    V16<T>::st(out + img + (size_t)u * E, va);
+    V16<T>::st(out + img + (size_t)(u + step) * E, vb);
+  }
+  if (u < units) {
+    float v[E], r[E];
+    V16<T>::ld(x + img + (size_t)u * E, v);
+    if (res) V16<T>::ld(res + img + (size_t)u * E, r);
+    apply(v, r);
     V16<T>::st(out + img + (size_t)u * E, v);
   }
 }
@@ -131,12 +157,7 @@ __global__ __launch_bounds__(256) void instnorm_act_bwd_reduce_kernel(const T* _
 #pragma unroll
   for (int i = 0; i < E; ++i) s1[i] = s2[i] = 0.f;
   if (row < rows) {
-    const float* st = stats + ((size_t)n * c + unit * E) * 2;
-#pragma unroll
-    for (int i = 0; i < E; ++i) {
-      mean[i] = st[2 * i] * inv;
-      rstd[i] = rsqrtf(fmaxf(st[2 * i + 1] * inv - mean[i] * mean[i], 0.f) + kEps);
-    }
+    load_mean_rstd<E>(stats + ((size_t)n * c + unit * E) * 2, inv, mean, rstd);
     auto body = [&](const float (&gv)[E], const float (&xv)[E]) {
 #pragma unroll
       for (int i = 0; i < E; ++i) {
@@ -219,28 +240,45 @@ __global__ __launch_bounds__(256) void instnorm_act_bwd_apply_kernel(const T* __
   const int unit = threadIdx.x % cu;
   float mean[E], rstd[E], m1[E], m2[E];
   {
-    const float* st = stats + ((size_t)n * c + unit * E) * 2;
+    load_mean_rstd<E>(stats + ((size_t)n * c + unit * E) * 2, inv, mean, rstd);
     const float* sm = sums + ((size_t)n * c + unit * E) * 2;
 #pragma unroll
-    for (int i = 0; i < E; ++i) {
-      mean[i] = st[2 * i] * inv;
-      rstd[i] = rsqrtf(fmaxf(st[2 * i + 1] * inv - mean[i] * mean[i], 0.f) + kEps);
-      m1[i] = sm[2 * i] * inv;
-      m2[i] = sm[2 * i + 1] * inv;
+    for (int i = 0; i < E / 2; ++i) {
+      const f32x4 v = *(const f32x4*)(sm + 4 * i);
+      m1[2 * i] = v[0] * inv;
+      m2[2 * i] = v[1] * inv;
+      m1[2 * i + 1] = v[2] * inv;
+      m2[2 * i + 1] = v[3] * inv;
     }
   }
   const unsigned units = (unsigned)hw * cu;
   const size_t img = (size_t)n * units * E;
-  for (unsigned u = blockIdx.x * 256 + threadIdx.x; u < units; u += gridDim.x * 256) {
-    float gv[E], xv[E];
-    V16<T>::ld(g + img + (size_t)u * E, gv);
-    V16<T>::ld(x + img + (size_t)u * E, xv);
+  const unsigned step = gridDim.x * 256;
+  auto apply = [&](const float (&gv)[E], float (&xv)[E]) {
 #pragma unroll
     for (int i = 0; i < E; ++i) {
       const float xh = (xv[i] - mean[i]) * rstd[i];
       const float gz = gv[i] * (xh > 0.f ? 1.f : slope);
       xv[i] = rstd[i] * (gz - m1[i] - xh * m2[i]);
     }
+  };
+  unsigned u = blockIdx.x * 256 + threadIdx.x;
+  for (; u + step < units; u += 2 * step) {      // two units per trip: four 16-byte loads in flight per lane
+    float ga[E], xa[E], gb[E], xb[E];
+    V16<T>::ld(g + img + (size_t)u * E, ga);
+    V16<T>::ld(x + img + (size_t)u * E, xa);
+    V16<T>::ld(g + img + (size_t)(u + step) * E, gb);
+    V16<T>::ld(x + img + (size_t)(u + step) * E, xb);
+    apply(ga, xa);
+    apply(gb, xb);
+    V16<T>::st(dx + img + (size_t)u * E, xa);
+    V16<T>::st(dx + img + (size_t)(u + step) * E, xb);
+  }
+  if (u < units) {
+    float gv[E], xv[E];
+    V16<T>::ld(g + img + (size_t)u * E, gv);
+    V16<T>::ld(x + img + (size_t)u * E, xv);
+    apply(gv, xv);
     V16<T>::st(dx + img + (size_t)u * E, xv);
   }
 }
