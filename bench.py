@@ -189,7 +189,8 @@ def main():
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of hipGraph replays")
     args = ap.parse_args()
 
-    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+    # FSR_BENCH_FORCE_SPAWN=1 takes the launcher path for N = 1 as well (tests: the self-spawn logic on a one-GPU box)
+    if (args.gpus > 1 or os.environ.get("FSR_BENCH_FORCE_SPAWN") == "1") and "WORLD_SIZE" not in os.environ:
         raise SystemExit(respawn_under_launcher(args))
 
     pkg = importlib.import_module("fast-srgan_amd")

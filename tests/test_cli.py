@@ -96,3 +96,25 @@ def test_inference_pipeline_batched_frames(tmp_path):
     x = (torch.from_numpy(frames[0]) / 127.5 - 1.0).permute(2, 0, 1).unsqueeze(0)
     want = O.postprocess_u8(O.generator_forward(sd, x))
     assert np.abs(outs[0].astype(int) - want.astype(int)).mean() < 3.0
+
+
+@pytest.mark.gpu
+def test_bench_self_spawns_ranks_and_runs_the_rccl_path():
+    """`python bench.py --gpus N` without a launcher re-executes itself under torch.distributed.run (here N = 1, forced);
+    with a process group (FSR_FORCE_DIST=1: a 1-rank RCCL world) the step runs as three phase graphs around two real
+    all-reduces and rank 0 prints the contract's JSON line."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, FSR_BENCH_FORCE_SPAWN="1", FSR_FORCE_DIST="1")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1", "--batch", "2",
+                        "--no-cpu-baseline", "--no-inference", "--no-f32"], env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-1500:]
+    line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1]
+    d = json.loads(line)
+    assert d["n_gpus"] == 1 and d["steps"] == 2 and d["unit"] == "images/s" and d["value"] > 0
+    assert d["config"]["collectives"] == "rccl world 1" and d["config"]["launch"].startswith("3 phase hipGraphs")
+    assert d["roofline"]["bound"] == "mfma" and 0 < d["roofline"]["frac"] < 1
