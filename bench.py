@@ -182,7 +182,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=None, help="per-GPU batch (default: 32 for cfg3, 4 for cfg5)")
     ap.add_argument("--workload", default="cfg3", choices=sorted(WORKLOADS), help="cfg3 = the headline metric; cfg5 = BASELINE configs[4]")
-    ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "f16", "f32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-inference", action="store_true")
     ap.add_argument("--no-f32", action="store_true", help="skip the short exact-f32 run")

@@ -12,7 +12,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # FSR_HIP_LIB: another build of the same sources (kernel A/B experiments, tools/ab.py); the default is the in-tree library
 LIB_PATH = os.environ.get("FSR_HIP_LIB") or os.path.join(_HERE, "libfsr_hip.so")
 
-FSR_F32, FSR_BF16 = 0, 1
+FSR_F32, FSR_BF16, FSR_F16 = 0, 1, 2
 ACT_NONE, ACT_RELU, ACT_LEAKY, ACT_PRELU, ACT_TANH = 0, 1, 2, 3, 4
 CONV_FWD, CONV_DGRAD = 0, 1
 PACK_FWD, PACK_FWD_PS, PACK_DGRAD, PACK_DGRAD_PS = 0, 1, 2, 3

@@ -39,11 +39,10 @@ __device__ __forceinline__ unsigned tap64(const ConvKArgs& a, int t) {
 // NT = 16-row tiles of output channels per workgroup: 4 (a 64-channel block) or 1 (THIN: a float output of at most 16
 // channels -- the 64 -> 3 head with its tanh, and the image gradients with their per-channel scale; the filter is then
 // 9 x 16 rows and the kernel streams the 64-channel input at memory speed instead of living one tile per workgroup).
-template <int NT>
+template <typename T, int NT>
 __global__ __launch_bounds__(NTHR64, 2) void conv64_persistent_kernel(const ConvKArgs a) {
   constexpr bool THIN = NT == 1;
   constexpr int ROWS = NT * 16;
-  typedef bf16_t T;
   constexpr int HUNITS = HT * HT * 8;                   // 16-byte units of one halo
   constexpr int HPT = (HUNITS + NTHR64 - 1) / NTHR64;   // 6
   HIP_DYNAMIC_SHARED(char, smem)
@@ -178,7 +177,7 @@ __global__ __launch_bounds__(NTHR64, 2) void conv64_persistent_kernel(const Conv
 #pragma unroll
         for (int m = 0; m < 2; ++m)
 #pragma unroll
-          for (int n = 0; n < NT; ++n) acc[m][n] = mfma_bf16_16x16x32(wf[n], xf[m], acc[m][n]);
+          for (int n = 0; n < NT; ++n) acc[m][n] = mfma16<T>(wf[n], xf[m], acc[m][n]);
       }
     }
 
@@ -234,8 +233,8 @@ __global__ __launch_bounds__(NTHR64, 2) void conv64_persistent_kernel(const Conv
           f32x4 v = acc[m][n] + bias[n];
           if (maskp) {
             const u32x2 t = mkv[m][n];
-            const float mk[4] = {__uint_as_float(t.x << 16), __uint_as_float(t.x & 0xffff0000u),
-                                 __uint_as_float(t.y << 16), __uint_as_float(t.y & 0xffff0000u)};
+            const float mk[4] = {cvt_lo<T>(t.x), cvt_hi<T>(t.x),
+                                 cvt_lo<T>(t.y), cvt_hi<T>(t.y)};
 #pragma unroll
             for (int r = 0; r < 4; ++r) v[r] = mk[r] > 0.f ? v[r] : v[r] * a.dmask_slope;
           }
@@ -245,15 +244,15 @@ __global__ __launch_bounds__(NTHR64, 2) void conv64_persistent_kernel(const Conv
           }
           if (prep) {
             u32x2 pp;
-            pp.x = pack_bf16x2(v[0], v[1]);
-            pp.y = pack_bf16x2(v[2], v[3]);
+            pp.x = pack2<T>(v[0], v[1]);
+            pp.y = pack2<T>(v[2], v[3]);
             *(u32x2*)(prep + off) = pp;
           }
 #pragma unroll
           for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f) + slope * fminf(v[r], 0.f);
           u32x2 pk;
-          pk.x = pack_bf16x2(v[0], v[1]);
-          pk.y = pack_bf16x2(v[2], v[3]);
+          pk.x = pack2<T>(v[0], v[1]);
+          pk.y = pack2<T>(v[2], v[3]);
           *(u32x2*)(outp + off) = pk;
         }
       });
@@ -297,8 +296,8 @@ __global__ __launch_bounds__(NTHR64, 2) void conv64_persistent_kernel(const Conv
 // tile the 32x32 block of dx: tap (ky, kx) feeds class (py, px) = (1 - (ky & 1), 1 - (kx & 1)) from dz[i + (ky == 0),
 // j + (kx == 0)], 144 MFMAs per wave and tile into 32 accumulator tiles (4 classes x 2 rows x 4 channel tiles).  dz is
 // read once, dx (and the fused activation mask) as whole rows.
+template <typename T>
 __global__ __launch_bounds__(NTHR64, 2) void conv64_s2dgrad_kernel(const ConvKArgs a) {
-  typedef bf16_t T;
   constexpr int HUNITS = HT * HT * 8;
   constexpr int HPT = (HUNITS + NTHR64 - 1) / NTHR64;
   HIP_DYNAMIC_SHARED(char, smem)
@@ -388,7 +387,7 @@ __global__ __launch_bounds__(NTHR64, 2) void conv64_s2dgrad_kernel(const ConvKAr
 #pragma unroll
         for (int m = 0; m < 2; ++m)
 #pragma unroll
-          for (int n = 0; n < 4; ++n) acc[q][m][n] = mfma_bf16_16x16x32(wf[n], xf[m], acc[q][m][n]);
+          for (int n = 0; n < 4; ++n) acc[q][m][n] = mfma16<T>(wf[n], xf[m], acc[q][m][n]);
       }
       __builtin_amdgcn_sched_barrier(0);   // 128 accumulators + the prefetched halo: keep fragment live ranges to one tap
     });
@@ -426,14 +425,14 @@ __global__ __launch_bounds__(NTHR64, 2) void conv64_s2dgrad_kernel(const ConvKAr
             f32x4 v = acc[q][m][n];
             if (maskp) {
               const u32x2 tm = mkv[m][n];
-              const float mk[4] = {__uint_as_float(tm.x << 16), __uint_as_float(tm.x & 0xffff0000u),
-                                   __uint_as_float(tm.y << 16), __uint_as_float(tm.y & 0xffff0000u)};
+              const float mk[4] = {cvt_lo<T>(tm.x), cvt_hi<T>(tm.x),
+                                   cvt_lo<T>(tm.y), cvt_hi<T>(tm.y)};
 #pragma unroll
               for (int r = 0; r < 4; ++r) v[r] = mk[r] > 0.f ? v[r] : v[r] * a.dmask_slope;
             }
             u32x2 pk;
-            pk.x = pack_bf16x2(v[0], v[1]);
-            pk.y = pack_bf16x2(v[2], v[3]);
+            pk.x = pack2<T>(v[0], v[1]);
+            pk.y = pack2<T>(v[2], v[3]);
             *(u32x2*)(outp + off) = pk;
           });
         }
@@ -467,7 +466,7 @@ static int persistent_slots() {
 // Stride-2 data gradient, 64 -> 64 channels: 1 = launched, 0 = not this kernel's shape, < 0 = error.
 // `a`: in = dz [N, IH, IW, 64], out = dx [N, FOH, FOW, 64], wpk = the [9][64][64] data-gradient pack.
 int fsr_conv64_s2dgrad_try(int dtype, ConvKArgs& a, hipStream_t stream) {
-  if (dtype != FSR_BF16 || a.Cin != 64 || a.Cout != 64 || a.CoutPad != 64) return 0;
+  if ((dtype != FSR_BF16 && dtype != FSR_F16) || a.Cin != 64 || a.Cout != 64 || a.CoutPad != 64) return 0;
   if (a.ps || a.in_ps || a.out_f32 || a.preact || a.oscale || a.bias || a.stats || a.act != FSR_ACT_NONE) return 0;
   if (a.IH != (a.FOH - 1) / 2 + 1 || a.IW != (a.FOW - 1) / 2 + 1) return 0;
   if ((long long)a.N * a.FOH * a.FOW * 64 >= (1LL << 31)) return 0;
@@ -477,14 +476,16 @@ int fsr_conv64_s2dgrad_try(int dtype, ConvKArgs& a, hipStream_t stream) {
   if (ntiles <= 0 || ntiles > 0x7fffffffLL) return 0;
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute((const void*)conv64_s2dgrad_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS64);
+    (void)hipFuncSetAttribute((const void*)conv64_s2dgrad_kernel<bf16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS64);
+    (void)hipFuncSetAttribute((const void*)conv64_s2dgrad_kernel<f16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS64);
     attr_set = true;
   }
   const int cus = persistent_slots();
   const int per = (int)((ntiles + cus - 1) / cus);
   a.nblk_n = per;
   const int grid = (int)((ntiles + per - 1) / per);
-  hipLaunchKernelGGL(conv64_s2dgrad_kernel, dim3(grid), dim3(NTHR64), LDS64, stream, a);
+  if (dtype == FSR_F16) hipLaunchKernelGGL(conv64_s2dgrad_kernel<f16_t>, dim3(grid), dim3(NTHR64), LDS64, stream, a);
+  else hipLaunchKernelGGL(conv64_s2dgrad_kernel<bf16_t>, dim3(grid), dim3(NTHR64), LDS64, stream, a);
   fsr_note_kernel("conv64_s2dgrad_kernel");
   int rc = fsr_check_launch("conv64_s2dgrad_kernel");
   return rc ? rc : 1;
@@ -492,7 +493,7 @@ int fsr_conv64_s2dgrad_try(int dtype, ConvKArgs& a, hipStream_t stream) {
 
 // Returns 1 if the launch was taken, 0 if the shape is not this kernel's, < 0 on error.
 int fsr_conv64_persistent_try(int dtype, ConvKArgs& a, int S, hipStream_t stream) {
-  if (dtype != FSR_BF16 || S != 1 || a.Cin != 64 || a.ntaps != 9) return 0;
+  if ((dtype != FSR_BF16 && dtype != FSR_F16) || S != 1 || a.Cin != 64 || a.ntaps != 9) return 0;
   // thin: float output of at most 16 channels (head conv, image gradients); otherwise 64-channel blocks
   const bool thin = a.CoutPad == 16 && a.out_f32 && !a.ps && !a.in_ps && !a.stats && !a.preact && !a.dmask;
   if (!thin) {
@@ -518,8 +519,10 @@ int fsr_conv64_persistent_try(int dtype, ConvKArgs& a, int S, hipStream_t stream
   if (ntiles <= 0 || ntiles > 0x7fffffffLL) return 0;
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute((const void*)conv64_persistent_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS64);
-    (void)hipFuncSetAttribute((const void*)conv64_persistent_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS64);
+    (void)hipFuncSetAttribute((const void*)conv64_persistent_kernel<bf16_t, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS64);
+    (void)hipFuncSetAttribute((const void*)conv64_persistent_kernel<bf16_t, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS64);
+    (void)hipFuncSetAttribute((const void*)conv64_persistent_kernel<f16_t, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS64);
+    (void)hipFuncSetAttribute((const void*)conv64_persistent_kernel<f16_t, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS64);
     attr_set = true;
   }
   const int cus = persistent_slots();    // one persistent workgroup per CU (LDS admits exactly one)
@@ -533,8 +536,14 @@ int fsr_conv64_persistent_try(int dtype, ConvKArgs& a, int S, hipStream_t stream
   a.stats_per = per;
   a.stats_P = (a.stats_tpi + per - 1) / per + 1;
   const int grid = (int)((ntiles + per - 1) / per) * nblk;
-  if (thin) hipLaunchKernelGGL(conv64_persistent_kernel<1>, dim3(grid), dim3(NTHR64), 9 * 16 * P64 * 2 + H_BYTES + 16, stream, a);
-  else hipLaunchKernelGGL(conv64_persistent_kernel<4>, dim3(grid), dim3(NTHR64), LDS64, stream, a);
+  const size_t lds_thin = 9 * 16 * P64 * 2 + H_BYTES + 16;
+  if (dtype == FSR_F16) {
+    if (thin) hipLaunchKernelGGL((conv64_persistent_kernel<f16_t, 1>), dim3(grid), dim3(NTHR64), lds_thin, stream, a);
+    else hipLaunchKernelGGL((conv64_persistent_kernel<f16_t, 4>), dim3(grid), dim3(NTHR64), LDS64, stream, a);
+  } else {
+    if (thin) hipLaunchKernelGGL((conv64_persistent_kernel<bf16_t, 1>), dim3(grid), dim3(NTHR64), lds_thin, stream, a);
+    else hipLaunchKernelGGL((conv64_persistent_kernel<bf16_t, 4>), dim3(grid), dim3(NTHR64), LDS64, stream, a);
+  }
   fsr_note_kernel(thin ? "conv64_persistent_kernel<1>" : "conv64_persistent_kernel<4>");
   int rc = fsr_check_launch("conv64_persistent_kernel");
   return rc ? rc : 1;

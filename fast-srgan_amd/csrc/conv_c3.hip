@@ -50,6 +50,7 @@ __device__ __forceinline__ int patch_off(int k) {
 template <typename T> __device__ __forceinline__ float round_T(float v);
 template <> __device__ __forceinline__ float round_T<float>(float v) { return v; }
 template <> __device__ __forceinline__ float round_T<bf16_t>(float v) { return bf2f(f2bf(v)); }
+template <> __device__ __forceinline__ float round_T<f16_t>(float v) { return (float)(f16_t)v; }
 
 // stage rows [y0-1, y0+TH] x cols [x0-1, x0+16] of image n, normalised and rounded to T, as floats.
 // All loads of a thread are issued before the first use: the address of an out-of-image element is clamped to the
@@ -162,15 +163,15 @@ __global__ __launch_bounds__(256) void conv_c3_fwd_kernel(const C3Args a) {
     for (int e = 0; e < 8; ++e) xv[e] = koff[e] >= 0 ? base[koff[e]] : 0.f;
     s16x8 xf16;
     if constexpr (sizeof(T) == 2) {
-      const unsigned p0 = pack_bf16x2(xv[0], xv[1]), p1 = pack_bf16x2(xv[2], xv[3]);
-      const unsigned p2 = pack_bf16x2(xv[4], xv[5]), p3 = pack_bf16x2(xv[6], xv[7]);
+      const unsigned p0 = pack2<T>(xv[0], xv[1]), p1 = pack2<T>(xv[2], xv[3]);
+      const unsigned p2 = pack2<T>(xv[4], xv[5]), p3 = pack2<T>(xv[6], xv[7]);
       xf16 = __builtin_bit_cast(s16x8, (u32x4){p0, p1, p2, p3});
     }
     if constexpr (sizeof(T) == 2) {
       if (wide) {
         f32x4 acc[4];
 #pragma unroll
-        for (int t = 0; t < 4; ++t) acc[t] = mfma_bf16_16x16x32(wf16[t], xf16, (f32x4){0.f, 0.f, 0.f, 0.f});
+        for (int t = 0; t < 4; ++t) acc[t] = mfma16<T>(wf16[t], xf16, (f32x4){0.f, 0.f, 0.f, 0.f});
         if (gx < a.W && gy < a.H) {
           const size_t off = (((size_t)n * a.H + gy) * a.W + gx) * a.cout + nb * 64 + lg * 8;
 #pragma unroll
@@ -179,15 +180,15 @@ __global__ __launch_bounds__(256) void conv_c3_fwd_kernel(const C3Args a) {
             lo += bv[2 * p];
             hi += bv[2 * p + 1];
             if (prep)
-              *(u32x4*)(prep + off + p * 32) = (u32x4){pack_bf16x2(lo[0], lo[1]), pack_bf16x2(lo[2], lo[3]),
-                                                       pack_bf16x2(hi[0], hi[1]), pack_bf16x2(hi[2], hi[3])};
+              *(u32x4*)(prep + off + p * 32) = (u32x4){pack2<T>(lo[0], lo[1]), pack2<T>(lo[2], lo[3]),
+                                                       pack2<T>(hi[0], hi[1]), pack2<T>(hi[2], hi[3])};
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
               lo[q] = fmaxf(lo[q], 0.f) + slope * fminf(lo[q], 0.f);
               hi[q] = fmaxf(hi[q], 0.f) + slope * fminf(hi[q], 0.f);
             }
-            *(u32x4*)(outp + off + p * 32) = (u32x4){pack_bf16x2(lo[0], lo[1]), pack_bf16x2(lo[2], lo[3]),
-                                                     pack_bf16x2(hi[0], hi[1]), pack_bf16x2(hi[2], hi[3])};
+            *(u32x4*)(outp + off + p * 32) = (u32x4){pack2<T>(lo[0], lo[1]), pack2<T>(lo[2], lo[3]),
+                                                     pack2<T>(hi[0], hi[1]), pack2<T>(hi[2], hi[3])};
           }
         }
         continue;
@@ -198,7 +199,7 @@ __global__ __launch_bounds__(256) void conv_c3_fwd_kernel(const C3Args a) {
       if (t < ntile) {
         f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
         if constexpr (sizeof(T) == 2) {
-          acc = mfma_bf16_16x16x32(wf16[t], xf16, acc);
+          acc = mfma16<T>(wf16[t], xf16, acc);
         } else {
 #pragma unroll
           for (int j = 0; j < 8; ++j) acc = mfma_f32_16x16x4(wf32[t][j], xv[j], acc);
@@ -210,8 +211,8 @@ __global__ __launch_bounds__(256) void conv_c3_fwd_kernel(const C3Args a) {
           if constexpr (sizeof(T) == 2) {
             if (prep) {
               u32x2 pk;
-              pk.x = pack_bf16x2(acc[0], acc[1]);
-              pk.y = pack_bf16x2(acc[2], acc[3]);
+              pk.x = pack2<T>(acc[0], acc[1]);
+              pk.y = pack2<T>(acc[2], acc[3]);
               *(u32x2*)(prep + off) = pk;
             }
           } else {
@@ -221,8 +222,8 @@ __global__ __launch_bounds__(256) void conv_c3_fwd_kernel(const C3Args a) {
           for (int q = 0; q < 4; ++q) acc[q] = fmaxf(acc[q], 0.f) + slope * fminf(acc[q], 0.f);
           if constexpr (sizeof(T) == 2) {
             u32x2 pk;
-            pk.x = pack_bf16x2(acc[0], acc[1]);
-            pk.y = pack_bf16x2(acc[2], acc[3]);
+            pk.x = pack2<T>(acc[0], acc[1]);
+            pk.y = pack2<T>(acc[2], acc[3]);
             *(u32x2*)(outp + off) = pk;
           } else {
             *(f32x4*)(outp + off) = acc;
@@ -304,12 +305,12 @@ __global__ __launch_bounds__(256) void conv_c3_wgrad_kernel(const C3Args a) {
           b0[e] = pb[e * 3 + off0];
           b1[e] = off1 >= 0 ? pb[e * 3 + off1] : ones27;
         }
-        const s16x8 bf0 = __builtin_bit_cast(s16x8, (u32x4){pack_bf16x2(b0[0], b0[1]), pack_bf16x2(b0[2], b0[3]),
-                                                           pack_bf16x2(b0[4], b0[5]), pack_bf16x2(b0[6], b0[7])});
-        const s16x8 bf1 = __builtin_bit_cast(s16x8, (u32x4){pack_bf16x2(b1[0], b1[1]), pack_bf16x2(b1[2], b1[3]),
-                                                           pack_bf16x2(b1[4], b1[5]), pack_bf16x2(b1[6], b1[7])});
-        acc0 = mfma_bf16_16x16x32(af, bf0, acc0);
-        acc1 = mfma_bf16_16x16x32(af, bf1, acc1);
+        const s16x8 bf0 = __builtin_bit_cast(s16x8, (u32x4){pack2<T>(b0[0], b0[1]), pack2<T>(b0[2], b0[3]),
+                                                           pack2<T>(b0[4], b0[5]), pack2<T>(b0[6], b0[7])});
+        const s16x8 bf1 = __builtin_bit_cast(s16x8, (u32x4){pack2<T>(b1[0], b1[1]), pack2<T>(b1[2], b1[3]),
+                                                           pack2<T>(b1[4], b1[5]), pack2<T>(b1[6], b1[7])});
+        acc0 = mfma16<T>(af, bf0, acc0);
+        acc1 = mfma16<T>(af, bf1, acc1);
       }
     } else {
       // K step = 4 pixels of one row: pixel k = lg -> (row s>>2, column 4(s&3) + lg)
@@ -382,7 +383,7 @@ __global__ void pack_c3_kernel(const float* __restrict__ w, T* __restrict__ out,
 
 int fill_args(C3Args& a, const char* what, int dtype, const float* img, long long sn, long long sc, long long sh,
               long long sw, int n, int h, int w, const float (&scale3)[3], const float (&shift3)[3], int cout) {
-  if (dtype != FSR_F32 && dtype != FSR_BF16) return fsr_fail(-2, "%s: unknown dtype %d", what, dtype);
+  if (dtype != FSR_F32 && dtype != FSR_BF16 && dtype != FSR_F16) return fsr_fail(-2, "%s: unknown dtype %d", what, dtype);
   if (!img) return fsr_fail(-1, "%s: null image", what);
   if (n <= 0 || h <= 0 || w <= 0) return fsr_fail(-2, "%s: bad dims", what);
   if (cout <= 0 || cout % 16) return fsr_fail(-2, "%s: cout=%d is not a multiple of 16", what, cout);
@@ -406,6 +407,8 @@ extern "C" int fsr_pack_conv3x3_c3(int dtype, const float* w_oihw, int cout, voi
   const int blocks = (rows_pad * 32 + 255) / 256;
   if (dtype == FSR_BF16)
     hipLaunchKernelGGL(pack_c3_kernel<bf16_t>, dim3(blocks), dim3(256), 0, (hipStream_t)stream_, w_oihw, (bf16_t*)packed, cout, rows_pad);
+  else if (dtype == FSR_F16)
+    hipLaunchKernelGGL(pack_c3_kernel<f16_t>, dim3(blocks), dim3(256), 0, (hipStream_t)stream_, w_oihw, (f16_t*)packed, cout, rows_pad);
   else if (dtype == FSR_F32)
     hipLaunchKernelGGL(pack_c3_kernel<float>, dim3(blocks), dim3(256), 0, (hipStream_t)stream_, w_oihw, (float*)packed, cout, rows_pad);
   else
@@ -436,6 +439,7 @@ extern "C" int fsr_conv3x3_c3_fwd(int dtype, const float* img, long long sn, lon
   if (nwg > 0x7fffffffLL) return fsr_fail(-2, "fsr_conv3x3_c3_fwd: bad grid");
   const dim3 grid((unsigned)nwg, (unsigned)((cout + 63) / 64));
   if (dtype == FSR_BF16) hipLaunchKernelGGL(conv_c3_fwd_kernel<bf16_t>, grid, dim3(256), 0, (hipStream_t)stream_, a);
+  else if (dtype == FSR_F16) hipLaunchKernelGGL(conv_c3_fwd_kernel<f16_t>, grid, dim3(256), 0, (hipStream_t)stream_, a);
   else hipLaunchKernelGGL(conv_c3_fwd_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream_, a);
   return fsr_check_launch("conv_c3_fwd_kernel");
 }
@@ -470,6 +474,7 @@ extern "C" int fsr_conv3x3_c3_wgrad(int dtype, const float* img, long long sn, l
   a.ntiles = a.tiles_x * a.tiles_y * n;
   const dim3 grid((unsigned)nslab, (unsigned)((cout + 63) / 64));
   if (dtype == FSR_BF16) hipLaunchKernelGGL(conv_c3_wgrad_kernel<bf16_t>, grid, dim3(256), 0, (hipStream_t)stream_, a);
+  else if (dtype == FSR_F16) hipLaunchKernelGGL(conv_c3_wgrad_kernel<f16_t>, grid, dim3(256), 0, (hipStream_t)stream_, a);
   else hipLaunchKernelGGL(conv_c3_wgrad_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream_, a);
   if (int rc = fsr_check_launch("conv_c3_wgrad_kernel")) return rc;
   hipLaunchKernelGGL(conv_c3_wgrad_reduce_kernel, dim3(cout), dim3(256), 0, (hipStream_t)stream_, (const float*)workspace,

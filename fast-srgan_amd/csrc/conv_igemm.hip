@@ -50,6 +50,7 @@
 
 template <typename T> struct Frag;
 template <> struct Frag<bf16_t> { typedef s16x8 type; };
+template <> struct Frag<f16_t> { typedef s16x8 type; };
 template <> struct Frag<float> { typedef f32x4 type; };
 
 // tap t of the launch: bits 0-1 halo row offset, bits 2-3 halo column offset, bits 4-7 filter slice
@@ -71,8 +72,8 @@ __device__ __forceinline__ void store_vec4(T* p, f32x4 v) {
     *(f32x4*)p = v;
   } else {
     u32x2 pk;
-    pk.x = pack_bf16x2(v[0], v[1]);
-    pk.y = pack_bf16x2(v[2], v[3]);
+    pk.x = pack2<T>(v[0], v[1]);
+    pk.y = pack2<T>(v[2], v[3]);
     *(u32x2*)p = pk;
   }
 }
@@ -258,7 +259,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv_igemm_kernel(const ConvK
 #pragma unroll
           for (int n = 0; n < NH; ++n) {
             if constexpr (sizeof(T) == 2) {
-              acc[m][n0 + n] = mfma_bf16_16x16x32(wf[n], xf[m], acc[m][n0 + n]);
+              acc[m][n0 + n] = mfma16<T>(wf[n], xf[m], acc[m][n0 + n]);
             } else {
 #pragma unroll
               for (int j = 0; j < 4; ++j) acc[m][n0 + n] = mfma_f32_16x16x4(wf[n][j], xf[m][j], acc[m][n0 + n]);
@@ -302,7 +303,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv_igemm_kernel(const ConvK
 #pragma unroll
         for (int m = 0; m < MT; ++m)
 #pragma unroll
-          for (int n = 0; n < 2; ++n) acc[m][h * 2 + n] = mfma_bf16_16x16x32(wf[i & 1][n], xf[t & 1][m], acc[m][h * 2 + n]);
+          for (int n = 0; n < 2; ++n) acc[m][h * 2 + n] = mfma16<T>(wf[i & 1][n], xf[t & 1][m], acc[m][h * 2 + n]);
         __builtin_amdgcn_sched_barrier(0);
       });
     } else {
@@ -488,7 +489,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv_igemm_kernel(const ConvK
               v = (a.act == FSR_ACT_TANH) ? tanhf(v) : (v > 0.f ? v : v * slope);
               if (a.out_f32 == FSR_OUT_U8) ((unsigned char*)a.out)[off + r] = image_u8(v);
               else if (a.out_f32 || sizeof(T) == 4) ((float*)a.out)[off + r] = v;
-              else ((bf16_t*)a.out)[off + r] = f2bf(v);
+              else ElemIO<T>::st((T*)a.out + (off + r), v);
             }
         }
       });
@@ -553,8 +554,8 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv_igemm_kernel(const ConvK
             u32x2 t;
             if (premask) t = mkreg[PREMASK ? n : 0][PREMASK ? m : 0];
             else t = *(const u32x2*)(maskp + (base + m * rstride));
-            mk[0] = __uint_as_float(t.x << 16); mk[1] = __uint_as_float(t.x & 0xffff0000u);
-            mk[2] = __uint_as_float(t.y << 16); mk[3] = __uint_as_float(t.y & 0xffff0000u);
+            mk[0] = cvt_lo<T>(t.x); mk[1] = cvt_hi<T>(t.x);
+            mk[2] = cvt_lo<T>(t.y); mk[3] = cvt_hi<T>(t.y);
           }
 #pragma unroll
           for (int r = 0; r < 4; ++r) v[r] = mk[r] > 0.f ? v[r] : v[r] * a.dmask_slope;
@@ -661,7 +662,7 @@ static int launch_cfg(ConvKArgs& a, hipStream_t stream, ConvKArgs* more = nullpt
     attr_set = true;
   }
   hipLaunchKernelGGL(kern, dim3((unsigned)nwg), dim3(WM * WN * 64), lds, stream, a, cls);
-  fsr_note_kernel("conv_igemm_kernel<%s,%d,%d,%d,%d,%d,%d,%d,%d>", sizeof(T) == 2 ? "bf16" : "f32", TH, BN, WM, WN, KC, S, G, DMA);
+  fsr_note_kernel("conv_igemm_kernel<%s,%d,%d,%d,%d,%d,%d,%d,%d>", sizeof(T) == 4 ? "f32" : (std::is_same<T, f16_t>::value ? "f16" : "bf16"), TH, BN, WM, WN, KC, S, G, DMA);
   return fsr_check_launch("conv_igemm_kernel");
 }
 
@@ -747,6 +748,7 @@ static int dispatch_T(ConvKArgs& a, int S, hipStream_t stream, ConvKArgs* more =
 int fsr_conv_igemm_dispatch_classes(int dtype, ConvKArgs* cls, int n, hipStream_t stream) {
   if (n < 1 || n > 4) return fsr_fail(-2, "conv3x3: %d classes in one launch", n);
   if (dtype == FSR_BF16) return dispatch_T<bf16_t, 64, 32>(cls[0], 1, stream, cls + 1, n - 1);
+  if (dtype == FSR_F16) return dispatch_T<f16_t, 64, 32>(cls[0], 1, stream, cls + 1, n - 1);
   if (dtype == FSR_F32) return dispatch_T<float, 16, 16>(cls[0], 1, stream, cls + 1, n - 1);
   return fsr_fail(-2, "conv3x3: unknown dtype %d", dtype);
 }
@@ -755,6 +757,7 @@ int fsr_conv_igemm_dispatch(int dtype, ConvKArgs& a, int S, hipStream_t stream) 
   // 64 -> 64 channel stride-1 layers: persistent kernel with the whole filter resident in LDS (conv64_persistent.hip)
   if (const int rc = fsr_conv64_persistent_try(dtype, a, S, stream)) return rc < 0 ? rc : 0;
   if (dtype == FSR_BF16) return dispatch_T<bf16_t, 64, 32>(a, S, stream);
+  if (dtype == FSR_F16) return dispatch_T<f16_t, 64, 32>(a, S, stream);
   if (dtype == FSR_F32) return dispatch_T<float, 16, 16>(a, S, stream);
   return fsr_fail(-2, "conv3x3: unknown dtype %d", dtype);
 }

@@ -175,14 +175,14 @@ __global__ __launch_bounds__((BM == 64 && BN == 64) ? 512 : 256) void conv_wgrad
             const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(FSR_LDS_PTR(s16x4, pb0 + 4 * S * PB));
             const s16x8 bf = (s16x8){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
 #pragma unroll
-            for (int w = 0; w < TPW; ++w) acc[t][w] = mfma_bf16_16x16x32(af[w], bf, acc[t][w]);
+            for (int w = 0; w < TPW; ++w) acc[t][w] = mfma16<T>(af[w], bf, acc[t][w]);
           } else {
 #pragma unroll
             for (int j = 0; j < TPW; ++j) {
               const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(FSR_LDS_PTR(s16x4, pb0 + j * 16));
               const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(FSR_LDS_PTR(s16x4, pb0 + j * 16 + 4 * S * PB));
               const s16x8 bf = (s16x8){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-              acc[t][j] = mfma_bf16_16x16x32(af[0], bf, acc[t][j]);
+              acc[t][j] = mfma16<T>(af[0], bf, acc[t][j]);
             }
           }
         }
@@ -274,12 +274,12 @@ struct WgradPlan {
 
 int make_plan(const fsr_wgrad_desc* d, WgradPlan& p) {
   if (!d) return fsr_fail(-1, "conv3x3_wgrad: null descriptor");
-  if (d->dtype != FSR_F32 && d->dtype != FSR_BF16) return fsr_fail(-2, "conv3x3_wgrad: unknown dtype %d", d->dtype);
-  const int cpad = d->dtype == FSR_BF16 ? 32 : 16;
+  if (d->dtype != FSR_F32 && d->dtype != FSR_BF16 && d->dtype != FSR_F16) return fsr_fail(-2, "conv3x3_wgrad: unknown dtype %d", d->dtype);
+  const int cpad = d->dtype != FSR_F32 ? 32 : 16;
   if (d->stride != 1 && d->stride != 2) return fsr_fail(-2, "conv3x3_wgrad: stride must be 1 or 2");
   if (d->cin_pad % cpad || d->cin_pad <= 0) return fsr_fail(-2, "conv3x3_wgrad: cin_pad %d is not a multiple of %d", d->cin_pad, cpad);
   if (d->cout_pad % 16 || d->cout_pad <= 0) return fsr_fail(-2, "conv3x3_wgrad: cout_pad %d is not a multiple of 16", d->cout_pad);
-  if (d->dtype == FSR_BF16 && d->cout_pad % 8) return fsr_fail(-2, "conv3x3_wgrad: bad cout_pad");
+  if (d->dtype != FSR_F32 && d->cout_pad % 8) return fsr_fail(-2, "conv3x3_wgrad: bad cout_pad");
   if (d->cin > d->cin_pad || d->cout > d->cout_pad || d->cin <= 0 || d->cout <= 0) return fsr_fail(-2, "conv3x3_wgrad: bad channel counts");
   if (d->oh != (d->ih - 1) / d->stride + 1 || d->ow != (d->iw - 1) / d->stride + 1)
     return fsr_fail(-2, "conv3x3_wgrad: output dims do not match k=3,p=1,stride=%d", d->stride);
@@ -291,7 +291,7 @@ int make_plan(const fsr_wgrad_desc* d, WgradPlan& p) {
   p.BM = (d->cout_pad % 64 == 0) ? 64 : 16;
   p.BN = (d->cin_pad % 64 == 0) ? 64 : (d->cin_pad % 32 == 0 ? 32 : 16);
   if (d->dy_pixel_shuffled && (d->cout_pad / 4) % p.BM) p.BM = 16;  // a BM block must stay inside one quadrant slice
-  p.TPH = d->dtype == FSR_BF16 ? 8 : 4;
+  p.TPH = d->dtype != FSR_F32 ? 8 : 4;
   p.tiles_x = (d->ow + 15) / 16;
   p.tiles_y = (d->oh + p.TPH - 1) / p.TPH;
   p.tiles_total = p.tiles_x * p.tiles_y * d->n;
@@ -305,7 +305,7 @@ int make_plan(const fsr_wgrad_desc* d, WgradPlan& p) {
   if (want < 1) want = 1;
   p.tiles_per_slab = (p.tiles_total + want - 1) / want;
   p.nslab = (p.tiles_total + p.tiles_per_slab - 1) / p.tiles_per_slab;
-  const int es = d->dtype == FSR_BF16 ? 2 : 4;
+  const int es = d->dtype != FSR_F32 ? 2 : 4;
   const int HH = (p.TPH - 1) * p.S + 3, HW = 15 * p.S + 3;
   p.lds = ((size_t)p.TPH * 16 * (p.BM + 16) + (size_t)HH * HW * (p.BN + 16)) * es;
   return 0;
@@ -373,7 +373,8 @@ extern "C" int fsr_conv3x3_wgrad(const fsr_wgrad_desc* d, const void* x, const v
   a.nslab = p.nslab;
   a.nbm = p.nbm;
   a.nbn = p.nbn;
-  int rc = d->dtype == FSR_BF16 ? dispatch_wgrad<bf16_t, 8>(p, a, stream) : dispatch_wgrad<float, 4>(p, a, stream);
+  int rc = d->dtype == FSR_BF16 ? dispatch_wgrad<bf16_t, 8>(p, a, stream)
+           : (d->dtype == FSR_F16 ? dispatch_wgrad<f16_t, 8>(p, a, stream) : dispatch_wgrad<float, 4>(p, a, stream));
   if (rc) return rc;
   const int total = 9 * d->cout * d->cin;
   int blocks = (total + 31) / 32;

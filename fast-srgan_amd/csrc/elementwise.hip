@@ -16,7 +16,25 @@ namespace {
 
 constexpr float kEps = 1e-5f;  // torch.nn.InstanceNorm2d default eps
 
-template <typename T> struct V16;  // one 16-byte unit of T viewed as floats
+// one 16-byte unit of T viewed as floats
+template <typename T> struct V16 {   // the 16-bit storage types (bf16_t, f16_t): 8 elements per 16-byte unit
+  static constexpr int N = 8;
+  static __device__ __forceinline__ void ld(const T* p, float (&v)[8]) {
+    const u32x4 t = *(const u32x4*)p;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      v[2 * i] = cvt_lo<T>(t[i]);
+      v[2 * i + 1] = cvt_hi<T>(t[i]);
+    }
+  }
+  static __device__ __forceinline__ void st(T* p, const float (&v)[8]) {
+    u32x4 t;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) t[i] = pack2<T>(v[2 * i], v[2 * i + 1]);
+    *(u32x4*)p = t;
+  }
+};
+
 template <> struct V16<float> {
   static constexpr int N = 4;
   static __device__ __forceinline__ void ld(const float* p, float (&v)[4]) {
@@ -27,24 +45,6 @@ template <> struct V16<float> {
     *(f32x4*)p = (f32x4){v[0], v[1], v[2], v[3]};
   }
 };
-template <> struct V16<bf16_t> {
-  static constexpr int N = 8;
-  static __device__ __forceinline__ void ld(const bf16_t* p, float (&v)[8]) {
-    const u32x4 t = *(const u32x4*)p;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      v[2 * i] = __uint_as_float(t[i] << 16);
-      v[2 * i + 1] = __uint_as_float(t[i] & 0xffff0000u);
-    }
-  }
-  static __device__ __forceinline__ void st(bf16_t* p, const float (&v)[8]) {
-    u32x4 t;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) t[i] = pack_bf16x2(v[2 * i], v[2 * i + 1]);
-    *(u32x4*)p = t;
-  }
-};
-
 // derivative with respect to the pre-activation, evaluated from the pre-activation
 __device__ __forceinline__ float act_dz(float z, int act, float slope) {
   if (act == FSR_ACT_NONE) return 1.f;
@@ -508,15 +508,15 @@ template <typename T> T* P(void* p) { return (T*)p; }
 template <typename T> const T* P(const void* p) { return (const T*)p; }
 
 int check_c(const char* what, int dtype, int c) {
-  const int e = dtype == FSR_BF16 ? 8 : 4;
-  if (dtype != FSR_F32 && dtype != FSR_BF16) return fsr_fail(-2, "%s: unknown dtype %d", what, dtype);
+  const int e = dtype != FSR_F32 ? 8 : 4;
+  if (dtype != FSR_F32 && dtype != FSR_BF16 && dtype != FSR_F16) return fsr_fail(-2, "%s: unknown dtype %d", what, dtype);
   if (c <= 0 || c % e != 0) return fsr_fail(-2, "%s: channel count %d is not a multiple of %d", what, c, e);
   return 0;
 }
 int check_reduce_c(const char* what, int dtype, int c) {
   int rc = check_c(what, dtype, c);
   if (rc) return rc;
-  const int cu = c / (dtype == FSR_BF16 ? 8 : 4);
+  const int cu = c / (dtype != FSR_F32 ? 8 : 4);
   if (cu > 256 || 256 % cu != 0) return fsr_fail(-2, "%s: %d channels do not tile a 256-thread workgroup", what, c);
   return 0;
 }
@@ -534,6 +534,9 @@ int slabs_for(int n, int hw) {
   if ((dtype) == FSR_BF16) {                          \
     typedef bf16_t T;                                 \
     __VA_ARGS__                                       \
+  } else if ((dtype) == FSR_F16) {                    \
+    typedef f16_t T;                                  \
+    __VA_ARGS__                                       \
   } else {                                            \
     typedef float T;                                  \
     __VA_ARGS__                                       \
@@ -545,7 +548,7 @@ extern "C" int fsr_instnorm_act_fwd(int dtype, const void* x, const float* stats
   if (!x || !stats || !out) return fsr_fail(-1, "fsr_instnorm_act_fwd: null argument");
   if (act == FSR_ACT_PRELU && !prelu_weight) return fsr_fail(-1, "fsr_instnorm_act_fwd: PReLU needs its weight");
   if (int rc = check_reduce_c("fsr_instnorm_act_fwd", dtype, c)) return rc;
-  const long long units = (long long)hw * (c / (dtype == FSR_BF16 ? 8 : 4));   // per image
+  const long long units = (long long)hw * (c / (dtype != FSR_F32 ? 8 : 4));   // per image
   if (units >= (1LL << 31)) return fsr_fail(-2, "fsr_instnorm_act_fwd: image too large");
   FSR_DISPATCH_T(dtype, hipLaunchKernelGGL(instnorm_act_fwd_kernel<T>, dim3(image_blocks(units, n), n), dim3(256), 0,
                                            stream, P<T>(x), stats, P<T>(res), act, slope, prelu_weight, P<T>(out), hw, c);)
@@ -583,7 +586,7 @@ extern "C" int fsr_instnorm_act_bwd_apply(int dtype, const void* g, const void* 
   if (!g || !x || !stats || !sums || !dx) return fsr_fail(-1, "fsr_instnorm_act_bwd_apply: null argument");
   if (act == FSR_ACT_PRELU && !prelu_weight) return fsr_fail(-1, "fsr_instnorm_act_bwd_apply: PReLU needs its weight");
   if (int rc = check_reduce_c("fsr_instnorm_act_bwd_apply", dtype, c)) return rc;
-  const long long units = (long long)hw * (c / (dtype == FSR_BF16 ? 8 : 4));
+  const long long units = (long long)hw * (c / (dtype != FSR_F32 ? 8 : 4));
   if (units >= (1LL << 31)) return fsr_fail(-2, "fsr_instnorm_act_bwd_apply: image too large");
   FSR_DISPATCH_T(dtype, hipLaunchKernelGGL(instnorm_act_bwd_apply_kernel<T>, dim3(image_blocks(units, n), n), dim3(256), 0,
                                            stream, P<T>(g), P<T>(x), stats, sums, act, slope, prelu_weight, P<T>(dx), hw, c);)
@@ -631,7 +634,7 @@ extern "C" int fsr_image_to_nhwc(int dtype, const float* img, long long sn, long
   hipStream_t stream = (hipStream_t)stream_;
   if (!img || !out) return fsr_fail(-1, "fsr_image_to_nhwc: null argument");
   if (int rc = check_c("fsr_image_to_nhwc", dtype, cpad)) return rc;
-  const int rowunits = w * (cpad / (dtype == FSR_BF16 ? 8 : 4));
+  const int rowunits = w * (cpad / (dtype != FSR_F32 ? 8 : 4));
   FSR_DISPATCH_T(dtype, hipLaunchKernelGGL(image_to_nhwc_kernel<T>, dim3(n * h, row_blocks(rowunits)), dim3(256), 0, stream,
                                            img, sn, sc, sh, sw, h, w, scale0, scale1, scale2, shift0, shift1, shift2,
                                            P<T>(out), cpad);)
@@ -655,7 +658,7 @@ extern "C" int fsr_tanh_bwd_to_nhwc(int dtype, const float* g, long long sn, lon
   if (!g || !y_nhwc3 || !dz) return fsr_fail(-1, "fsr_tanh_bwd_to_nhwc: null argument");
   if (dbias && !scratch) return fsr_fail(-1, "fsr_tanh_bwd_to_nhwc: the bias gradient needs the scratch buffer");
   if (int rc = check_c("fsr_tanh_bwd_to_nhwc", dtype, cpad)) return rc;
-  const int rowunits = w * (cpad / (dtype == FSR_BF16 ? 8 : 4));
+  const int rowunits = w * (cpad / (dtype != FSR_F32 ? 8 : 4));
   const int gx = n * h < 512 ? n * h : 512, gy = row_blocks(rowunits);   // <= 512 x 64 workgroups
   FSR_DISPATCH_T(dtype, hipLaunchKernelGGL(tanh_bwd_to_nhwc_kernel<T>, dim3(gx, gy), dim3(256), 0,
                                            stream, g, sn, sc, sh, sw, y_nhwc3, h, w, P<T>(dz), cpad, n * h,
@@ -670,7 +673,7 @@ extern "C" int fsr_maxpool2_fwd(int dtype, const void* x, void* y, int n, int h,
   if (!x || !y) return fsr_fail(-1, "fsr_maxpool2_fwd: null argument");
   if (int rc = check_c("fsr_maxpool2_fwd", dtype, c)) return rc;
   if ((h | w) & 1) return fsr_fail(-2, "fsr_maxpool2_fwd: odd extent %dx%d", h, w);
-  const int rowunits = (w / 2) * (c / (dtype == FSR_BF16 ? 8 : 4));
+  const int rowunits = (w / 2) * (c / (dtype != FSR_F32 ? 8 : 4));
   FSR_DISPATCH_T(dtype, hipLaunchKernelGGL(maxpool2_fwd_kernel<T>, dim3(n * (h / 2), row_blocks(rowunits)), dim3(256), 0,
                                            stream, P<T>(x), P<T>(y), h, w, c);)
   return fsr_check_launch("maxpool2_fwd_kernel");
@@ -682,7 +685,7 @@ extern "C" int fsr_maxpool2_bwd(int dtype, const void* g, const void* x, const v
   if (!g || !x || !y || !dx) return fsr_fail(-1, "fsr_maxpool2_bwd: null argument");
   if (int rc = check_c("fsr_maxpool2_bwd", dtype, c)) return rc;
   if ((h | w) & 1) return fsr_fail(-2, "fsr_maxpool2_bwd: odd extent %dx%d", h, w);
-  const int rowunits = (w / 2) * (c / (dtype == FSR_BF16 ? 8 : 4));
+  const int rowunits = (w / 2) * (c / (dtype != FSR_F32 ? 8 : 4));
   FSR_DISPATCH_T(dtype, hipLaunchKernelGGL(maxpool2_bwd_kernel<T>, dim3(n * (h / 2), row_blocks(rowunits)), dim3(256), 0,
                                            stream, P<T>(g), P<T>(x), P<T>(y), P<T>(dx), h, w, c, relu_mask);)
   return fsr_check_launch("maxpool2_bwd_kernel");

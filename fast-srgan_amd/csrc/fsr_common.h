@@ -14,6 +14,7 @@
 #include <type_traits>
 
 typedef unsigned short bf16_t;  // raw bf16 bits
+typedef _Float16 f16_t;         // IEEE half (FSR_F16: the fp16-MFMA mode of BASELINE configs[4])
 
 typedef short s16x8 __attribute__((ext_vector_type(8)));
 typedef short s16x4 __attribute__((ext_vector_type(4)));
@@ -79,11 +80,42 @@ template <> struct ElemIO<bf16_t> {
   static __device__ __forceinline__ float ld(const bf16_t* p) { return bf2f(*p); }
   static __device__ __forceinline__ void st(bf16_t* p, float v) { *p = f2bf(v); }
 };
+template <> struct ElemIO<f16_t> {
+  static __device__ __forceinline__ float ld(const f16_t* p) { return (float)*p; }
+  static __device__ __forceinline__ void st(f16_t* p, float v) { *p = (f16_t)v; }
+};
 
 __device__ __forceinline__ f32x4 mfma_bf16_16x16x32(s16x8 a, s16x8 b, f32x4 c) {
   return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_hw, a),
                                                  __builtin_bit_cast(bf16x8_hw, b), c, 0, 0, 0);
 }
+// ---- 16-bit storage types, generically (T = bf16_t or f16_t): two elements of a packed 32-bit word to float, two floats to
+// a packed word (round to nearest even), one MFMA step v_mfma_f32_16x16x32_{bf16,f16}.
+typedef _Float16 f16x8_hw __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x2_hw __attribute__((ext_vector_type(2)));
+template <typename T> struct Num16;
+template <> struct Num16<bf16_t> {
+  static __device__ __forceinline__ float lo(unsigned w) { return __uint_as_float(w << 16); }
+  static __device__ __forceinline__ float hi(unsigned w) { return __uint_as_float(w & 0xffff0000u); }
+  static __device__ __forceinline__ unsigned pack(float a, float b) { return pack_bf16x2(a, b); }
+  static __device__ __forceinline__ f32x4 mfma(s16x8 a, s16x8 b, f32x4 c) { return mfma_bf16_16x16x32(a, b, c); }
+};
+template <> struct Num16<f16_t> {
+  static __device__ __forceinline__ float lo(unsigned w) { return (float)__builtin_bit_cast(f16x2_hw, w)[0]; }
+  static __device__ __forceinline__ float hi(unsigned w) { return (float)__builtin_bit_cast(f16x2_hw, w)[1]; }
+  static __device__ __forceinline__ unsigned pack(float a, float b) {
+    const f16x2_hw v = {(_Float16)a, (_Float16)b};
+    return __builtin_bit_cast(unsigned, v);
+  }
+  static __device__ __forceinline__ f32x4 mfma(s16x8 a, s16x8 b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8_hw, a), __builtin_bit_cast(f16x8_hw, b), c, 0, 0, 0);
+  }
+};
+template <typename T> __device__ __forceinline__ unsigned pack2(float a, float b) { return Num16<T>::pack(a, b); }
+template <typename T> __device__ __forceinline__ float cvt_lo(unsigned w) { return Num16<T>::lo(w); }
+template <typename T> __device__ __forceinline__ float cvt_hi(unsigned w) { return Num16<T>::hi(w); }
+template <typename T> __device__ __forceinline__ f32x4 mfma16(s16x8 a, s16x8 b, f32x4 c) { return Num16<T>::mfma(a, b, c); }
+
 __device__ __forceinline__ f32x4 mfma_f32_16x16x4(float a, float b, f32x4 c) {
   return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
 }

@@ -50,7 +50,23 @@ __global__ __launch_bounds__(256) void bce_logits_bwd_kernel(const float* __rest
   }
 }
 
-template <typename T> struct LV;  // 16-byte unit loader
+template <typename T> struct LV {  // 16-byte unit loader; generic = the 16-bit storage types (bf16_t, f16_t)
+  static constexpr int N = 8;
+  static __device__ __forceinline__ void ld(const T* p, float (&v)[8]) {
+    const u32x4 t = *(const u32x4*)p;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      v[2 * i] = cvt_lo<T>(t[i]);
+      v[2 * i + 1] = cvt_hi<T>(t[i]);
+    }
+  }
+  static __device__ __forceinline__ void st(T* p, const float (&v)[8]) {
+    u32x4 t;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) t[i] = pack2<T>(v[2 * i], v[2 * i + 1]);
+    *(u32x4*)p = t;
+  }
+};
 template <> struct LV<float> {
   static constexpr int N = 4;
   static __device__ __forceinline__ void ld(const float* p, float (&v)[4]) {
@@ -59,24 +75,6 @@ template <> struct LV<float> {
   }
   static __device__ __forceinline__ void st(float* p, const float (&v)[4]) { *(f32x4*)p = (f32x4){v[0], v[1], v[2], v[3]}; }
 };
-template <> struct LV<bf16_t> {
-  static constexpr int N = 8;
-  static __device__ __forceinline__ void ld(const bf16_t* p, float (&v)[8]) {
-    const u32x4 t = *(const u32x4*)p;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      v[2 * i] = __uint_as_float(t[i] << 16);
-      v[2 * i + 1] = __uint_as_float(t[i] & 0xffff0000u);
-    }
-  }
-  static __device__ __forceinline__ void st(bf16_t* p, const float (&v)[8]) {
-    u32x4 t;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) t[i] = pack_bf16x2(v[2 * i], v[2 * i + 1]);
-    *(u32x4*)p = t;
-  }
-};
-
 template <typename T>
 __global__ __launch_bounds__(256) void smooth_l1_fwd_kernel(const T* __restrict__ a, const T* __restrict__ b,
                                                             float* __restrict__ loss, long long units) {
@@ -229,11 +227,14 @@ extern "C" int fsr_bce_logits_bwd(const float* x, const float* t, const float* g
 extern "C" int fsr_smooth_l1_fwd(int dtype, const void* a, const void* b, float* loss, void* scratch, long long count,
                                  fsr_stream_t stream_) {
   if (!a || !b || !loss || !scratch || count <= 0) return fsr_fail(-1, "fsr_smooth_l1_fwd: bad argument");
-  const int e = dtype == FSR_BF16 ? 8 : 4;
+  const int e = dtype != FSR_F32 ? 8 : 4;
   if (count % e) return fsr_fail(-2, "fsr_smooth_l1_fwd: count %lld is not a multiple of %d", count, e);
   const long long units = count / e;
   const int blocks = red_blocks(units * 4);
-  if (dtype == FSR_BF16)
+  if (dtype == FSR_F16)
+    hipLaunchKernelGGL(smooth_l1_fwd_kernel<f16_t>, dim3(blocks), dim3(256), 0, (hipStream_t)stream_,
+                       (const f16_t*)a, (const f16_t*)b, (float*)scratch, units);
+  else if (dtype == FSR_BF16)
     hipLaunchKernelGGL(smooth_l1_fwd_kernel<bf16_t>, dim3(blocks), dim3(256), 0, (hipStream_t)stream_,
                        (const bf16_t*)a, (const bf16_t*)b, (float*)scratch, units);
   else if (dtype == FSR_F32)
@@ -247,10 +248,13 @@ extern "C" int fsr_smooth_l1_fwd(int dtype, const void* a, const void* b, float*
 extern "C" int fsr_smooth_l1_bwd(int dtype, const void* a, const void* b, const float* gscale, void* da, long long count,
                                  fsr_stream_t stream_) {
   if (!a || !b || !gscale || !da || count <= 0) return fsr_fail(-1, "fsr_smooth_l1_bwd: bad argument");
-  const int e = dtype == FSR_BF16 ? 8 : 4;
+  const int e = dtype != FSR_F32 ? 8 : 4;
   if (count % e) return fsr_fail(-2, "fsr_smooth_l1_bwd: count %lld is not a multiple of %d", count, e);
   const long long units = count / e;
-  if (dtype == FSR_BF16)
+  if (dtype == FSR_F16)
+    hipLaunchKernelGGL(smooth_l1_bwd_kernel<f16_t>, dim3(red_blocks(units * 4)), dim3(256), 0, (hipStream_t)stream_,
+                       (const f16_t*)a, (const f16_t*)b, gscale, (f16_t*)da, units, 1.f / (float)count);
+  else if (dtype == FSR_BF16)
     hipLaunchKernelGGL(smooth_l1_bwd_kernel<bf16_t>, dim3(red_blocks(units * 4)), dim3(256), 0, (hipStream_t)stream_,
                        (const bf16_t*)a, (const bf16_t*)b, gscale, (bf16_t*)da, units, 1.f / (float)count);
   else if (dtype == FSR_F32)
@@ -262,8 +266,8 @@ extern "C" int fsr_smooth_l1_bwd(int dtype, const void* a, const void* b, const 
 }
 
 static int c1_check(const char* what, int dtype, int c) {
-  if (dtype != FSR_F32 && dtype != FSR_BF16) return fsr_fail(-2, "%s: unknown dtype %d", what, dtype);
-  const int e = dtype == FSR_BF16 ? 8 : 4;
+  if (dtype != FSR_F32 && dtype != FSR_BF16 && dtype != FSR_F16) return fsr_fail(-2, "%s: unknown dtype %d", what, dtype);
+  const int e = dtype != FSR_F32 ? 8 : 4;
   if (c <= 0 || c % e) return fsr_fail(-2, "%s: %d channels is not a multiple of %d", what, c, e);
   return 0;
 }
@@ -274,7 +278,10 @@ extern "C" int fsr_conv1x1_c1_fwd(int dtype, const void* x, const float* w, cons
   if (int rc = c1_check("fsr_conv1x1_c1_fwd", dtype, c)) return rc;
   int blocks = (npix + 3) / 4;
   if (blocks > 2048) blocks = 2048;
-  if (dtype == FSR_BF16)
+  if (dtype == FSR_F16)
+    hipLaunchKernelGGL(conv1x1_c1_fwd_kernel<f16_t>, dim3(blocks), dim3(256), 0, (hipStream_t)stream_, (const f16_t*)x, w,
+                       b, logits, npix, c);
+  else if (dtype == FSR_BF16)
     hipLaunchKernelGGL(conv1x1_c1_fwd_kernel<bf16_t>, dim3(blocks), dim3(256), 0, (hipStream_t)stream_, (const bf16_t*)x, w,
                        b, logits, npix, c);
   else
@@ -289,14 +296,17 @@ extern "C" int fsr_conv1x1_c1_bwd(int dtype, const float* g, const void* x, cons
                                   void* scratch, int npix, int c, fsr_stream_t stream_) {
   if (!g || !x || !w || !dw || !db || !scratch || npix <= 0) return fsr_fail(-1, "fsr_conv1x1_c1_bwd: bad argument");
   if (int rc = c1_check("fsr_conv1x1_c1_bwd", dtype, c)) return rc;
-  const int cu = c / (dtype == FSR_BF16 ? 8 : 4);
+  const int cu = c / (dtype != FSR_F32 ? 8 : 4);
   if (cu > 256 || 256 % cu) return fsr_fail(-2, "fsr_conv1x1_c1_bwd: %d channels do not tile a 256-thread workgroup", c);
   const int rows = 256 / cu;
   int blocks = (npix + rows * 8 - 1) / (rows * 8);
   if (blocks > 512) blocks = 512;
   if (blocks < 1) blocks = 1;
   float* part = (float*)scratch;   // [blocks][c + 1]: weight-gradient partials, then the bias-gradient partial
-  if (dtype == FSR_BF16)
+  if (dtype == FSR_F16)
+    hipLaunchKernelGGL(conv1x1_c1_bwd_kernel<f16_t>, dim3(blocks), dim3(256), 0, (hipStream_t)stream_, g, (const f16_t*)x,
+                       w, (f16_t*)dx, part, npix, c);
+  else if (dtype == FSR_BF16)
     hipLaunchKernelGGL(conv1x1_c1_bwd_kernel<bf16_t>, dim3(blocks), dim3(256), 0, (hipStream_t)stream_, g, (const bf16_t*)x,
                        w, (bf16_t*)dx, part, npix, c);
   else

@@ -51,7 +51,10 @@ extern "C" int fsr_pack_conv3x3(int dtype, int mode, const float* w_oihw, int co
   const long long total = 9LL * rows_pad * K;
   int blocks = (int)((total + 255) / 256);
   if (blocks > 4096) blocks = 4096;
-  if (dtype == FSR_BF16)
+  if (dtype == FSR_F16)
+    hipLaunchKernelGGL(pack_conv3x3_kernel<f16_t>, dim3(blocks), dim3(256), 0, stream, w_oihw, (f16_t*)packed, cout,
+                       cin, mode, rows, rows_pad, K, Kreal);
+  else if (dtype == FSR_BF16)
     hipLaunchKernelGGL(pack_conv3x3_kernel<bf16_t>, dim3(blocks), dim3(256), 0, stream, w_oihw, (bf16_t*)packed, cout,
                        cin, mode, rows, rows_pad, K, Kreal);
   else if (dtype == FSR_F32)

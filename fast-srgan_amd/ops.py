@@ -14,15 +14,16 @@ import torch
 
 from . import _lib as L
 
-_DT = {"f32": (L.FSR_F32, torch.float32, 16), "bf16": (L.FSR_BF16, torch.bfloat16, 32)}
+_DT = {"f32": (L.FSR_F32, torch.float32, 16), "bf16": (L.FSR_BF16, torch.bfloat16, 32), "f16": (L.FSR_F16, torch.float16, 32)}
 
 
 class Compute:
-    """Compute mode of a module: 'bf16' (bf16 MFMA, f32 accumulate) or 'f32' (exact-f32 MFMA)."""
+    """Compute mode of a module: 'bf16' / 'f16' (16-bit MFMA, f32 accumulate; f16 = BASELINE configs[4]) or 'f32' (exact-f32
+    MFMA, the parity mode)."""
 
     def __init__(self, name="bf16"):
         if name not in _DT:
-            raise ValueError("compute dtype must be 'bf16' or 'f32', got %r" % (name,))
+            raise ValueError("compute dtype must be 'bf16', 'f16' or 'f32', got %r" % (name,))
         self.name = name
         self.code, self.torch_dtype, self.cpad = _DT[name]
 
@@ -682,8 +683,8 @@ class SmoothL1Fn(torch.autograd.Function):
             raise L.FsrError("SmoothL1: operands must share dtype and shape")
         if not (a.stride() == b.stride() and _is_dense(a)):  # elementwise: any shared dense layout will do
             a, b = a.contiguous(), b.contiguous()
-        code = L.FSR_BF16 if a.dtype == torch.bfloat16 else L.FSR_F32
-        if code == L.FSR_F32 and a.dtype != torch.float32:
+        code = {torch.bfloat16: L.FSR_BF16, torch.float16: L.FSR_F16, torch.float32: L.FSR_F32}.get(a.dtype)
+        if code is None:
             raise L.FsrError("SmoothL1: unsupported dtype %s" % a.dtype)
         loss = _zeros((1,), a.device).view(())
         scr = _workspace(L.lib().fsr_loss_scratch(), a.device)

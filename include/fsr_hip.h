@@ -12,9 +12,10 @@
  *     the library never allocates, frees or synchronises; calls only enqueue work on `stream`
  *     (a hipStream_t passed as void*), so they are legal inside hipGraph stream capture;
  *   - activations are NHWC; `dtype` is the storage type of activations, activation gradients and
- *     packed filters: FSR_F32 (exact-f32 MFMA, parity mode) or FSR_BF16 (bf16 MFMA, f32
- *     accumulate); parameters, biases, statistics, parameter gradients and losses are float;
- *   - channel counts of NHWC activations are multiples of FSR_CPAD(dtype) = 16 (f32) / 32 (bf16);
+ *     packed filters: FSR_F32 (exact-f32 MFMA, parity mode), FSR_BF16 (bf16 MFMA, f32 accumulate) or
+ *     FSR_F16 (fp16 MFMA, f32 accumulate: BASELINE configs[4]); parameters, biases, statistics,
+ *     parameter gradients and losses are float;
+ *   - channel counts of NHWC activations are multiples of FSR_CPAD(dtype) = 16 (f32) / 32 (bf16, f16);
  *     3-channel images are stored zero-padded to that width;
  *   - reductions over pixels (InstanceNorm statistics, backward sums, bias / PReLU-slope gradients, loss
  *     means) are two-level and ORDER-FIXED: the producing kernel stores one partial vector per workgroup into
@@ -39,7 +40,7 @@ extern "C" {
 
 #define FSR_ABI_VERSION 6
 
-enum { FSR_F32 = 0, FSR_BF16 = 1 };
+enum { FSR_F32 = 0, FSR_BF16 = 1, FSR_F16 = 2 };
 enum { FSR_ACT_NONE = 0, FSR_ACT_RELU = 1, FSR_ACT_LEAKY = 2, FSR_ACT_PRELU = 3, FSR_ACT_TANH = 4 };
 enum { FSR_CONV_FWD = 0, FSR_CONV_DGRAD = 1 };
 enum { FSR_PACK_FWD = 0, FSR_PACK_FWD_PS = 1, FSR_PACK_DGRAD = 2, FSR_PACK_DGRAD_PS = 3 };

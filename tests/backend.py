@@ -40,7 +40,8 @@ BACKENDS = ["emu", pytest.param("hip", marks=pytest.mark.gpu)]
 
 
 def tol(cd_name, f32=2e-4, bf16=3e-2):
-    return f32 if cd_name == "f32" else bf16
+    """f16 has 3 more mantissa bits than bf16: it passes the bf16 bounds with room to spare (an eighth is asserted)."""
+    return f32 if cd_name == "f32" else (bf16 if cd_name == "bf16" else max(bf16 / 8, 2 * f32))
 
 
 def relerr(a, b):

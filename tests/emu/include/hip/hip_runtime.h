@@ -198,6 +198,29 @@ inline f32x4_e mfma_bf16_16x16x32(VA a, VB b, f32x4_e c) {
   wave_sync();
   return c;
 }
+// v_mfma_f32_16x16x32_f16: the same lane layout with IEEE half operands
+template <class VA, class VB>
+inline f32x4_e mfma_f16_16x16x32(VA a, VB b, f32x4_e c) {
+  _Float16 ha[8], hb[8];
+  memcpy(ha, &a, 16);
+  memcpy(hb, &b, 16);
+  WaveState* w = ctx.w;
+  for (int e = 0; e < 8; ++e) {
+    w->fa[ctx.lane][e] = (float)ha[e];
+    w->fb[ctx.lane][e] = (float)hb[e];
+  }
+  wave_sync();
+  const int j = ctx.lane & 15;
+  for (int r = 0; r < 4; ++r) {
+    const int i = (ctx.lane >> 4) * 4 + r;
+    float acc = c[r];
+    for (int k = 0; k < 32; ++k)
+      acc = fmaf(w->fa[i + 16 * (k >> 3)][k & 7], w->fb[j + 16 * (k >> 3)][k & 7], acc);
+    c[r] = acc;
+  }
+  wave_sync();
+  return c;
+}
 // v_mfma_f32_16x16x4_f32: A[i][k] lane i+16k ; B[k][j] lane j+16k
 inline f32x4_e mfma_f32_16x16x4(float a, float b, f32x4_e c) {
   WaveState* w = ctx.w;
@@ -286,6 +309,7 @@ inline float __expf(float x) { return expf(x); }
 inline float __logf(float x) { return logf(x); }
 
 #define __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, x, y, z) emu::mfma_bf16_16x16x32((a), (b), (c))
+#define __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, x, y, z) emu::mfma_f16_16x16x32((a), (b), (c))
 #define __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, x, y, z) emu::mfma_f32_16x16x4((a), (b), (c))
 #define __builtin_amdgcn_ds_read_tr16_b64_v4i16(p) emu::ds_read_tr16((const void*)(p))
 #define __builtin_amdgcn_readfirstlane(x) (x)

@@ -212,3 +212,32 @@ def test_generator_uint8_frames_in_and_out(dev, pkg):
         with torch.no_grad():
             yf = G(x.to(dev)).cpu()
         assert torch.equal(got, torch.from_numpy(O.postprocess_u8(yf)))
+
+
+def test_generator_and_discriminator_fp16_mode(dev, pkg):
+    """compute_dtype="f16" (fp16 MFMA, BASELINE configs[4]): the same kernels instantiated for IEEE half -- forward and
+    gradients against the fp32 oracle (3 more mantissa bits than bf16: an order of magnitude closer)."""
+    torch.manual_seed(5)
+    nf = 32
+    G = pkg.Generator(ns(n_filters=nf, n_layers=1), compute_dtype="f16")
+    D = pkg.Discriminator(ns(n_filters=nf, n_layers=7), compute_dtype="f16")
+    gsd = {k: v.clone() for k, v in G.state_dict().items()}
+    dsd = {k: v.clone() for k, v in D.state_dict().items()}
+    G.to(dev), D.to(dev)
+    x = torch.rand(1, 3, 16, 20) * 2 - 1 if dev.type == "cuda" else torch.rand(1, 3, 8, 12) * 2 - 1
+    sr = G(x.to(dev))
+    assert sr.dtype == torch.float32
+    logits = D(sr)
+    r = torch.randn(logits.shape)
+    (logits * r.to(dev)).sum().backward()
+    gp = {k: v.clone().requires_grad_(True) for k, v in gsd.items()}
+    dp = {k: v.clone().requires_grad_(True) for k, v in dsd.items()}
+    sr_ref = O.generator_forward(gp, x)
+    lg_ref = O.discriminator_forward(dp, sr_ref)
+    grads = torch.autograd.grad((lg_ref * r).sum(), list(gp.values()) + list(dp.values()))
+    ref = dict(zip(["g." + k for k in gp] + ["d." + k for k in dp], grads))
+    assert report("modules.f16.sr.%s" % dev.type, relerr(sr, sr_ref)) < 3e-3
+    assert report("modules.f16.logits.%s" % dev.type, relerr(logits, lg_ref)) < 2e-2
+    named = [("g." + k, p.grad) for k, p in G.named_parameters()] + [("d." + k, p.grad) for k, p in D.named_parameters()]
+    bad = check_grads("modules.f16.grad.%s" % dev.type, named, ref, t_tensor=0.35, t_slope=0.5, t_cos=0.95)
+    assert not bad, bad

@@ -34,7 +34,7 @@ def _big(dev):
     return dev.type == "cuda"
 
 
-@pytest.mark.parametrize("cdn", ["f32", "bf16"])
+@pytest.mark.parametrize("cdn", ["f32", "bf16", "f16"])
 @pytest.mark.parametrize("stride,cin,cout,ps", [(1, 32, 64, False), (1, 64, 64, False), (2, 64, 64, False), (1, 32, 128, True), (1, 64, 3, False),
                                                 (1, 64, 128, False), (1, 64, 256, True)])
 def test_conv_fwd_dgrad_wgrad(dev, cdn, stride, cin, cout, ps):
@@ -100,7 +100,7 @@ def test_conv_stage_modes(dev, cdn, stride, cin, cout, mode, monkeypatch):
     assert relerr(_nchw(dx), xr.grad) < tol(cdn, 1e-5, 1e-2)
 
 
-@pytest.mark.parametrize("cdn", ["f32", "bf16"])
+@pytest.mark.parametrize("cdn", ["f32", "bf16", "f16"])
 def test_conv_image_in_and_tanh_head_autograd(dev, cdn):
     """First-layer conv on a strided NCHW image (with the VGG normalisation fused) and the tanh head."""
     cd = ops.Compute(cdn)
@@ -287,7 +287,7 @@ def test_first_layer_kernels_reject_bad_arguments(dev):
     assert lib.fsr_conv3x3_c3_wgrad_workspace(0, 8, 8, 16) == 0
 
 
-@pytest.mark.parametrize("cdn", ["f32", "bf16"])
+@pytest.mark.parametrize("cdn", ["f32", "bf16", "f16"])
 @pytest.mark.parametrize("act,slope", [(L.ACT_PRELU, -0.28), (L.ACT_LEAKY, 0.01), (L.ACT_NONE, 0.0)])
 def test_instnorm_act_residual_fwd_bwd(dev, cdn, act, slope):
     cd = ops.Compute(cdn)
@@ -316,7 +316,7 @@ def test_instnorm_act_residual_fwd_bwd(dev, cdn, act, slope):
         assert abs(float(ad.grad) - float(ar.grad)) < tol(cdn, 1e-5, 2e-3) * scale
 
 
-@pytest.mark.parametrize("cdn", ["f32", "bf16"])
+@pytest.mark.parametrize("cdn", ["f32", "bf16", "f16"])
 def test_conv_fused_prelu_pixelshuffle_autograd(dev, cdn):
     """UpSamplingBlock (model.py:26-40) as one fused op, including a NEGATIVE PReLU slope."""
     cd = ops.Compute(cdn)
@@ -342,7 +342,7 @@ def test_conv_fused_prelu_pixelshuffle_autograd(dev, cdn):
     assert abs(float(ad.grad) - float(ar.grad)) < tol(cdn, 1e-5, 2e-3) * scale
 
 
-@pytest.mark.parametrize("cdn", ["f32", "bf16"])
+@pytest.mark.parametrize("cdn", ["f32", "bf16", "f16"])
 def test_maxpool_relu_conv1x1(dev, cdn):
     cd = ops.Compute(cdn)
     torch.manual_seed(5)
@@ -386,7 +386,7 @@ def test_losses_and_adamw(dev):
     (0.05 * loss).backward()
     (0.05 * lr).backward()
     assert relerr(xd.grad, xr.grad) < 1e-5
-    for dt, tl in ((torch.float32, 1e-5), (torch.bfloat16, 1e-2)):
+    for dt, tl in ((torch.float32, 1e-5), (torch.bfloat16, 1e-2), (torch.float16, 2e-3)):
         a, b = (torch.randn(n) * 1.5).to(dt), torch.randn(n).to(dt)
         ad = leaf(a, dev)
         l2 = ops.smooth_l1(ad, b.to(dev))
@@ -411,7 +411,7 @@ def test_losses_and_adamw(dev):
     assert (pd.cpu() - ref.detach()).abs().max() < 1e-6
 
 
-@pytest.mark.parametrize("cdn", ["f32", "bf16"])
+@pytest.mark.parametrize("cdn", ["f32", "bf16", "f16"])
 @pytest.mark.parametrize("cin,cout,stride", [(64, 64, 1), (64, 128, 1), (64, 64, 2), (128, 64, 2)])
 def test_dgrad_with_fused_activation_mask(dev, cdn, cin, cout, stride):
     """Data gradient fused with the producer's ReLU / LeakyReLU backward (mask = saved forward input); stride 2 with

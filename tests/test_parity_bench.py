@@ -163,9 +163,10 @@ def test_generator_cfg5_full_size_vs_oracle(pkg):
     with torch.no_grad():
         y32 = G32.to(dev).eval()(x.to(dev)).cpu()
     assert report("cfg5.f32.sr", relerr(y32, want)) < 1e-3
-    G16 = pkg.Generator(ns(n_filters=64, n_layers=12, n_upsample=3), compute_dtype="bf16")
-    G16.load_state_dict(sd)
-    with torch.no_grad():
-        y16 = G16.to(dev).eval()(x.to(dev)).cpu()
-    assert report("cfg5.bf16.mean_abs", float((y16 - want).abs().mean())) < 2e-2
-    assert report("cfg5.bf16.max_abs", float((y16 - want).abs().max())) < 0.3
+    for cdn, t_mean, t_max in (("bf16", 1e-3, 6e-3), ("f16", 2e-4, 1.5e-3)):      # ~2x measured (fp16: the dtype configs[4] names)
+        G16 = pkg.Generator(ns(n_filters=64, n_layers=12, n_upsample=3), compute_dtype=cdn)
+        G16.load_state_dict(sd)
+        with torch.no_grad():
+            y16 = G16.to(dev).eval()(x.to(dev)).cpu()
+        assert report("cfg5.%s.mean_abs" % cdn, float((y16 - want).abs().mean())) < t_mean
+        assert report("cfg5.%s.max_abs" % cdn, float((y16 - want).abs().max())) < t_max
