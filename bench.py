@@ -39,7 +39,7 @@ import torch
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-MFMA_PEAK_TFLOPS = {"bf16": 2500.0, "f32": 157.3}   # /opt/skills/guides/MI355X_MICROARCH.md, dense
+MFMA_PEAK_TFLOPS = {"bf16": 2500.0, "f16": 2500.0, "f32": 157.3}   # /opt/skills/guides/MI355X_MICROARCH.md, dense
 STEP_GFLOP_PER_IMAGE = 686.71                         # BASELINE.md section 2, as the REFERENCE graph executes it
 TRAFFIC_FILE = os.path.join(ROOT, "profiles", "conv_traffic.json")
 

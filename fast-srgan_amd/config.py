@@ -2,7 +2,7 @@
 
 hydra / omegaconf are not dependencies; PyYAML reads the same file and the result is an attribute tree with
 the reference's 20 keys (configs/config.yaml:1-25) plus `generator.n_upsample` (default 2),
-`training.compute_dtype` (default bf16), `training.vgg19_weights` (path of torchvision's vgg19 checkpoint) and
+`training.compute_dtype` (bf16 | f16 | f32, default bf16), `training.loss_scale` (static, default 16384 for f16 else 1), `training.vgg19_weights` (path of torchvision's vgg19 checkpoint) and
 `training.allow_random_vgg` (tests / benchmarks only).
 """
 import os

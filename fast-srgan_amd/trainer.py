@@ -74,6 +74,14 @@ class Trainer:
         D.broadcast_parameters(self.optim_discriminator)
         self._sync_g = D.GradSync(self.optim_generator)
         self._sync_d = D.GradSync(self.optim_discriminator)
+        # Static loss scaling (extension key training.loss_scale; default 1, 16384 in the fp16 mode): both backward passes are
+        # seeded with S and AdamW divides the gradients by S again.  fp16 activation gradients need it: the content loss is a
+        # mean over N x 512 x 24 x 24 values, its per-element gradient (~4e-8) lies below the smallest fp16 subnormal.  bf16 and
+        # f32 share float32's exponent range and run unscaled.
+        self.loss_scale = float(getattr(config.training, "loss_scale", 16384.0 if cdt == "f16" else 1.0))
+        self._seed = torch.tensor(self.loss_scale, dtype=torch.float32, device=dev) if self.loss_scale != 1.0 else None
+        for opt in (self.optim_generator, self.optim_discriminator):
+            opt.grad_scale = opt.grad_scale / self.loss_scale
         self._streams = {}
         self.use_side_stream = os.environ.get("FSR_SIDE_STREAM", "1") != "0"
         self.loss_fn = ops.bce_with_logits      # torch.nn.BCEWithLogitsLoss(), trainer.py:41
@@ -152,7 +160,7 @@ class Trainer:
         loss_real = self.loss_fn(y_real, real_labels)                           # :177
         loss_fake = self.loss_fn(y_fake, fake_labels)                           # :178
         discriminator_loss = 0.5 * loss_real + 0.5 * loss_fake                  # :179
-        discriminator_loss.backward()                                           # :180
+        discriminator_loss.backward(self._seed)                                 # :180 (seed = the loss scale, if any)
         ops.wgrad_stream_join()
         joined = False
         if join_side and side is not None:      # a captured phase must end with every forked stream joined
@@ -175,7 +183,7 @@ class Trainer:
             if st["side"] is not None and not st["joined"]:
                 st["main"].wait_stream(st["side"])
             generator_loss = 0.5 * adv_loss + 0.5 * st["content"]               # :194
-            generator_loss.backward()                                           # :195
+            generator_loss.backward(self._seed)                                 # :195
         finally:
             for p in Dm.parameters():
                 p.requires_grad_(True)
@@ -264,7 +272,7 @@ class Trainer:
             self.optim_generator.zero_grad()
             fake_hr_images = self.generator(lr_images)
             gen_loss = self.l1_loss(fake_hr_images, hr_images)
-            gen_loss.backward()
+            gen_loss.backward(self._seed)
             self._sync_g.run()
             self.optim_generator.step()
             return gen_loss.detach().clone()
