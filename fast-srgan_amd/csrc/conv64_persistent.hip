@@ -13,6 +13,10 @@
 //           wave with NO barrier inside (nothing is restaged during a tile);
 //   tiles : the halo of the next tile is loaded into registers before the MFMAs of the current one and committed
 //           to LDS after its epilogue -- two barriers per tile instead of ten.
+// (Measured and rejected in round 2: software-pipelining the 18 (tap, half) steps -- the reads of step i + 1 before the MFMAs
+// of step i, double fragment set, 236 instead of 120 VGPRs: +-1 % on every 64-channel layer.  With two waves per SIMD the
+// partner wave already covers the LDS round trips; what bounds this kernel is the per-tile prologue / epilogue and, at
+// 384^2, HBM.)
 // Same operand mapping, tap table, epilogue semantics (bias, ReLU/LeakyReLU/identity, InstanceNorm statistics,
 // fused activation-backward mask) and therefore the same results as conv_igemm_kernel.  bf16 only: the f32
 // filter (144 KB + pads) does not fit next to a halo, the parity mode stays on the generic kernel.
