@@ -709,7 +709,9 @@ static int dispatch_T(ConvKArgs& a, int S, hipStream_t stream, ConvKArgs* more =
     // half the workgroups; measured +2..7 % on the 128/256-channel layers.  Narrow chunks keep two workgroups per CU.
     if (!th8 && a.Cin >= 128) {
       // (32-row tiles with 8 waves -- half the filter traffic per FLOP, one workgroup per CU -- measured again with the
-      // pipelined stage: 128-channel layers +-0, 256-channel layers -5 %: not dispatched)
+      // pipelined stage: 128-channel layers +-0, 256-channel layers -5 %: not dispatched.  12-row tiles, which turn the 2.25 /
+      // 4.5 workgroup rounds of the 48^2 / 96^2 layers into whole rounds: +-1 % at 48^2, -4 % at 96^2 -- the workgroups of a
+      // partial last round run alone on their CUs and finish early, the rounds are not the quantum the arithmetic suggests)
       if (t9 && (sm & 64)) FSR_GO(16, 128, 4, 1, KCN, 1, 3, 1);
       if (t2 && (sm & 64)) FSR_GO(16, 128, 4, 1, KCN, 1, 2, 1);
       FSR_GO(16, 128, 4, 1, KCN, 1);
