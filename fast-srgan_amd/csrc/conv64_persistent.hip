@@ -213,6 +213,31 @@ __global__ __launch_bounds__(NTHR64, 2) void conv64_persistent_kernel(const Conv
       __syncthreads();
       continue;
     }
+    if (a.pool2) {
+      // MaxPool2d(2,2) fused (no-grad vgg19 passes): the wave's two rows and the columns (l15, l15 ^ 1) of neighbouring
+      // lanes; even lanes store pixel (gy / 2, gx / 2) of the [N][FOH/2][FOW/2][Cout] tensor
+      static_for<0, NT>([&](auto nc) {
+        constexpr int n = decltype(nc)::value;
+        f32x4 v = acc[0][n] + bias[n], w = acc[1][n] + bias[n];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          float x = fmaxf(v[r], w[r]);
+          x = fmaxf(x, __shfl_xor(x, 1, 64));
+          v[r] = fmaxf(x, 0.f) + slope * fminf(x, 0.f);
+        }
+        if (col_ok && gyb < a.GH && !(l15 & 1)) {
+          const unsigned off = (unsigned)((img * (a.FOH >> 1) + (gyb >> 1)) * (a.FOW >> 1) + (gx >> 1)) * (unsigned)a.Cout + (unsigned)(nb * 64 + n * 16 + lg * 4);
+          u32x2 pk;
+          pk.x = pack2<T>(v[0], v[1]);
+          pk.y = pack2<T>(v[2], v[3]);
+          *(u32x2*)(outp + off) = pk;
+        }
+      });
+      __syncthreads();
+      if (next < tile_end) halo_commit();
+      __syncthreads();
+      continue;
+    }
     // plain: pixel (gy, gx), channels nb*64 + ...; PixelShuffle(2): pixel (2 gy + (nb >> 1), 2 gx + (nb & 1)) of the
     // [2 FOH, 2 FOW, 64] tensor, channels 0..63
     const unsigned rstride = a.ps ? (unsigned)(4 * a.FOW * 64) : (unsigned)(a.FOW * a.Cout);
@@ -499,12 +524,13 @@ int fsr_conv64_s2dgrad_try(int dtype, ConvKArgs& a, hipStream_t stream) {
 int fsr_conv64_persistent_try(int dtype, ConvKArgs& a, int S, hipStream_t stream) {
   if ((dtype != FSR_BF16 && dtype != FSR_F16) || S != 1 || a.Cin != 64 || a.ntaps != 9) return 0;
   // thin: float output of at most 16 channels (head conv, image gradients); otherwise 64-channel blocks
-  const bool thin = a.CoutPad == 16 && a.out_f32 && !a.ps && !a.in_ps && !a.stats && !a.preact && !a.dmask;
+  const bool thin = a.CoutPad == 16 && a.out_f32 && !a.ps && !a.in_ps && !a.stats && !a.preact && !a.dmask && !a.pool2;
   if (!thin) {
     if (a.Cout % 64 != 0 || a.CoutPad != a.Cout || a.Cout > 256) return 0;
     if (a.in_ps || a.out_f32 || a.oscale) return 0;
     if (a.ps && (a.Cout != 256 || a.stats || a.dmask)) return 0;   // PixelShuffle(2): one quadrant = one 64-row block
     if (a.preact && a.dmask) return 0;
+    if (a.pool2 && (a.ps || a.stats || a.dmask || a.preact)) return 0;
     if (a.stats && a.dmask) return 0;   // InstanceNorm backward sums: generic kernel
   }
   if (a.osy != 1 || a.osx != 1 || a.ooy != 0 || a.oox != 0) return 0;

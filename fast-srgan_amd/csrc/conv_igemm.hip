@@ -541,6 +541,28 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv_igemm_kernel(const ConvK
       rstride = (unsigned)(4 * a.FOW * cps);
     }
     f32x4 s1 = (f32x4){0.f, 0.f, 0.f, 0.f}, s2 = (f32x4){0.f, 0.f, 0.f, 0.f};
+    if constexpr (sizeof(T) == 2 && MT % 2 == 0) {
+      if (a.pool2) {
+        // MaxPool2d(2,2) fused: rows (m, m+1) of this wave (gyb is even) and columns (l15, l15 ^ 1) of neighbouring lanes;
+        // even lanes store pixel (gy / 2, gx / 2) of the [N][FOH/2][FOW/2][Cout] tensor.  The activation is monotonic, so
+        // it commutes with the maximum.
+        static_for<0, MT / 2>([&](auto mc) {
+          constexpr int m = 2 * decltype(mc)::value;
+          f32x4 v = acc[m][n] + bv, w = acc[m + 1][n] + bv;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            float x = fmaxf(v[r], w[r]);
+            x = fmaxf(x, __shfl_xor(x, 1, 64));
+            v[r] = fmaxf(x, 0.f) + slope * fminf(x, 0.f);
+          }
+          if (col_ok && gyb + m < a.GH && !(l15 & 1)) {
+            const unsigned off = (unsigned)((img * (a.FOH >> 1) + ((gyb + m) >> 1)) * (a.FOW >> 1) + (gx >> 1)) * (unsigned)a.Cout + (unsigned)co;
+            store_vec4<T>(outp + off, v);
+          }
+        });
+        return;
+      }
+    }
     static_for<0, MT>([&](auto mc) {
       constexpr int m = decltype(mc)::value;
       if (col_ok && gyb + m < a.GH) {

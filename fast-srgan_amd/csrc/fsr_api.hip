@@ -95,6 +95,11 @@ extern "C" int fsr_conv3x3(const fsr_conv_desc* d, const void* in, const void* p
   a.ps = d->pixel_shuffle;
   a.in_ps = d->in_pixel_shuffled;
   a.out_f32 = d->out_f32;
+  a.pool2 = d->pool2;
+  if (d->pool2 && (d->mode != FSR_CONV_FWD || d->dtype == FSR_F32 || d->stride != 1 || d->pixel_shuffle || d->out_f32 || stats || preact ||
+                   dact_mask || oscale || (d->oh & 1) || (d->ow & 1) || d->cout % 16 != 0 || d->act == FSR_ACT_TANH))
+    return fsr_fail(-2, "fsr_conv3x3: pool2 is for stride-1 forward launches of the 16-bit modes with even output extents "
+                        "(no statistics / pre-activation / mask / scale tensors, no pixel shuffle)");
   if (d->out_f32 < 0 || d->out_f32 > FSR_OUT_U8) return fsr_fail(-2, "fsr_conv3x3: unknown output kind %d", d->out_f32);
   if (d->out_f32 == FSR_OUT_U8 && (d->act != FSR_ACT_TANH || d->cout > 16 || d->pixel_shuffle || d->mode != FSR_CONV_FWD))
     return fsr_fail(-2, "fsr_conv3x3: uint8 image output is for tanh heads (forward, cout <= 16)");

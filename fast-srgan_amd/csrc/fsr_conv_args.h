@@ -38,6 +38,7 @@ struct ConvKArgs {
   int ps;               // epilogue stores depth-to-space(2); weight rows packed [q][c]
   int in_ps;            // `in` is stored depth-to-space(2) (gradient of a pixel-shuffle conv)
   int out_f32;          // 1: store float regardless of T;  2 (FSR_OUT_U8): store the uint8 image of a tanh head
+  int pool2;            // epilogue stores MaxPool2d(2,2) of the activated result ([N][FOH/2][FOW/2][Cout]) instead of the result
   int tiles_x, tiles_y, nblk_n;
   int premask;          // epilogue loads every mask value before its first store
 };

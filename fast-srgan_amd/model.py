@@ -239,10 +239,24 @@ class VGG19(torch.nn.Module):
                                               act_bwd_by_consumer=nxt is not None),
                                isinstance(nxt, torch.nn.MaxPool2d)))
 
+    @property
+    def _plan_pooled(self):
+        plan = getattr(self, "_plan_pooled_cache", None)
+        if plan is None:
+            plan = {k: ops.ConvCfg(self.compute, act=L.ACT_RELU, pool_after=True) for k, (_, _, pool) in enumerate(self._plan) if pool}
+            self._plan_pooled_cache = plan
+        return plan
+
     def features_nhwc(self, x):
         y = x
-        for i, cfg, pool_after in self._plan:
+        # no gradient wanted (the target features of trainer.py:191, inference): conv + ReLU + MaxPool2d as ONE kernel in the
+        # 16-bit modes -- the full-resolution tensor, which only the pool's backward would read, is never written
+        fuse_pool = (not torch.is_grad_enabled()) and self.compute.name != "f32"
+        for k, (i, cfg, pool_after) in enumerate(self._plan):
             m = self.vgg[i]
+            if pool_after and fuse_pool and not cfg.image_in and y.shape[1] % 2 == 0 and y.shape[2] % 2 == 0:
+                y, _ = ops.conv3x3(y, m.weight, m.bias, None, self._plan_pooled[k])
+                continue
             y, _ = ops.conv3x3(y, m.weight, m.bias, None, cfg)
             if pool_after:
                 y = ops.maxpool2(y, self.compute, relu_mask=True)

@@ -248,9 +248,10 @@ class _on_wgrad_stream:
 # ---------------------------------------------------------------------------------- raw launches
 def conv3x3_raw(cd, x, wpk, cout, *, mode=L.CONV_FWD, out_hw=None, stride=1, bias=None, act=L.ACT_NONE, slope=0.0,
                 prelu=None, oscale=None, pixel_shuffle=False, in_pixel_shuffled=False, out_f32=False, want_stats=False,
-                want_preact=False, alg_k=None, dact_mask=None, dact_slope=0.0, out_u8=False):
+                want_preact=False, alg_k=None, dact_mask=None, dact_slope=0.0, out_u8=False, pool2=False):
     """One fsr_conv3x3 launch.  x: (N,IH,IW,Cin) [or its depth-to-space form when in_pixel_shuffled].
-    out_u8 (tanh heads): the output is the finished uint8 HWC image of inference.py:53-56."""
+    out_u8 (tanh heads): the output is the finished uint8 HWC image of inference.py:53-56.
+    pool2 (no-grad passes): the output is MaxPool2d(2,2) of the activated result; the full-resolution tensor is never written."""
     _check_dev(x)
     n = x.shape[0]
     if in_pixel_shuffled:
@@ -262,12 +263,12 @@ def conv3x3_raw(cd, x, wpk, cout, *, mode=L.CONV_FWD, out_hw=None, stride=1, bia
     else:
         oh, ow = out_hw
     odt = torch.uint8 if out_u8 else (torch.float32 if out_f32 else cd.torch_dtype)
-    oshape = (n, 2 * oh, 2 * ow, cout // 4) if pixel_shuffle else (n, oh, ow, cout)
+    oshape = (n, 2 * oh, 2 * ow, cout // 4) if pixel_shuffle else ((n, oh // 2, ow // 2, cout) if pool2 else (n, oh, ow, cout))
     out = torch.empty(oshape, dtype=odt, device=x.device)
     pre = torch.empty(oshape, dtype=odt, device=x.device) if want_preact else None
     stats = _zeros((n, cout, 2), x.device) if want_stats else None
     d = L.ConvDesc(cd.code, mode, n, ih, iw, cin, oh, ow, cout, stride, act, float(slope), int(pixel_shuffle),
-                   int(in_pixel_shuffled), L.OUT_U8 if out_u8 else int(out_f32))
+                   int(in_pixel_shuffled), L.OUT_U8 if out_u8 else int(out_f32), int(pool2))
     scratch = _workspace(L.lib().fsr_conv3x3_scratch(ctypes.byref(d)), x.device) if want_stats else None
     prof = PROFILE_CONV
     if prof is not None:
@@ -330,7 +331,7 @@ class ConvCfg:
 
     def __init__(self, cd, *, stride=1, act=L.ACT_NONE, slope=0.0, pixel_shuffle=False, stats=False, image_in=False,
                  in_scale=(1.0, 1.0, 1.0), in_shift=(0.0, 0.0, 0.0), tanh_head=False, input_act_bwd=None,
-                 act_bwd_by_consumer=False, u8_head=False):
+                 act_bwd_by_consumer=False, u8_head=False, pool_after=False):
         # u8_head (inference only, with tanh_head): the head stores the finished uint8 HWC frame instead of float
         # input_act_bwd = slope: the data-gradient launch also applies the backward of the ReLU (0.0) / LeakyReLU
         #   that produced this conv's input (the mask is the saved input itself), so the tensor it returns is
@@ -343,6 +344,9 @@ class ConvCfg:
         self.pixel_shuffle, self.stats, self.image_in = pixel_shuffle, stats, image_in
         self.in_scale, self.in_shift, self.tanh_head = in_scale, in_shift, tanh_head
         self.u8_head = u8_head and tanh_head
+        # pool_after (no-grad passes only): the MaxPool2d(2,2) that follows this conv + ReLU is taken in the epilogue and
+        # only the pooled tensor is stored (the full-resolution tensor is what a backward pass would need)
+        self.pool_after = pool_after
 
 
 class Conv3x3Fn(torch.autograd.Function):
@@ -375,14 +379,15 @@ class Conv3x3Fn(torch.autograd.Function):
         cin_pad = xin.shape[3]
         wpk = packed_filter(cd, weight, L.PACK_FWD_PS if cfg.pixel_shuffle else L.PACK_FWD, cin_pad)
         training = ctx.grad_on and any(ctx.needs_input_grad)
-        if cfg.u8_head and training:
-            raise L.FsrError("the uint8 head is an inference epilogue: it has no gradient")
+        if (cfg.u8_head or cfg.pool_after) and training:
+            raise L.FsrError("the uint8 head / fused max-pool epilogues are inference-only: they have no gradient")
         act = L.ACT_TANH if cfg.tanh_head else cfg.act
         want_pre = training and act == L.ACT_PRELU
         b32 = bias if bias is None or bias.dtype == torch.float32 else bias.float()
         out, pre, stats = conv3x3_raw(cd, xin, wpk, cout, stride=cfg.stride, bias=b32, act=act, slope=cfg.slope,
                                       prelu=prelu, pixel_shuffle=cfg.pixel_shuffle, out_f32=cfg.tanh_head,
-                                      want_stats=cfg.stats, want_preact=want_pre, alg_k=cin, out_u8=cfg.u8_head)
+                                      want_stats=cfg.stats, want_preact=want_pre, alg_k=cin, out_u8=cfg.u8_head,
+                                      pool2=cfg.pool_after)
         ctx.cfg = cfg
         ctx.dims = (cout, cin, tuple(xin.shape))
         ctx.has_bias = bias is not None

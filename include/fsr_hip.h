@@ -87,6 +87,9 @@ int fsr_pack_conv3x3(int dtype, int mode, const float* w_oihw, int cout, int cin
  *   head images, image gradients); FSR_OUT_U8 (2, FSR_ACT_TANH heads, forward): store the uint8 HWC image
  *   (unsigned char)(((tanh(z) + 1) / 2) * 255) -- inference.py:53-56's post-processing with its truncating cast,
  *   out [n,oh,ow,cout] bytes (cout = 3: the finished RGB frame).
+ * pool2 (inference / no-grad passes of vgg19.features, model.py:8,191): the kernel's epilogue takes the 2x2 maximum of the
+ *   activated outputs and stores only the pooled tensor -- the full-resolution tensor, which only a backward pass would
+ *   read, is never written.  oh, ow even; cout %% 16 == 0; no stats / preact / mask tensors.
  * stats (optional): float [n][cout][2]; receives the sum and the sum of squares of the pre-activation
  *   over pixels (needs `scratch` of fsr_conv3x3_scratch(desc) bytes; FWD and stride-1 DGRAD launches).
  * preact (optional): tensor like out; receives the pre-activation (training: PReLU backward
@@ -107,6 +110,7 @@ typedef struct fsr_conv_desc {
   int pixel_shuffle;
   int in_pixel_shuffled;
   int out_f32;
+  int pool2; /* FWD, 16-bit dtypes, no pixel shuffle: out is the MaxPool2d(2,2) of the activated result, [n,oh/2,ow/2,cout] */
 } fsr_conv_desc;
 
 size_t fsr_conv3x3_scratch(const fsr_conv_desc* desc);

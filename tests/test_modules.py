@@ -241,3 +241,25 @@ def test_generator_and_discriminator_fp16_mode(dev, pkg):
     named = [("g." + k, p.grad) for k, p in G.named_parameters()] + [("d." + k, p.grad) for k, p in D.named_parameters()]
     bad = check_grads("modules.f16.grad.%s" % dev.type, named, ref, t_tensor=0.35, t_slope=0.5, t_cos=0.95)
     assert not bad, bad
+
+
+def test_vgg_no_grad_pass_with_fused_pools_equals_the_training_pass(dev, pkg):
+    """Under torch.no_grad() (trainer.py:191's target features) the 16-bit VGG19 fuses every MaxPool2d into the epilogue of
+    the convolution in front of it; the features equal those of the grad-enabled pass (conv, then the pool kernel) bit
+    for bit -- the maximum commutes with the rounding and the ReLU."""
+    cdn = "bf16"
+    wd = 2
+    V = pkg.VGG19(compute_dtype=cdn, width_div=wd, seed=7).to(dev)
+    torch.manual_seed(2)
+    x = (torch.rand(2, 3, 32, 48) * 2 - 1).to(dev)
+    with torch.no_grad():
+        fused = V.features_nhwc(x)
+    plain = V.features_nhwc(x.clone().requires_grad_(True))
+    assert fused.shape == plain.shape == (2, 2, 3, 512 // wd)
+    assert torch.equal(fused, plain.detach())
+    if dev.type == "cuda":      # full width, larger image: the persistent 64-channel kernel and the tall configuration
+        V = pkg.VGG19(compute_dtype="f16", seed=7).to(dev)
+        x = (torch.rand(8, 3, 96, 64) * 2 - 1).to(dev)
+        with torch.no_grad():
+            fused = V.features_nhwc(x)
+        assert torch.equal(fused, V.features_nhwc(x.clone().requires_grad_(True)).detach())

@@ -235,10 +235,10 @@ def test_c_abi_rejects_malformed_calls(dev):
 
     def desc(**kw):
         base = dict(dtype=L.FSR_F32, mode=L.CONV_FWD, n=1, ih=8, iw=8, cin=16, oh=8, ow=8, cout=16, stride=1, act=L.ACT_NONE, slope=0.0,
-                    pixel_shuffle=0, in_pixel_shuffled=0, out_f32=0)
+                    pixel_shuffle=0, in_pixel_shuffled=0, out_f32=0, pool2=0)
         base.update(kw)
         return L.ConvDesc(*[base[k] for k in ("dtype", "mode", "n", "ih", "iw", "cin", "oh", "ow", "cout", "stride", "act", "slope",
-                                              "pixel_shuffle", "in_pixel_shuffled", "out_f32")])
+                                              "pixel_shuffle", "in_pixel_shuffled", "out_f32", "pool2")])
 
     def conv(d, **kw):
         a = dict(inp=p, w=p, bias=None, prelu=None, oscale=None, mask=None, out=p, pre=None, stats=None, scratch=p)
@@ -255,6 +255,8 @@ def test_c_abi_rejects_malformed_calls(dev):
     assert conv(desc(pixel_shuffle=1, cout=64), stats=p) < 0          # statistics + pixel shuffle
     assert conv(desc(cout=3), stats=p) < 0                            # statistics need cout % 16 == 0
     assert conv(desc(), stats=p, scratch=None) < 0                    # statistics need the partial-sum scratch
+    assert conv(desc(pool2=1)) < 0                                    # the fused max-pool epilogue is for the 16-bit modes
+    assert conv(desc(pool2=1, dtype=L.FSR_BF16, cin=32, oh=7, ih=7), stats=None) < 0   # ... and even output extents
     assert conv(desc(mode=L.CONV_DGRAD, stride=2, ih=4, iw=4), stats=p) < 0   # no statistics for stride-2 data gradients
     assert lib.fsr_conv3x3_scratch(ctypes.byref(desc())) >= 1 * 2 * 16 * 2 * 4
     # weight gradient: dims must match k=3, p=1

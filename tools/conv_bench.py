@@ -34,14 +34,14 @@ SHAPES = [
 ]
 
 
-def timeit(fn, iters=10):
+def timeit(fn, iters=10, eager=False):
     """Kernel time per call: `iters` calls captured into one hipGraph (no host launch gaps, no allocator calls between
     the kernels) and replayed; falls back to eager launches if the capture fails."""
     fn()
     torch.cuda.synchronize()
     s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     try:
-        if os.environ.get("FSR_BENCH_EAGER") == "1":    # PMC passes: plain launches
+        if eager or os.environ.get("FSR_BENCH_EAGER") == "1":    # PMC passes / library calls that cannot be captured
             raise RuntimeError("eager requested")
         g = torch.cuda.CUDAGraph()
         with torch.cuda.graph(g):
@@ -114,9 +114,9 @@ def main():
             wtt = wt.to(torch.bfloat16).contiguous(memory_format=torch.channels_last).requires_grad_(True)
             y = torch.nn.functional.conv2d(xt, wtt, None, stride, 1)
             g = torch.randn_like(y)
-            tf = timeit(lambda: torch.nn.functional.conv2d(xt, wtt, None, stride, 1))
-            td = timeit(lambda: torch.autograd.grad(y, xt, g, retain_graph=True))
-            tw = timeit(lambda: torch.autograd.grad(y, wtt, g, retain_graph=True))
+            tf = timeit(lambda: torch.nn.functional.conv2d(xt, wtt, None, stride, 1), 20, eager=True)
+            td = timeit(lambda: torch.autograd.grad(y, xt, g, retain_graph=True), 20, eager=True)
+            tw = timeit(lambda: torch.autograd.grad(y, wtt, g, retain_graph=True), 20, eager=True)
             extra = "%.0f / %.0f / %.0f" % (gflop / tf, gflop / td, gflop / tw)
         print("%-26s %9.1f | %8.1f %7.1f | %8.1f %7.1f | %8.1f %7.1f | %s" % (name, gflop, *res, extra), flush=True)
 
