@@ -337,8 +337,10 @@ __global__ __launch_bounds__(256) void conv_c3_wgrad_kernel(const C3Args a) {
 // dw[co][ci][ky][kx] += sum_slab ws[slab][co][k], k = (ky*3+kx)*3 + ci;  k == 27: the bias gradient.
 // Block = 32 consecutive k of one output channel x 8 slab lanes: lane j adds slabs j, j+8, ... in order, the eight lane
 // sums are added in order and one thread adds the result (no atomics: bit-reproducible).
+// transposed: the kernel ran with the roles swapped (image = the 3-channel gradient of a cout -> 3 convolution, dz = that
+// convolution's 64-channel input), so row co / column (tap, c3) is dW[c3][co][8 - tap] of the 3-output filter.
 __global__ __launch_bounds__(256) void conv_c3_wgrad_reduce_kernel(const float* __restrict__ ws, float* __restrict__ dw, int nslab,
-                                                                   int cout, float* __restrict__ dbias) {
+                                                                   int cout, float* __restrict__ dbias, int transposed) {
   __shared__ float red[8][32];
   const int total = cout * 32;
   const int k = threadIdx.x & 31, pl = threadIdx.x >> 5;
@@ -362,20 +364,22 @@ __global__ __launch_bounds__(256) void conv_c3_wgrad_reduce_kernel(const float* 
 #pragma unroll
     for (int j = 1; j < 8; ++j) r += red[j][k];
     const int tap = k / 3, ci = k - tap * 3;
-    float* o = (k == 27) ? dbias + co : dw + ((size_t)co * 3 + ci) * 9 + tap;
+    float* o = (k == 27) ? dbias + co : (transposed ? dw + ((size_t)ci * cout + co) * 9 + (8 - tap) : dw + ((size_t)co * 3 + ci) * 9 + tap);
     *o += r;
   }
 }
 
 // [cout_pad][32] filter image for the forward kernel
 template <typename T>
-__global__ void pack_c3_kernel(const float* __restrict__ w, T* __restrict__ out, int cout, int rows_pad) {
+__global__ void pack_c3_kernel(const float* __restrict__ w, T* __restrict__ out, int cout, int rows_pad, int transposed) {
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < rows_pad * 32; i += gridDim.x * blockDim.x) {
     const int k = i & 31, row = i >> 5;
     float v = 0.f;
     if (row < cout && k < 27) {
       const int tap = k / 3, ci = k - tap * 3;
-      v = w[((size_t)row * 3 + ci) * 9 + tap];
+      // transposed: w is the [3][cout][3][3] filter of a cout -> 3 convolution; its data gradient is the 3 -> cout
+      // convolution with rows = input channels and the taps flipped
+      v = transposed ? w[((size_t)ci * cout + row) * 9 + (8 - tap)] : w[((size_t)row * 3 + ci) * 9 + tap];
     }
     ElemIO<T>::st(out + i, v);
   }
@@ -401,16 +405,16 @@ int fill_args(C3Args& a, const char* what, int dtype, const float* img, long lon
 
 }  // namespace
 
-extern "C" int fsr_pack_conv3x3_c3(int dtype, const float* w_oihw, int cout, void* packed, fsr_stream_t stream_) {
+extern "C" int fsr_pack_conv3x3_c3(int dtype, const float* w_oihw, int cout, void* packed, int transposed, fsr_stream_t stream_) {
   if (!w_oihw || !packed || cout <= 0) return fsr_fail(-1, "fsr_pack_conv3x3_c3: bad argument");
   const int rows_pad = (cout + 15) / 16 * 16;
   const int blocks = (rows_pad * 32 + 255) / 256;
   if (dtype == FSR_BF16)
-    hipLaunchKernelGGL(pack_c3_kernel<bf16_t>, dim3(blocks), dim3(256), 0, (hipStream_t)stream_, w_oihw, (bf16_t*)packed, cout, rows_pad);
+    hipLaunchKernelGGL(pack_c3_kernel<bf16_t>, dim3(blocks), dim3(256), 0, (hipStream_t)stream_, w_oihw, (bf16_t*)packed, cout, rows_pad, transposed);
   else if (dtype == FSR_F16)
-    hipLaunchKernelGGL(pack_c3_kernel<f16_t>, dim3(blocks), dim3(256), 0, (hipStream_t)stream_, w_oihw, (f16_t*)packed, cout, rows_pad);
+    hipLaunchKernelGGL(pack_c3_kernel<f16_t>, dim3(blocks), dim3(256), 0, (hipStream_t)stream_, w_oihw, (f16_t*)packed, cout, rows_pad, transposed);
   else if (dtype == FSR_F32)
-    hipLaunchKernelGGL(pack_c3_kernel<float>, dim3(blocks), dim3(256), 0, (hipStream_t)stream_, w_oihw, (float*)packed, cout, rows_pad);
+    hipLaunchKernelGGL(pack_c3_kernel<float>, dim3(blocks), dim3(256), 0, (hipStream_t)stream_, w_oihw, (float*)packed, cout, rows_pad, transposed);
   else
     return fsr_fail(-2, "fsr_pack_conv3x3_c3: unknown dtype %d", dtype);
   return fsr_check_launch("pack_c3_kernel");
@@ -462,7 +466,7 @@ extern "C" size_t fsr_conv3x3_c3_wgrad_workspace(int n, int h, int w, int cout) 
 
 extern "C" int fsr_conv3x3_c3_wgrad(int dtype, const float* img, long long sn, long long sc, long long sh, long long sw,
                                     int n, int h, int w, float scale0, float scale1, float scale2, float shift0,
-                                    float shift1, float shift2, const void* dz, int cout, float* dw_oihw, float* dbias, void* workspace,
+                                    float shift1, float shift2, const void* dz, int cout, float* dw_oihw, float* dbias, void* workspace, int transposed,
                                     fsr_stream_t stream_) {
   C3Args a = {};
   const float scale3[3] = {scale0, scale1, scale2}, shift3[3] = {shift0, shift1, shift2};
@@ -478,6 +482,6 @@ extern "C" int fsr_conv3x3_c3_wgrad(int dtype, const float* img, long long sn, l
   else hipLaunchKernelGGL(conv_c3_wgrad_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream_, a);
   if (int rc = fsr_check_launch("conv_c3_wgrad_kernel")) return rc;
   hipLaunchKernelGGL(conv_c3_wgrad_reduce_kernel, dim3(cout), dim3(256), 0, (hipStream_t)stream_, (const float*)workspace,
-                     dw_oihw, nslab, cout, dbias);
+                     dw_oihw, nslab, cout, dbias, transposed);
   return fsr_check_launch("conv_c3_wgrad_reduce_kernel");
 }

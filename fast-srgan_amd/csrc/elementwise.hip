@@ -504,6 +504,46 @@ __global__ __launch_bounds__(256) void maxpool2_bwd_kernel(const T* __restrict__
   }
 }
 
+// Head backward straight to a 3-channel float image [n,h,w,3]: dz = g * (1 - y^2).  The first-layer kernels then read it in
+// place (data gradient = the 3 -> 64 convolution with the transposed, flipped filter; weight gradient with the roles of
+// image and gradient swapped) -- no 32-channel zero-padded copy of a 3-channel tensor is ever written.
+__global__ __launch_bounds__(256) void tanh_bwd_image_kernel(const float* __restrict__ g, long long sn, long long sc, long long sh,
+                                                             long long sw, const float* __restrict__ y, int h, int w,
+                                                             float* __restrict__ dz, int nrows, float* __restrict__ dbias) {
+  __shared__ float red[3][4];
+  float b0 = 0.f, b1 = 0.f, b2 = 0.f;
+  for (int row = blockIdx.x; row < nrows; row += gridDim.x) {
+    const int n = row / h, yy = row - n * h;
+    const float* src = g + n * sn + yy * sh;
+    const float* ty = y + (size_t)row * w * 3;
+    float* dst = dz + (size_t)row * w * 3;
+    for (int x = blockIdx.y * 256 + threadIdx.x; x < w; x += gridDim.y * 256) {
+      const float* s = src + x * sw;
+      const float* t = ty + x * 3;
+      const float v0 = s[0] * (1.f - t[0] * t[0]), v1 = s[sc] * (1.f - t[1] * t[1]), v2 = s[2 * sc] * (1.f - t[2] * t[2]);
+      dst[x * 3] = v0;
+      dst[x * 3 + 1] = v1;
+      dst[x * 3 + 2] = v2;
+      b0 += v0;
+      b1 += v1;
+      b2 += v2;
+    }
+  }
+  if (dbias) {
+    b0 = wave_sum(b0);
+    b1 = wave_sum(b1);
+    b2 = wave_sum(b2);
+    if ((threadIdx.x & 63) == 0) {
+      red[0][threadIdx.x >> 6] = b0;
+      red[1][threadIdx.x >> 6] = b1;
+      red[2][threadIdx.x >> 6] = b2;
+    }
+    __syncthreads();
+    if (threadIdx.x < 3)
+      dbias[(blockIdx.y * gridDim.x + blockIdx.x) * 3 + threadIdx.x] = red[threadIdx.x][0] + red[threadIdx.x][1] + red[threadIdx.x][2] + red[threadIdx.x][3];
+  }
+}
+
 template <typename T> T* P(void* p) { return (T*)p; }
 template <typename T> const T* P(const void* p) { return (const T*)p; }
 
@@ -664,6 +704,20 @@ extern "C" int fsr_tanh_bwd_to_nhwc(int dtype, const float* g, long long sn, lon
                                            stream, g, sn, sc, sh, sw, y_nhwc3, h, w, P<T>(dz), cpad, n * h,
                                            dbias ? (float*)scratch : nullptr);)
   if (int rc = fsr_check_launch("tanh_bwd_to_nhwc_kernel")) return rc;
+  if (dbias) return fsr_launch_reduce_partials((const float*)scratch, dbias, 1, gx * gy, 3, 3, 0, 0, 1.f, 0, stream);
+  return 0;
+}
+
+extern "C" int fsr_tanh_bwd_image(const float* g, long long sn, long long sc, long long sh, long long sw, const float* y_nhwc3,
+                                  int n, int h, int w, float* dz_nhwc3, float* dbias, void* scratch, fsr_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  if (!g || !y_nhwc3 || !dz_nhwc3) return fsr_fail(-1, "fsr_tanh_bwd_image: null argument");
+  if (dbias && !scratch) return fsr_fail(-1, "fsr_tanh_bwd_image: the bias gradient needs the scratch buffer");
+  if (n <= 0 || h <= 0 || w <= 0) return fsr_fail(-2, "fsr_tanh_bwd_image: bad dims");
+  const int gx = n * h < 512 ? n * h : 512, gy = (w + 255) / 256 < 64 ? (w + 255) / 256 : 64;
+  hipLaunchKernelGGL(tanh_bwd_image_kernel, dim3(gx, gy), dim3(256), 0, stream, g, sn, sc, sh, sw, y_nhwc3, h, w, dz_nhwc3, n * h,
+                     dbias ? (float*)scratch : nullptr);
+  if (int rc = fsr_check_launch("tanh_bwd_image_kernel")) return rc;
   if (dbias) return fsr_launch_reduce_partials((const float*)scratch, dbias, 1, gx * gy, 3, 3, 0, 0, 1.f, 0, stream);
   return 0;
 }

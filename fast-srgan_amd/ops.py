@@ -52,6 +52,7 @@ _pack_cache = {}   # id(weight) -> (weakref to the weight, {(mode, dtype, k_pad)
 
 
 PACK_C3 = "c3"   # packed_filter mode of the first-layer (image-input) kernels
+PACK_C3T = "c3t"  # ... of the head conv's data gradient run as a first-layer forward (transposed, tap-flipped filter)
 
 
 def packed_filter(cd, weight, mode, k_pad):
@@ -80,12 +81,17 @@ def packed_filter(cd, weight, mode, k_pad):
     if w.dtype != torch.float32 or not w.is_contiguous():
         w = w.float().contiguous()
     _check_dev(w)
-    numel = ((cout + 15) // 16 * 16) * 32 if mode == PACK_C3 else 9 * rows_pad * k_pad
+    if mode == PACK_C3T:
+        numel = ((cin + 15) // 16 * 16) * 32
+    else:
+        numel = ((cout + 15) // 16 * 16) * 32 if mode == PACK_C3 else 9 * rows_pad * k_pad
     out = hit[1] if (hit is not None and hit[1].device == w.device) else None
     if out is None:
         out = torch.empty(numel, dtype=cd.torch_dtype, device=w.device)
     if mode == PACK_C3:     # first-layer kernels: [rows_pad][32]
-        L.check(L.lib().fsr_pack_conv3x3_c3(cd.code, _p(w), cout, _p(out), _stream()), "fsr_pack_conv3x3_c3")
+        L.check(L.lib().fsr_pack_conv3x3_c3(cd.code, _p(w), cout, _p(out), 0, _stream()), "fsr_pack_conv3x3_c3")
+    elif mode == PACK_C3T:  # head conv [3][cin][3][3]: rows = its input channels
+        L.check(L.lib().fsr_pack_conv3x3_c3(cd.code, _p(w), cin, _p(out), 1, _stream()), "fsr_pack_conv3x3_c3")
     else:
         L.check(L.lib().fsr_pack_conv3x3(cd.code, mode, _p(w), cout, cin, k_pad, _p(out), _stream()), "fsr_pack_conv3x3")
     slot[1][key] = (ver, out)
@@ -458,6 +464,8 @@ class Conv3x3Fn(torch.autograd.Function):
         dbias = _zeros((cout,), xin.device) if ctx.has_bias else None
         dprelu = None
         act = L.ACT_TANH if cfg.tanh_head else cfg.act
+        if cfg.tanh_head and USE_C3_KERNELS and cout == 3 and cin_pad % 16 == 0 and cin == cin_pad:
+            return Conv3x3Fn._backward_head_c3(ctx, g)
         if cfg.tanh_head:
             # g: (N,3,H,W) float of any strides; saved: head output (N,H,W,3) float
             if g.dtype != torch.float32:
@@ -517,7 +525,7 @@ class Conv3x3Fn(torch.autograd.Function):
                     sn, sc, sh, sw = xin.stride()
                     L.check(lib.fsr_conv3x3_c3_wgrad(cd.code, _p(xin), sn, sc, sh, sw, n, ih, iw, *cfg.in_scale, *cfg.in_shift,
                                                      _p(dz), cout, _p(out), _p(bias_arena) if fused_dbias else None,
-                                                     _p(_workspace(need, xin.device)), _stream()),
+                                                     _p(_workspace(need, xin.device)), 0, _stream()),
                             "fsr_conv3x3_c3_wgrad")
                     return out
                 return conv3x3_wgrad_raw(cd, xin, dz, cout, cin, cfg.stride, dy_pixel_shuffled=cfg.pixel_shuffle, out=arena)
@@ -534,6 +542,60 @@ class Conv3x3Fn(torch.autograd.Function):
             db = None       # accumulated in the arena by the weight-gradient launch
         dp = dprelu if (dprelu is not None and ctx.needs_input_grad[3]) else None
         return dx, dw, db, dp, None, None
+
+
+def _head_backward_c3(ctx, g):
+    """Backward of the head Conv2d(nf -> 3) + Tanh (model.py:102-110) on the first-layer kernels: dz = g (1 - y^2) is written
+    as a 3-channel float image; the data gradient is the 3 -> nf convolution of that image with the transposed, tap-flipped
+    filter (fsr_conv3x3_c3_fwd), the weight gradient the first-layer weight gradient with the roles of image and gradient
+    swapped.  (The generic path pads dz to 32 channels: 10x the bytes for 3 channels of data.)"""
+    cfg, cd = ctx.cfg, ctx.cfg.cd
+    xin, weight, _prelu, saved = ctx.saved_tensors
+    cout, cin, xshape = ctx.dims
+    n, ih, iw, cin_pad = xshape
+    lib, st = L.lib(), _stream()
+    if g.dtype != torch.float32:
+        g = g.float()
+    dbias = _zeros((cout,), xin.device) if (ctx.has_bias and ctx.needs_input_grad[2]) else None
+    dz_img = torch.empty((n, ih, iw, 3), dtype=torch.float32, device=xin.device)
+    sn, sc, sh, sw = g.stride()
+    L.check(lib.fsr_tanh_bwd_image(_p(g), sn, sc, sh, sw, _p(saved), n, ih, iw, _p(dz_img), _p(dbias),
+                                   _p(_workspace(lib.fsr_tanh_bwd_scratch(), xin.device)), st), "fsr_tanh_bwd_image")
+    img_strides = (ih * iw * 3, 1, iw * 3, 3)     # the NHWC float image viewed as (N,3,H,W)
+    one, zero = (1.0, 1.0, 1.0), (0.0, 0.0, 0.0)
+    dx = None
+    if ctx.needs_input_grad[0]:
+        wpk = packed_filter(cd, weight, PACK_C3T, 32)
+        dx = torch.empty((n, ih, iw, cin_pad), dtype=cd.torch_dtype, device=xin.device)
+        prof = PROFILE_CONV
+        if prof is not None:
+            ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            ev0.record()
+        L.check(lib.fsr_conv3x3_c3_fwd(cd.code, _p(dz_img), *img_strides, n, ih, iw, *one, *zero, _p(wpk), None, L.ACT_NONE, 0.0, None,
+                                       cin_pad, _p(dx), None, st), "fsr_conv3x3_c3_fwd")
+        if prof is not None:
+            ev1.record()
+            prof.append((ev0, ev1, 2.0 * n * ih * iw * cin * 27, dz_img.numel() * 4 + dx.numel() * dx.element_size(), "conv_c3_fwd_kernel", "dgrad"))
+    dw = None
+    if ctx.needs_input_grad[1]:
+        arena = getattr(weight, "_fsr_grad", None)
+
+        def launch():
+            out = arena if arena is not None else torch.zeros((cout, cin, 3, 3), dtype=torch.float32, device=xin.device)
+            need = lib.fsr_conv3x3_c3_wgrad_workspace(n, ih, iw, cin_pad)
+            L.check(lib.fsr_conv3x3_c3_wgrad(cd.code, _p(dz_img), *img_strides, n, ih, iw, *one, *zero, _p(xin), cin_pad, _p(out), None,
+                                             _p(_workspace(need, xin.device)), 1, _stream()), "fsr_conv3x3_c3_wgrad")
+            return out
+
+        if arena is not None:
+            with _on_wgrad_stream(xin, dz_img):
+                launch()
+        else:
+            dw = launch()
+    return dx, dw, dbias, None, None, None
+
+
+Conv3x3Fn._backward_head_c3 = staticmethod(_head_backward_c3)
 
 
 def conv3x3(x, weight, bias, prelu, cfg):

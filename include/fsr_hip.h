@@ -174,8 +174,11 @@ int fsr_image_to_nhwc(int dtype, const float* img, long long sn, long long sc, l
                       float shift2, void* out, int cpad, fsr_stream_t stream);
 /* Head backward (model.py:102-110): dz = g * (1 - y^2) for y = tanh(z), written zero-padded NHWC;
  * g has element strides (sn,sc,sh,sw), y is the head output [n,h,w,3] float.  dbias[3] (optional) = sums;
- * scratch (with dbias): fsr_tanh_bwd_scratch() bytes. */
+ * scratch (with dbias): fsr_tanh_bwd_scratch() bytes.
+ * fsr_tanh_bwd_image: the same gradient as a 3-channel float image dz [n,h,w,3] (no padding), for the first-layer kernels. */
 size_t fsr_tanh_bwd_scratch(void);
+int fsr_tanh_bwd_image(const float* g, long long sn, long long sc, long long sh, long long sw, const float* y_nhwc3, int n, int h,
+                       int w, float* dz_nhwc3, float* dbias, void* scratch, fsr_stream_t stream);
 int fsr_tanh_bwd_to_nhwc(int dtype, const float* g, long long sn, long long sc, long long sh, long long sw,
                          const float* y_nhwc3, int n, int h, int w, void* dz, int cpad, float* dbias, void* scratch,
                          fsr_stream_t stream);
@@ -195,8 +198,13 @@ int fsr_u8_to_image(const uint8_t* frames, float* img, long long count, fsr_stre
  *   fsr_conv3x3_c3_wgrad: dw_oihw (float [cout][3][3][3]) += d loss / d weight for dz [n,h,w,cout] `dtype`;
  *                         dbias (optional, float [cout]) += per-channel sums of dz (the bias gradient: a column of
  *                         ones in the padded K dimension of the same MFMAs);
- *                         workspace of fsr_conv3x3_c3_wgrad_workspace(n,h,w,cout) bytes. */
-int fsr_pack_conv3x3_c3(int dtype, const float* w_oihw, int cout, void* packed, fsr_stream_t stream);
+ *                         workspace of fsr_conv3x3_c3_wgrad_workspace(n,h,w,cout) bytes.
+ * transposed != 0 serves the OTHER 3-channel end, the head Conv2d(cout -> 3) + Tanh (model.py:102-110), whose backward has the
+ * same shape with the roles swapped -- img is then the 3-channel gradient dz = g (1 - y^2) (fsr_tanh_bwd_image):
+ *   fsr_pack_conv3x3_c3(transposed): w_oihw is the head's [3][cout][3][3] filter; the pack holds its transposed, tap-flipped
+ *                         form, and fsr_conv3x3_c3_fwd of `img` with it IS the head's data gradient [n,h,w,cout];
+ *   fsr_conv3x3_c3_wgrad(transposed): `dz` is the head's 64-channel INPUT, dw_oihw the head's [3][cout][3][3] gradient. */
+int fsr_pack_conv3x3_c3(int dtype, const float* w_oihw, int cout, void* packed, int transposed, fsr_stream_t stream);
 int fsr_conv3x3_c3_fwd(int dtype, const float* img, long long sn, long long sc, long long sh, long long sw, int n, int h,
                        int w, float scale0, float scale1, float scale2, float shift0, float shift1, float shift2,
                        const void* packed_w, const float* bias, int act, float slope, const float* prelu_weight, int cout,
@@ -204,7 +212,8 @@ int fsr_conv3x3_c3_fwd(int dtype, const float* img, long long sn, long long sc, 
 size_t fsr_conv3x3_c3_wgrad_workspace(int n, int h, int w, int cout);
 int fsr_conv3x3_c3_wgrad(int dtype, const float* img, long long sn, long long sc, long long sh, long long sw, int n, int h,
                          int w, float scale0, float scale1, float scale2, float shift0, float shift1, float shift2,
-                         const void* dz, int cout, float* dw_oihw, float* dbias, void* workspace, fsr_stream_t stream);
+                         const void* dz, int cout, float* dw_oihw, float* dbias, void* workspace, int transposed,
+                         fsr_stream_t stream);
 
 /* ------------------------------------------------------------------ MaxPool2d(2,2) of vgg19.features (model.py:8)
  * x [n,h,w,c] -> y [n,h/2,w/2,c].  Backward routes g to the first maximum in window scan order; with

@@ -285,7 +285,7 @@ def test_first_layer_kernels_reject_bad_arguments(dev):
     assert lib.fsr_conv3x3_c3_fwd(cd.code, *args, wpk.data_ptr(), None, L.ACT_NONE, 0.0, None, 24, out.data_ptr(), None, None) < 0
     assert b"multiple of 16" in lib.fsr_last_error()
     assert lib.fsr_conv3x3_c3_fwd(cd.code, *args, wpk.data_ptr(), None, L.ACT_PRELU, 0.0, None, 16, out.data_ptr(), None, None) < 0
-    assert lib.fsr_conv3x3_c3_wgrad(cd.code, *args, None, 16, out.data_ptr(), None, out.data_ptr(), None) < 0
+    assert lib.fsr_conv3x3_c3_wgrad(cd.code, *args, None, 16, out.data_ptr(), None, out.data_ptr(), 0, None) < 0
     assert lib.fsr_conv3x3_c3_wgrad_workspace(0, 8, 8, 16) == 0
 
 
