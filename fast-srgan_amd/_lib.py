@@ -55,6 +55,8 @@ SIGNATURES = {
     "fsr_conv3x3": (c_int, [ctypes.POINTER(ConvDesc), P, P, P, P, P, P, c_float, P, P, P, P, P]),
     "fsr_conv3x3_wgrad_workspace": (c_size_t, [ctypes.POINTER(WgradDesc)]),
     "fsr_conv3x3_wgrad": (c_int, [ctypes.POINTER(WgradDesc), P, P, P, P, P]),
+    "fsr_conv3x3_wgrad_grouped_workspace": (c_size_t, [ctypes.POINTER(WgradDesc), c_int]),
+    "fsr_conv3x3_wgrad_grouped": (c_int, [ctypes.POINTER(WgradDesc), c_int, P, P, P, P, P]),
     "fsr_instnorm_act_fwd": (c_int, [c_int, P, P, P, c_int, c_float, P, P, c_int, c_int, c_int, P]),
     "fsr_instnorm_act_bwd_scratch": (c_size_t, [c_int, c_int, c_int]),
     "fsr_instnorm_act_bwd_reduce": (c_int, [c_int, P, P, P, c_int, c_float, P, P, P, P, c_int, c_int, c_int, P]),

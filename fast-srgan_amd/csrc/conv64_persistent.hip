@@ -318,6 +318,346 @@ __global__ __launch_bounds__(NTHR64, 2) void conv64_persistent_kernel(const Conv
 }
 
 // ---------------------------------------------------------------------------------------------------------------
+// The 64-channel-block kernel, second form (NT = 4 only; the thin kernel above keeps the first form, whose small LDS
+// footprint admits two workgroups per CU).  Measured on the first form at 96^2 (tools/conv_bench.py, batch 32 .. 256): a
+// workgroup needs 6.5 us per tile, of which the 288 MFMAs per SIMD are 1.9 us -- prefetch, MFMAs, epilogue, barrier,
+// LDS commit, barrier run one after the other and all eight waves walk them in lock step.  This form takes the phases
+// apart:
+//   * LDS rows are 128 B with an XOR swizzle (16-byte unit u of row r sits at u ^ (r & 7)) instead of a 160 B pitch:
+//     filter 73,728 B + TWO halo buffers of 328 pixels (41,984 B each) + statistics 4 KB = 161,792 B.
+//   * the halo of the next tile goes global -> LDS by DMA (global_load_lds_dwordx4, swizzle on the source address,
+//     padding from a zero page) into the other buffer: no staging registers, no commit pass, ONE barrier per tile.
+//   * the epilogue of tile i runs inside tile i + 1: waves 0-3 after the second tap, waves 4-7 (their SIMD partners)
+//     after the sixth, so one wave of a SIMD stores while the other owns the MFMA pipe.  Waves 0-3 also issue the DMA
+//     (after their epilogue: the mask loads of a fused activation gradient are then not queued behind it).
+// Results are those of the first form (same operand mapping, same summation order).
+#ifndef FSR_ABL64
+#define FSR_ABL64 0     // ablation builds (tools/build_variant.sh): 1 no stores, 2 no halo DMA after the first tile, 3 both, 4 no MFMAs
+#endif
+constexpr int HPIX2 = 328;                    // 18 x 18 halo pixels, rounded up to whole 8-pixel DMA instructions
+constexpr int NDMA2 = HPIX2 / 8;
+constexpr int W2_BYTES = 9 * 64 * 64 * 2;
+constexpr int H2_BYTES = HPIX2 * 64 * 2;
+constexpr int LDS64V2 = W2_BYTES + 2 * H2_BYTES + SRED_BYTES;
+
+__device__ unsigned conv64_zero_page[64];     // padding source of the halo DMA
+
+// STATS / MASK: InstanceNorm statistics / fused activation-gradient mask compiled in (never both: see the launcher);
+// the variants without them free the 32 / 16 registers those carry across the MFMA phase.
+template <typename T, bool STATS, bool MASK>
+__global__ __launch_bounds__(NTHR64) void conv64_v2_kernel(const ConvKArgs a) {
+  constexpr int NT = 4;
+  HIP_DYNAMIC_SHARED(char, smem)
+  T* wl = (T*)smem;
+  T* halo0 = (T*)(smem + W2_BYTES);
+  float* sred = (float*)(smem + W2_BYTES + 2 * H2_BYTES);
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int l15 = lane & 15, lg = lane >> 4;
+  const int l8 = lane >> 3, s8 = lane & 7;
+  const T* in = (const T*)a.in;
+  const int tiles_per_img = a.tiles_x * a.tiles_y;
+  const int ntiles = tiles_per_img * a.N;
+  const int nblk = a.CoutPad >> 6;
+  const int nb = (int)blockIdx.x % nblk;
+  const T* zero = (const T*)conv64_zero_page;
+
+  // ---- filter block nb, all nine taps: LDS row r = slice * 64 + row; 72 wave instructions of 8 rows
+  {
+    const T* wpk = (const T*)a.wpk + (size_t)nb * 64 * 64;
+#pragma unroll
+    for (int i = 0; i < 9; ++i) {
+      const int k = wave + i * 8;
+      const int r = k * 8 + l8;
+      const int slice = r >> 6, j = r & 63;
+      const int row = ((j & 12) << 2) + ((j >> 4) << 2) + (j & 3);   // MFMA row i of tile n <- channel (i >> 2) * 16 + n * 4 + (i & 3)
+      FSR_GLDS16(wpk + ((size_t)slice * a.CoutPad * 64 + (size_t)(row * 64 + ((s8 ^ (r & 7)) * 8))), wl + k * 8 * 64);
+    }
+  }
+  // halo of `tile` -> buffer `buf`: wave instruction k fills pixels 8k .. 8k+7 (this wave: k = wid, wid + nw, ...)
+  auto halo_dma = [&](int tile, int buf, int wid, int nw) {
+    const int img = tile / tiles_per_img;
+    const int rem = tile - img * tiles_per_img;
+    const int ty = rem / a.tiles_x, tx = rem - ty * a.tiles_x;
+    const int iy0 = ty * 16 + a.org_y, ix0 = tx * 16 + a.org_x;
+    T* hb = halo0 + buf * (HPIX2 * 64);
+    for (int k = wid; k < NDMA2; k += nw) {
+      const int p = k * 8 + l8;
+      const int hy = p / HT, hx = p - hy * HT;
+      const int iy = iy0 + hy, ix = ix0 + hx;
+      const bool ok = p < HT * HT && iy >= 0 && iy < a.IH && ix >= 0 && ix < a.IW;
+      const T* src = ok ? in + ((unsigned)((img * a.IH + iy) * a.IW + ix) * 64u + (unsigned)((s8 ^ (p & 7)) * 8)) : zero + s8 * 8;
+      FSR_GLDS16(src, hb + k * 8 * 64);
+    }
+  };
+
+  float slope = (a.act == FSR_ACT_PRELU) ? a.prelu[0] : a.slope;
+  if (a.act == FSR_ACT_NONE || a.act == FSR_ACT_TANH) slope = 1.f;
+  if (a.act == FSR_ACT_RELU) slope = 0.f;
+  constexpr bool want_stats = STATS;
+  const bool ps = !STATS && !MASK && a.ps;          // PixelShuffle / fused pool: plain variant only (launcher)
+  const bool pool2 = !STATS && !MASK && a.pool2;
+  T* outp = (T*)a.out;
+  T* prep = (T*)a.preact;
+  const T* maskp = MASK ? (const T*)a.dmask : nullptr;
+
+  int p0[2], wofs[2];
+#pragma unroll
+  for (int m = 0; m < 2; ++m) p0[m] = (wave * 2 + m) * HT + l15;
+#pragma unroll
+  for (int ks = 0; ks < 2; ++ks) wofs[ks] = l15 * 64 + (((ks * 4 + lg) ^ (l15 & 7)) * 8);
+  f32x4 bias[NT];
+#pragma unroll
+  for (int n = 0; n < NT; ++n) {
+    bias[n] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    if (a.bias) {
+      if (!ps) bias[n] = *(const f32x4*)(a.bias + nb * 64 + lg * 16 + n * 4);
+      else
+#pragma unroll
+        for (int r = 0; r < 4; ++r) bias[n][r] = a.bias[4 * (lg * 16 + n * 4 + r) + nb];   // torch order 4*cc + quadrant
+    }
+  }
+  const int tile_begin = ((int)blockIdx.x / nblk) * a.nblk_n;
+  const int tile_end = (tile_begin + a.nblk_n < ntiles) ? tile_begin + a.nblk_n : ntiles;
+  f32x4 s1acc[STATS ? NT : 1], s2acc[STATS ? NT : 1];
+#pragma unroll
+  for (int n = 0; n < (STATS ? NT : 1); ++n) s1acc[n] = s2acc[n] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  if (tile_begin < tile_end) halo_dma(tile_begin, 0, wave, 8);
+  FSR_WAIT_DMA();
+  __syncthreads();
+
+  f32x4 acc[2][NT], accp[2][NT];
+  const T* hb = halo0;
+  // One step = (tap, 32-channel half): 6 fragment reads, 8 MFMAs.  Inside a segment of taps the reads of step s + 1 are
+  // issued before the MFMAs of step s (two fragment sets): a wave then keeps the matrix pipe busy on its own and the
+  // DMA / epilogue issue time of its SIMD partner is covered instead of added.
+  auto load_step = [&](auto sc, s16x8 (&wf)[NT], s16x8 (&xf)[2]) {
+    constexpr int st = decltype(sc)::value;
+    constexpr int t = st >> 1, ks = st & 1;
+    const unsigned tc = tap64(a, t);
+    const int shift = (int)(tc & 3u) * HT + (int)((tc >> 2) & 3u);
+    const T* wsl = wl + (int)(tc >> 4) * (64 * 64);
+#pragma unroll
+    for (int n = 0; n < NT; ++n) wf[n] = *(const s16x8*)(wsl + wofs[ks] + n * (16 * 64));
+#pragma unroll
+    for (int m = 0; m < 2; ++m) {
+      const int p = p0[m] + shift;
+      const int u = (lg + ks * 4) ^ (p & 7);
+      xf[m] = *(const s16x8*)(hb + (p * 64 + u * 8));
+    }
+  };
+  auto run_taps = [&](auto t0c, auto t1c) {
+#if FSR_ABL64 == 4
+    if (a.GW >= 0) return;
+#endif
+    constexpr int S0 = decltype(t0c)::value * 2, S1 = decltype(t1c)::value * 2;
+    s16x8 wfa[NT], xfa[2], wfb[NT], xfb[2];
+    load_step(std::integral_constant<int, S0>{}, wfa, xfa);
+    static_for<S0, S1>([&](auto sc) {
+      constexpr int st = decltype(sc)::value;
+      constexpr bool even = ((st - S0) & 1) == 0;
+      if constexpr (st + 1 < S1) {
+        if constexpr (even) load_step(std::integral_constant<int, st + 1>{}, wfb, xfb);
+        else load_step(std::integral_constant<int, st + 1>{}, wfa, xfa);
+      }
+#pragma unroll
+      for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int n = 0; n < NT; ++n)
+          acc[m][n] = even ? mfma16<T>(wfa[n], xfa[m], acc[m][n]) : mfma16<T>(wfb[n], xfb[m], acc[m][n]);
+      __builtin_amdgcn_sched_barrier(0);
+    });
+  };
+
+  // ---- epilogue of the PREVIOUS tile, in two parts: coordinates + mask loads at the top of an iteration, the rest later
+  int e_img = 0, e_gx = 0, e_gyb = 0;
+  bool e_col_ok = false, e_flush = false;
+  unsigned e_rstride = 0, e_base0 = 0;
+  u32x4 mkv[MASK ? 2 : 1][2];     // the lane's 16 mask channels of a row: two 16-byte loads
+  auto ep_prepare = [&](int tile) {
+    e_img = tile / tiles_per_img;
+    const int rem = tile - e_img * tiles_per_img;
+    const int ty = rem / a.tiles_x, tx = rem - ty * a.tiles_x;
+    e_gx = tx * 16 + l15;
+    e_gyb = ty * 16 + wave * 2;
+    e_col_ok = e_gx < a.GW;
+    e_rstride = ps ? (unsigned)(4 * a.FOW * 64) : (unsigned)(a.FOW * a.Cout);
+    e_base0 = ps ? (unsigned)((e_img * 2 * a.FOH + 2 * e_gyb + (nb >> 1)) * (2 * a.FOW) + 2 * e_gx + (nb & 1)) * 64u + (unsigned)(lg * 16)
+                   : (unsigned)((e_img * a.FOH + e_gyb) * a.FOW + e_gx) * (unsigned)a.Cout + (unsigned)(nb * 64 + lg * 16);
+    e_flush = want_stats && (tile + 1 >= tile_end || (tile + 1) / tiles_per_img != e_img);
+  };
+  // mask vectors of the CURRENT tile (plain layout only), loaded late in its MFMA phase and used by its epilogue in the
+  // next iteration: they land before the iteration's closing s_waitcnt vmcnt(0), so the halo DMA issued at the top of the
+  // next iteration is never waited for by an epilogue
+  auto mask_issue = [&](int tile) {
+    const int img = tile / tiles_per_img;
+    const int rem = tile - img * tiles_per_img;
+    const int ty = rem / a.tiles_x, tx = rem - ty * a.tiles_x;
+    const int gx = tx * 16 + l15, gyb = ty * 16 + wave * 2;
+    const unsigned rstride = (unsigned)(a.FOW * a.Cout);
+    const unsigned base0 = (unsigned)((img * a.FOH + gyb) * a.FOW + gx) * (unsigned)a.Cout + (unsigned)(nb * 64 + lg * 16);
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+      for (int h = 0; h < 2; ++h)
+        mkv[m][h] = (gx < a.GW && gyb + m < a.GH) ? *(const u32x4*)(maskp + (base0 + m * rstride + h * 8)) : (u32x4){0u, 0u, 0u, 0u};
+  };
+  auto ep_finish = [&]() {
+    const int img = e_img, gx = e_gx, gyb = e_gyb;
+    const bool col_ok = e_col_ok;
+    if (pool2) {
+      // MaxPool2d(2,2) fused (no-grad vgg19 passes): the wave's two rows and the columns (l15, l15 ^ 1) of neighbouring
+      // lanes; even lanes store pixel (gy / 2, gx / 2) of the [N][FOH/2][FOW/2][Cout] tensor
+      u32x4 pk[2];
+      static_for<0, NT>([&](auto nc) {
+        constexpr int n = decltype(nc)::value;
+        f32x4 v = accp[0][n] + bias[n], w = accp[1][n] + bias[n];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          float x = fmaxf(v[r], w[r]);
+          x = fmaxf(x, __shfl_xor(x, 1, 64));
+          v[r] = fmaxf(x, 0.f) + slope * fminf(x, 0.f);
+        }
+        pk[n >> 1][(n & 1) * 2] = pack2<T>(v[0], v[1]);
+        pk[n >> 1][(n & 1) * 2 + 1] = pack2<T>(v[2], v[3]);
+      });
+      if (col_ok && gyb < a.GH && !(l15 & 1)) {
+        const unsigned off = (unsigned)((img * (a.FOH >> 1) + (gyb >> 1)) * (a.FOW >> 1) + (gx >> 1)) * (unsigned)a.Cout + (unsigned)(nb * 64 + lg * 16);
+        *(u32x4*)(outp + off) = pk[0];
+        *(u32x4*)(outp + off + 8) = pk[1];
+      }
+      return;
+    }
+    // the lane holds channels lg * 16 .. lg * 16 + 15 of its pixel (tile n: + 4 n): 32 contiguous bytes per row, two
+    // 16-byte stores (8-byte stores are issue-bound: ~7 B / clk / CU)
+    static_for<0, 2>([&](auto mc) {
+      constexpr int m = decltype(mc)::value;
+      if (col_ok && gyb + m < a.GH) {
+        const unsigned off = e_base0 + m * e_rstride;
+        u32x4 pk[2], pp[2];
+        static_for<0, NT>([&](auto nc) {
+          constexpr int n = decltype(nc)::value;
+          f32x4 v = accp[m][n] + bias[n];
+          if constexpr (MASK) {
+            const unsigned t0 = mkv[m][n >> 1][(n & 1) * 2], t1 = mkv[m][n >> 1][(n & 1) * 2 + 1];
+            const float mk[4] = {cvt_lo<T>(t0), cvt_hi<T>(t0), cvt_lo<T>(t1), cvt_hi<T>(t1)};
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] = mk[r] > 0.f ? v[r] : v[r] * a.dmask_slope;
+          }
+          if constexpr (STATS) {
+            s1acc[n] += v;
+            s2acc[n] += v * v;
+          }
+          if (prep) {
+            pp[n >> 1][(n & 1) * 2] = pack2<T>(v[0], v[1]);
+            pp[n >> 1][(n & 1) * 2 + 1] = pack2<T>(v[2], v[3]);
+          }
+#pragma unroll
+          for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f) + slope * fminf(v[r], 0.f);
+          pk[n >> 1][(n & 1) * 2] = pack2<T>(v[0], v[1]);
+          pk[n >> 1][(n & 1) * 2 + 1] = pack2<T>(v[2], v[3]);
+        });
+        if (prep) {
+          *(u32x4*)(prep + off) = pp[0];
+          *(u32x4*)(prep + off + 8) = pp[1];
+        }
+#if FSR_ABL64 == 1 || FSR_ABL64 == 3
+        if (a.GW < 0)
+#endif
+        {
+          *(u32x4*)(outp + off) = pk[0];
+          *(u32x4*)(outp + off + 8) = pk[1];
+        }
+      }
+    });
+    if constexpr (STATS) if (e_flush) {
+      static_for<0, NT>([&](auto nc) {
+        constexpr int n = decltype(nc)::value;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          float x1 = s1acc[n][r], x2 = s2acc[n][r];
+#pragma unroll
+          for (int o = 8; o >= 1; o >>= 1) {
+            x1 += __shfl_xor(x1, o, 64);
+            x2 += __shfl_xor(x2, o, 64);
+          }
+          if (l15 == 0) {
+            const int cl = lg * 16 + n * 4 + r;
+            sred[(wave * 64 + cl) * 2] = x1;
+            sred[(wave * 64 + cl) * 2 + 1] = x2;
+          }
+        }
+        s1acc[n] = s2acc[n] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      });
+    }
+  };
+  // the eight waves' statistics of image `img`, added in order -> this workgroup's slot (after the barrier that follows
+  // the flushing epilogue)
+  int pend_img = -1;
+  auto stats_store = [&]() {
+    if (tid < 128) {
+      float sum = sred[tid];
+#pragma unroll
+      for (int w = 1; w < 8; ++w) sum += sred[w * 128 + tid];
+      const int slot = (int)blockIdx.x / nblk - (pend_img * tiles_per_img) / a.nblk_n;
+      a.stats[(((size_t)pend_img * a.stats_P + slot) * a.Cout + nb * 64 + (tid >> 1)) * 2 + (tid & 1)] = sum;
+    }
+  };
+
+  int buf = 0;
+  for (int tile = tile_begin; tile <= tile_end && tile_begin < tile_end; ++tile) {
+    const bool have = tile < tile_end, hasprev = tile > tile_begin;
+    const int next = tile + 1;
+    if (pend_img >= 0) {          // uniform: a flush happened in the previous iteration
+      stats_store();
+      __syncthreads();            // sred may be rewritten by this iteration's epilogue
+      pend_img = -1;
+    }
+    // the whole iteration is the DMA's window: nothing this wave loads later is queued behind it (see mask_issue)
+#if FSR_ABL64 == 2 || FSR_ABL64 == 3
+    if (wave < 4 && have && next < tile_end && a.GW < 0) halo_dma(next, buf ^ 1, wave, 4);
+#else
+    if (wave < 4 && have && next < tile_end) halo_dma(next, buf ^ 1, wave, 4);
+#endif
+    if (hasprev) ep_prepare(tile - 1);
+    hb = halo0 + buf * (HPIX2 * 64);
+    if (have) {
+#pragma unroll
+      for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int n = 0; n < NT; ++n) acc[m][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      run_taps(std::integral_constant<int, 0>{}, std::integral_constant<int, 2>{});
+    }
+    if (wave < 4 && hasprev) ep_finish();
+    if (have) run_taps(std::integral_constant<int, 2>{}, std::integral_constant<int, 6>{});
+    if (wave >= 4 && hasprev) ep_finish();
+    if constexpr (MASK) {
+      if (have) mask_issue(tile);
+    }
+    if (have) {
+      run_taps(std::integral_constant<int, 6>{}, std::integral_constant<int, 9>{});
+#pragma unroll
+      for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int n = 0; n < NT; ++n) accp[m][n] = acc[m][n];
+    }
+    if (hasprev && e_flush) pend_img = e_img;
+    FSR_WAIT_DMA();
+    if constexpr (MASK) {
+      // the compiler's own wait for the mask loads goes here (first use), where it is already satisfied
+#pragma unroll
+      for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int h = 0; h < 2; ++h) FSR_TOUCH(mkv[m][h]);
+    }
+    __syncthreads();
+    buf ^= 1;
+  }
+  if (pend_img >= 0) stats_store();
+}
+
+// ---------------------------------------------------------------------------------------------------------------
 // Data gradient of the 64 -> 64 STRIDE-2 convolution (Discriminator block 0, /root/reference/model.py:148-152), all four
 // output-parity classes in one pass.  As four class launches of the generic kernel the layer is latency-bound (K is only
 // 64..256 per class, a workgroup lives for a prologue and an epilogue) at ~2 TB/s.  Here a persistent workgroup keeps
@@ -553,8 +893,15 @@ int fsr_conv64_persistent_try(int dtype, ConvKArgs& a, int S, hipStream_t stream
     (void)hipFuncSetAttribute((const void*)conv64_persistent_kernel<bf16_t, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS64);
     (void)hipFuncSetAttribute((const void*)conv64_persistent_kernel<f16_t, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS64);
     (void)hipFuncSetAttribute((const void*)conv64_persistent_kernel<f16_t, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS64);
+    (void)hipFuncSetAttribute((const void*)conv64_v2_kernel<bf16_t, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS64V2);
+    (void)hipFuncSetAttribute((const void*)conv64_v2_kernel<bf16_t, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS64V2);
+    (void)hipFuncSetAttribute((const void*)conv64_v2_kernel<bf16_t, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS64V2);
+    (void)hipFuncSetAttribute((const void*)conv64_v2_kernel<f16_t, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS64V2);
+    (void)hipFuncSetAttribute((const void*)conv64_v2_kernel<f16_t, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS64V2);
+    (void)hipFuncSetAttribute((const void*)conv64_v2_kernel<f16_t, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS64V2);
     attr_set = true;
   }
+  static const bool first_form = getenv("FSR_CONV64_V1") && atoi(getenv("FSR_CONV64_V1")) != 0;   // A/B switch
   const int cus = persistent_slots();    // one persistent workgroup per CU (LDS admits exactly one)
   const int nblk = thin ? 1 : a.Cout / 64;                   // channel blocks: workgroup w -> block w % nblk
   int slots = thin ? 2 * cus : cus / nblk;                   // tile ranges (the thin kernel's LDS admits two workgroups per CU)
@@ -569,12 +916,18 @@ int fsr_conv64_persistent_try(int dtype, ConvKArgs& a, int S, hipStream_t stream
   const size_t lds_thin = 9 * 16 * P64 * 2 + H_BYTES + 16;
   if (dtype == FSR_F16) {
     if (thin) hipLaunchKernelGGL((conv64_persistent_kernel<f16_t, 1>), dim3(grid), dim3(NTHR64), lds_thin, stream, a);
-    else hipLaunchKernelGGL((conv64_persistent_kernel<f16_t, 4>), dim3(grid), dim3(NTHR64), LDS64, stream, a);
+    else if (first_form) hipLaunchKernelGGL((conv64_persistent_kernel<f16_t, 4>), dim3(grid), dim3(NTHR64), LDS64, stream, a);
+    else if (a.stats) hipLaunchKernelGGL((conv64_v2_kernel<f16_t, true, false>), dim3(grid), dim3(NTHR64), LDS64V2, stream, a);
+    else if (a.dmask) hipLaunchKernelGGL((conv64_v2_kernel<f16_t, false, true>), dim3(grid), dim3(NTHR64), LDS64V2, stream, a);
+    else hipLaunchKernelGGL((conv64_v2_kernel<f16_t, false, false>), dim3(grid), dim3(NTHR64), LDS64V2, stream, a);
   } else {
     if (thin) hipLaunchKernelGGL((conv64_persistent_kernel<bf16_t, 1>), dim3(grid), dim3(NTHR64), lds_thin, stream, a);
-    else hipLaunchKernelGGL((conv64_persistent_kernel<bf16_t, 4>), dim3(grid), dim3(NTHR64), LDS64, stream, a);
+    else if (first_form) hipLaunchKernelGGL((conv64_persistent_kernel<bf16_t, 4>), dim3(grid), dim3(NTHR64), LDS64, stream, a);
+    else if (a.stats) hipLaunchKernelGGL((conv64_v2_kernel<bf16_t, true, false>), dim3(grid), dim3(NTHR64), LDS64V2, stream, a);
+    else if (a.dmask) hipLaunchKernelGGL((conv64_v2_kernel<bf16_t, false, true>), dim3(grid), dim3(NTHR64), LDS64V2, stream, a);
+    else hipLaunchKernelGGL((conv64_v2_kernel<bf16_t, false, false>), dim3(grid), dim3(NTHR64), LDS64V2, stream, a);
   }
-  fsr_note_kernel(thin ? "conv64_persistent_kernel<1>" : "conv64_persistent_kernel<4>");
+  fsr_note_kernel(thin ? "conv64_persistent_kernel<1>" : (first_form ? "conv64_persistent_kernel<4>" : "conv64_v2_kernel"));
   int rc = fsr_check_launch("conv64_persistent_kernel");
   return rc ? rc : 1;
 }

@@ -26,6 +26,8 @@
 #include "fsr_common.h"
 #include "fsr_host.h"
 
+constexpr int WGRAD_GROUP_MAX = 32;
+
 struct WgradKArgs {
   const void* x;
   const void* dy;
@@ -35,6 +37,15 @@ struct WgradKArgs {
   int dy_ps;
   int tiles_x, tiles_y, tiles_total, tiles_per_slab, nslab;
   int nbm, nbn;
+  // grouped launch (group_n > 0): group_n layers of ONE shape share the launch; workgroup b serves layer b / nslab, slab
+  // b % nslab of that layer (nbm = nbn = 1), operands gx[layer] / gdy[layer], partials at ws + layer * nslab * 9 * Cout * Cin
+  int group_n;
+  const void* gx[WGRAD_GROUP_MAX];
+  const void* gdy[WGRAD_GROUP_MAX];
+};
+
+struct WgradGroupOut {
+  float* dw[WGRAD_GROUP_MAX];
 };
 
 template <typename T, int BM, int BN, int S, int TPH>
@@ -58,6 +69,8 @@ __global__ __launch_bounds__((BM == 64 && BN == 64) ? 512 : 256) void conv_wgrad
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int l15 = lane & 15, lg = lane >> 4;
   int bid = (int)blockIdx.x;
+  const int layer = a.group_n > 0 ? bid / a.nslab : 0;
+  if (a.group_n > 0) bid -= layer * a.nslab;
   const int bn = bid % a.nbn;
   bid /= a.nbn;
   const int bm = bid % a.nbm;
@@ -76,8 +89,19 @@ __global__ __launch_bounds__((BM == 64 && BN == 64) ? 512 : 256) void conv_wgrad
 #pragma unroll
     for (int j = 0; j < TPW; ++j) acc[t][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-  const T* xg = (const T*)a.x;
-  const T* dyg = (const T*)a.dy;
+  // (a select chain over constant indices: indexing the by-value tables with `layer` would copy them to scratch)
+  const void* xsel = a.x;
+  const void* dysel = a.dy;
+  if (a.group_n > 0) {
+#pragma unroll
+    for (int l = 0; l < WGRAD_GROUP_MAX; ++l)
+      if (l == layer) {
+        xsel = a.gx[l];
+        dysel = a.gdy[l];
+      }
+  }
+  const T* xg = (const T*)xsel;
+  const T* dyg = (const T*)dysel;
   const int tile0 = slab * a.tiles_per_slab;
   const int tile1 = (tile0 + a.tiles_per_slab < a.tiles_total) ? tile0 + a.tiles_per_slab : a.tiles_total;
 
@@ -218,7 +242,7 @@ __global__ __launch_bounds__((BM == 64 && BN == 64) ? 512 : 256) void conv_wgrad
 #pragma unroll
     for (int j = 0; j < TPW; ++j) {
       const int cot = COPAIR ? co_t + j : co_t, cit = COPAIR ? ci_t0 : ci_t0 + j;
-      float* o = a.ws + (((size_t)slab * 9 + t) * a.CoutPad + bm * BM + cot * 16 + lg * 4) * a.CinPad + bn * BN + cit * 16 + l15;
+      float* o = a.ws + (((size_t)(layer * a.nslab + slab) * 9 + t) * a.CoutPad + bm * BM + cot * 16 + lg * 4) * a.CinPad + bn * BN + cit * 16 + l15;
 #pragma unroll
       for (int r = 0; r < 4; ++r) o[(size_t)r * a.CinPad] = acc[t][j][r];
     }
@@ -319,7 +343,7 @@ int launch_wgrad(const WgradKArgs& a, size_t lds, hipStream_t stream) {
     (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
     attr_set = true;
   }
-  hipLaunchKernelGGL(kern, dim3((unsigned)(a.nslab * a.nbm * a.nbn)), dim3((BM == 64 && BN == 64) ? 512 : 256), lds, stream, a);
+  hipLaunchKernelGGL(kern, dim3((unsigned)(a.nslab * a.nbm * a.nbn * (a.group_n > 0 ? a.group_n : 1))), dim3((BM == 64 && BN == 64) ? 512 : 256), lds, stream, a);
   return fsr_check_launch("conv_wgrad_kernel");
 }
 
@@ -342,6 +366,93 @@ int dispatch_wgrad(const WgradPlan& p, const WgradKArgs& a, hipStream_t stream) 
 
 }  // namespace
 
+// Grouped form of the reduce: blockIdx.y = layer; layer l adds its nslab partial blocks into out.dw[l].
+__global__ __launch_bounds__(256) void conv_wgrad_reduce_grouped_kernel(const float* __restrict__ ws, const WgradGroupOut out, int nslab,
+                                                                        int cout, int cin, int cout_pad, int cin_pad) {
+  __shared__ float red[8][32];
+  const int total = 9 * cout * cin;
+  const size_t sstride = (size_t)9 * cout_pad * cin_pad;
+  const int oi = threadIdx.x & 31, pl = threadIdx.x >> 5;
+  const float* wl = ws + (size_t)blockIdx.y * nslab * sstride;
+  float* dw = out.dw[0];
+#pragma unroll
+  for (int l = 1; l < WGRAD_GROUP_MAX; ++l)
+    if (l == (int)blockIdx.y) dw = out.dw[l];
+  for (int i0 = blockIdx.x * 32; i0 < total; i0 += gridDim.x * 32) {
+    const int i = i0 + oi;
+    float s = 0.f;
+    int co = 0, ci = 0, t = 0;
+    if (i < total) {
+      ci = i % cin;
+      co = (i / cin) % cout;
+      t = i / (cin * cout);
+      const float* p = wl + ((size_t)t * cout_pad + co) * cin_pad + ci;
+      for (int k = pl; k < nslab; k += 8) s += p[(size_t)k * sstride];
+    }
+    red[pl][oi] = s;
+    __syncthreads();
+    if (pl == 0 && i < total) {
+      float r = red[0][oi];
+#pragma unroll
+      for (int j = 1; j < 8; ++j) r += red[j][oi];
+      dw[((size_t)co * cin + ci) * 9 + t] += r;
+    }
+    __syncthreads();
+  }
+}
+
+// slabs per layer of a grouped launch: the layers share the ~256 workgroups of one ungrouped launch
+static int group_slabs(const WgradPlan& p, int nlayers) {
+  int wpl = 256 / nlayers;
+  if (wpl < 1) wpl = 1;
+  if (wpl > p.tiles_total) wpl = p.tiles_total;
+  return wpl;
+}
+
+extern "C" size_t fsr_conv3x3_wgrad_grouped_workspace(const fsr_wgrad_desc* d, int nlayers) {
+  WgradPlan p;
+  if (nlayers < 1 || nlayers > WGRAD_GROUP_MAX || make_plan(d, p) != 0) return 0;
+  return (size_t)nlayers * group_slabs(p, nlayers) * 9 * d->cout_pad * d->cin_pad * sizeof(float);
+}
+
+extern "C" int fsr_conv3x3_wgrad_grouped(const fsr_wgrad_desc* d, int nlayers, const void* const* x, const void* const* dy,
+                                         float* const* dw_oihw, void* workspace, fsr_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  WgradPlan p;
+  if (int rc = make_plan(d, p)) return rc;
+  if (nlayers < 1 || nlayers > WGRAD_GROUP_MAX) return fsr_fail(-2, "fsr_conv3x3_wgrad_grouped: 1..%d layers per launch", WGRAD_GROUP_MAX);
+  if (!x || !dy || !dw_oihw || !workspace) return fsr_fail(-1, "fsr_conv3x3_wgrad_grouped: null argument");
+  if (p.nbm * p.nbn != 1 || d->dy_pixel_shuffled || d->cout != d->cout_pad || d->cin != d->cin_pad)
+    return fsr_fail(-2, "fsr_conv3x3_wgrad_grouped: layers of one 64 x 64 block (cout = cin = 64, unpadded, no pixel shuffle)");
+  WgradKArgs a = {};
+  WgradGroupOut out = {};
+  for (int l = 0; l < nlayers; ++l) {
+    if (!x[l] || !dy[l] || !dw_oihw[l]) return fsr_fail(-1, "fsr_conv3x3_wgrad_grouped: null pointer for layer %d", l);
+    a.gx[l] = x[l];
+    a.gdy[l] = dy[l];
+    out.dw[l] = dw_oihw[l];
+  }
+  a.group_n = nlayers;
+  a.ws = (float*)workspace;
+  a.N = d->n; a.IH = d->ih; a.IW = d->iw; a.CinPad = d->cin_pad;
+  a.OH = d->oh; a.OW = d->ow; a.CoutPad = d->cout_pad;
+  a.dy_ps = 0;
+  a.tiles_x = p.tiles_x; a.tiles_y = p.tiles_y; a.tiles_total = p.tiles_total;
+  a.nslab = group_slabs(p, nlayers);
+  a.tiles_per_slab = (p.tiles_total + a.nslab - 1) / a.nslab;
+  a.nslab = (p.tiles_total + a.tiles_per_slab - 1) / a.tiles_per_slab;
+  a.nbm = a.nbn = 1;
+  const int rc = d->dtype == FSR_BF16 ? dispatch_wgrad<bf16_t, 8>(p, a, stream)
+                 : (d->dtype == FSR_F16 ? dispatch_wgrad<f16_t, 8>(p, a, stream) : dispatch_wgrad<float, 4>(p, a, stream));
+  if (rc) return rc;
+  const int total = 9 * d->cout * d->cin;
+  int blocks = (total + 31) / 32;
+  if (blocks > 2048) blocks = 2048;
+  hipLaunchKernelGGL(conv_wgrad_reduce_grouped_kernel, dim3(blocks, nlayers), dim3(256), 0, stream, (const float*)workspace, out, a.nslab,
+                     d->cout, d->cin, d->cout_pad, d->cin_pad);
+  return fsr_check_launch("conv_wgrad_reduce_grouped_kernel");
+}
+
 extern "C" size_t fsr_conv3x3_wgrad_workspace(const fsr_wgrad_desc* d) {
   WgradPlan p;
   if (make_plan(d, p) != 0) return 0;
@@ -354,7 +465,7 @@ extern "C" int fsr_conv3x3_wgrad(const fsr_wgrad_desc* d, const void* x, const v
   WgradPlan p;
   if (int rc = make_plan(d, p)) return rc;
   if (!x || !dy || !dw_oihw || !workspace) return fsr_fail(-1, "fsr_conv3x3_wgrad: null argument");
-  WgradKArgs a;
+  WgradKArgs a = {};
   a.x = x;
   a.dy = dy;
   a.ws = (float*)workspace;

@@ -55,6 +55,10 @@ __device__ __forceinline__ void fsr_glds16(const void* gsrc, void* lds_wave_base
 #define FSR_GLDS16(g, l) fsr_glds16((g), (l))
 #define FSR_WAIT_DMA() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
 #endif
+// A register "use" with no instruction: pins where the compiler places its s_waitcnt for a load's result.
+#ifndef FSR_TOUCH
+#define FSR_TOUCH(v) asm volatile("" : "+v"(v))
+#endif
 
 // dtype / activation / mode enums come from the public ABI header
 #include "fsr_hip.h"

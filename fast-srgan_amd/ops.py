@@ -204,11 +204,19 @@ def _workspace(nbytes, device):
 # stream, and `wgrad_stream_join()` makes the current stream wait for all of them (before gradients are reduced / used).
 # The tensors a queued launch reads are kept referenced until the join, so the caching allocator cannot hand their
 # memory to later work on the producing stream.
-_wgrad_state = {"stream": None, "active": False, "refs": []}
+#
+# Layers of ONE shape (the generator's 64 -> 64 stem: 17 of them, model.py:62-80) are additionally DEFERRED while the
+# trainer's iteration is open: backward only queues (x, dz, arena) and the join launches the whole group as one
+# fsr_conv3x3_wgrad_grouped call -- the layers share one launch's workgroups (15 slabs each instead of 256), so the
+# split-K partials shrink 17x and 17 reduce launches become one.
+_wgrad_state = {"stream": None, "active": False, "refs": [], "group": False, "pending": {}}
 USE_WGRAD_STREAM = os.environ.get("FSR_WGRAD_STREAM", "1") != "0"
+USE_WGRAD_GROUP = os.environ.get("FSR_WGRAD_GROUP", "1") != "0"
+WGRAD_GROUP_MAX = 32
 
 
 def wgrad_stream_begin(device):
+    _wgrad_state["group"] = USE_WGRAD_GROUP
     if not USE_WGRAD_STREAM or L.is_emulation() or not torch.cuda.is_available():
         return
     if _wgrad_state["stream"] is None:
@@ -216,8 +224,53 @@ def wgrad_stream_begin(device):
     _wgrad_state["active"] = True
 
 
+def _wgrad_defer(cd, xin, dz, cout, cin, cfg, arena):
+    """Queue a weight gradient for the grouped launch; False if this layer is not of the groupable class."""
+    st = _wgrad_state
+    if not st["group"] or cfg.stride != 1 or cfg.pixel_shuffle:
+        return False
+    if not (cout == cin == 64 and xin.shape[3] == 64 and dz.shape[3] == 64):
+        return False
+    st["pending"].setdefault((cd.code, tuple(xin.shape), str(xin.device)), []).append((cd, xin, dz, arena))
+    return True
+
+
+def _wgrad_flush():
+    st = _wgrad_state
+    pending, st["pending"] = st["pending"], {}
+    lib = L.lib()
+    for (_code, shape, _dev), items in pending.items():
+        for i0 in range(0, len(items), WGRAD_GROUP_MAX):
+            grp = items[i0:i0 + WGRAD_GROUP_MAX]
+            cd, x0, dz0, _ = grp[0]
+            if len(grp) == 1:
+                with _on_wgrad_stream(x0, dz0):
+                    conv3x3_wgrad_raw(cd, x0, dz0, 64, 64, 1, out=grp[0][3])
+                continue
+            n, ih, iw, _c = shape
+            d = L.WgradDesc(cd.code, n, ih, iw, 64, 64, ih, iw, 64, 64, 1, 0)
+            need = lib.fsr_conv3x3_wgrad_grouped_workspace(ctypes.byref(d), len(grp))
+            if need == 0:
+                L.check(-2, "fsr_conv3x3_wgrad_grouped_workspace")
+            arr = ctypes.c_void_p * len(grp)
+            xs, dys, dws = arr(*[_p(g[1]) for g in grp]), arr(*[_p(g[2]) for g in grp]), arr(*[_p(g[3]) for g in grp])
+            with _on_wgrad_stream(*[t for g in grp for t in (g[1], g[2])]):
+                prof = PROFILE_CONV
+                if prof is not None:
+                    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    ev0.record()
+                L.check(lib.fsr_conv3x3_wgrad_grouped(ctypes.byref(d), len(grp), xs, dys, dws, _p(_workspace(need, x0.device)),
+                                                      _stream()), "fsr_conv3x3_wgrad_grouped")
+                if prof is not None:
+                    ev1.record()
+                    nbytes = len(grp) * (2 * x0.numel() * x0.element_size() + 64 * 64 * 9 * 4)
+                    prof.append((ev0, ev1, len(grp) * 2.0 * n * ih * iw * 64 * 64 * 9, nbytes, "conv_wgrad_kernel", "wgrad"))
+
+
 def wgrad_stream_join():
     st = _wgrad_state
+    if st["pending"]:
+        _wgrad_flush()
     if st["active"] and st["refs"]:
         torch.cuda.current_stream().wait_stream(st["stream"])
     st["refs"] = []
@@ -226,6 +279,7 @@ def wgrad_stream_join():
 def wgrad_stream_end():
     wgrad_stream_join()
     _wgrad_state["active"] = False
+    _wgrad_state["group"] = False
 
 
 class _on_wgrad_stream:
@@ -531,8 +585,9 @@ class Conv3x3Fn(torch.autograd.Function):
                 return conv3x3_wgrad_raw(cd, xin, dz, cout, cin, cfg.stride, dy_pixel_shuffled=cfg.pixel_shuffle, out=arena)
 
             if arena is not None:   # nothing downstream reads the arena before the optimizer: own stream (see above)
-                with _on_wgrad_stream(xin, dz):
-                    launch_wgrad()
+                if ctx.c3 or not _wgrad_defer(cd, xin, dz, cout, cin, cfg, arena):
+                    with _on_wgrad_stream(xin, dz):
+                        launch_wgrad()
             else:
                 dw = launch_wgrad()
             if arena is not None:

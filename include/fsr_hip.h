@@ -133,6 +133,15 @@ typedef struct fsr_wgrad_desc {
 size_t fsr_conv3x3_wgrad_workspace(const fsr_wgrad_desc* desc);
 int fsr_conv3x3_wgrad(const fsr_wgrad_desc* desc, const void* x, const void* dy, float* dw_oihw, void* workspace,
                       fsr_stream_t stream);
+/* The same weight gradient for `nlayers` (1..32) layers of ONE shape in one launch: layer l reads x[l], dy[l] and
+ * accumulates into dw_oihw[l] (host arrays of device pointers, read during the call only).  For the generator's 64 -> 64
+ * 3x3 blocks (model.py:62-80; 17 identical layers at trainer.py:121-129's backward): cout = cin = 64 unpadded.
+ * The layers share the launch's workgroups, so the split-K partials (workspace:
+ * fsr_conv3x3_wgrad_grouped_workspace(desc, nlayers) bytes) shrink by the group size and one reduce serves all layers.
+ * Summation order is fixed by (shape, nlayers): bit-reproducible, but not bit-equal to nlayers separate calls. */
+size_t fsr_conv3x3_wgrad_grouped_workspace(const fsr_wgrad_desc* desc, int nlayers);
+int fsr_conv3x3_wgrad_grouped(const fsr_wgrad_desc* desc, int nlayers, const void* const* x, const void* const* dy,
+                              float* const* dw_oihw, void* workspace, fsr_stream_t stream);
 
 /* ------------------------------------------------------------------ InstanceNorm2d (+ activation, + residual)
  * torch.nn.InstanceNorm2d defaults (model.py:55,65,94,132: biased variance, eps 1e-5, no affine)

@@ -31,6 +31,7 @@
 #define FSR_WAIT_LOADS() ((void)0)
 #define FSR_GLDS16(g, l) emu::global_load_lds((const void*)(g), (void*)(l), 16, 0)
 #define FSR_WAIT_DMA() ((void)0)
+#define FSR_TOUCH(v) ((void)(v))
 
 struct dim3 {
   unsigned x, y, z;

@@ -75,6 +75,40 @@ def test_conv_fwd_dgrad_wgrad(dev, cdn, stride, cin, cout, ps):
     assert relerr(dw, wr.grad) < tol(cdn, 2e-5, 2e-3)
 
 
+@pytest.mark.parametrize("cdn", ["f32", "bf16", "f16"])
+@pytest.mark.parametrize("nlayers", [1, 3, 17])
+def test_conv_wgrad_grouped(dev, cdn, nlayers):
+    """The deferred grouped weight gradient (ops.wgrad_stream_begin .. join: the generator's 64 -> 64 layers in ONE
+    launch) against torch per layer, accumulating into the arenas, and bit-reproducible."""
+    import types
+    cd = ops.Compute(cdn)
+    torch.manual_seed(9)
+    n, h, w = (4, 40, 56) if _big(dev) else (1, 9, 20)
+    if nlayers == 17 and not _big(dev):
+        h = 5
+    xs = [_q(torch.randn(n, 64, h, w), cd) for _ in range(nlayers)]
+    gs = [_q(torch.randn(n, 64, h, w), cd) for _ in range(nlayers)]
+    cfg = types.SimpleNamespace(stride=1, pixel_shuffle=False)
+
+    def run():
+        arenas = [torch.full((64, 64, 3, 3), 0.5, dtype=torch.float32, device=dev) for _ in range(nlayers)]
+        ops.wgrad_stream_begin(dev)
+        try:
+            for x, g, a in zip(xs, gs, arenas):
+                assert ops._wgrad_defer(cd, _nhwc(x, cd, dev), _nhwc(g, cd, dev), 64, 64, cfg, a)
+            ops.wgrad_stream_join()
+        finally:
+            ops.wgrad_stream_end()
+        return [a.cpu() for a in arenas]
+
+    first, second = run(), run()
+    for x, g, a, b in zip(xs, gs, first, second):
+        wr = leaf(torch.zeros(64, 64, 3, 3))
+        F.conv2d(x, wr, None, 1, 1).backward(g)
+        assert relerr(a - 0.5, wr.grad) < tol(cdn, 2e-5, 2e-3)
+        assert torch.equal(a, b)
+
+
 @pytest.mark.parametrize("mode", [0, 30, 62, 1374, 1406, 34142])
 @pytest.mark.parametrize("cdn", ["f32", "bf16"])
 @pytest.mark.parametrize("stride,cin,cout", [(1, 128, 128), (2, 64, 128), (2, 128, 64), (1, 64, 64), (2, 64, 64)])
