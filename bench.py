@@ -15,7 +15,8 @@ Extra keys of that line:
   roofline      the implicit-GEMM 3x3 convolution family (forward + data-gradient launches): algorithmic FLOPs per launch /
                 average launch duration measured with HIP events on the launch stream during an instrumented step, against
                 the dense MFMA peak; `dominant` repeats that for the single kernel configuration with the largest share
-                of the time; `traffic` = HBM bytes per launch from the rocprofv3 PMC passes recorded in
+                of the time; `kernels` lists every kernel configuration of the family against both the MFMA and the HBM
+                roof (algorithmic bytes); `traffic` = HBM bytes per launch from the rocprofv3 PMC passes recorded in
                 profiles/conv_traffic.json (null when that file does not belong to the kernel sources being run);
   f32_mode      the same iteration in the exact-f32 MFMA parity mode (short run): the precision the reference computes in;
   cpu_baseline  the oracle's CPU restatement of the same iteration, timed on the host cores (N=1, rank 0);
@@ -40,6 +41,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 MFMA_PEAK_TFLOPS = {"bf16": 2500.0, "f16": 2500.0, "f32": 157.3}   # /opt/skills/guides/MI355X_MICROARCH.md, dense
+HBM_PEAK_GBS = 8000.0    # same guide: HBM3E ~8 TB/s
 STEP_GFLOP_PER_IMAGE = 686.71                         # BASELINE.md section 2, as the REFERENCE graph executes it
 TRAFFIC_FILE = os.path.join(ROOT, "profiles", "conv_traffic.json")
 
@@ -270,6 +272,12 @@ def main():
                              "achieved": round(dom_tf, 2), "frac": round(dom_tf / peak, 4),
                              "share_of_conv_time": round(dom[1] / conv_ms, 3) if conv_ms > 0 else None,
                              "algorithmic_bytes_per_launch": round(dom[3] / max(dom[0], 1))},
+                # every kernel configuration of the family against BOTH roofs (algorithmic flops / bytes over its launch time):
+                # the 64-channel persistent kernels sit as close to the HBM roof as to the MFMA roof (profiles/r02_ablation_conv64.txt)
+                "kernels": [{"kernel": k, "launches_per_step": v[0], "ms_per_step": round(v[1], 3),
+                             "tflops": round(v[2] / (v[1] * 1e-3) / 1e12, 1), "mfma_frac": round(v[2] / (v[1] * 1e-3) / 1e12 / peak, 3),
+                             "algorithmic_gb_per_s": round(v[3] / (v[1] * 1e-3) / 1e9, 1), "hbm_frac": round(v[3] / (v[1] * 1e-3) / 1e9 / HBM_PEAK_GBS, 3)}
+                            for k, v in sorted(by_kernel.items(), key=lambda kv: -kv[1][1])[:10] if v[1] > 0],
                 "weight_gradient": {"launches_per_step": len(wgr), "achieved": round(sum(r[1] for r in wgr) / max(sum(r[0] for r in wgr), 1e-9) / 1e9, 2),
                                     "unit": "TFLOP/s", "ms_per_step": round(sum(r[0] for r in wgr), 3)}}
     executed_gflop_per_image = sum(r[1] for r in rec) / B / 1e9

@@ -491,6 +491,50 @@ def test_persistent_conv_statistics_across_tile_ranges(dev, cus, monkeypatch):
         assert relerr(s[..., 1], (ref * ref).sum((2, 3))) < 1e-3
 
 
+@pytest.mark.parametrize("cus", [1, 3, 256])
+@pytest.mark.parametrize("shape", [(1, 5, 7), (3, 16, 16), (2, 17, 33), (4, 8, 40)])
+def test_persistent_conv_variants_on_ragged_shapes(dev, cus, shape, monkeypatch):
+    """Every epilogue of the 64-input-channel persistent kernel (plain + bias + activation, pre-activation copy, fused
+    PixelShuffle, fused max-pool, InstanceNorm statistics, fused activation-gradient mask) on images smaller than / not a
+    multiple of the 16x16 tile, with one, a few and more tile ranges than tiles (deferred epilogue of the last tile, statistics
+    flushes in consecutive tiles, empty workgroups)."""
+    monkeypatch.setenv("FSR_PERSIST_CUS", str(cus))
+    cd = ops.Compute("bf16")
+    torch.manual_seed(21)
+    n, h, w = shape
+    x = _q(torch.randn(n, 64, h, w), cd)
+    xd = _nhwc(x, cd, dev)
+    for cout in (64, 128):
+        wt = _q(torch.randn(cout, 64, 3, 3) * 0.1, cd)
+        bias = torch.randn(cout) * 0.1
+        wpk = ops.packed_filter(cd, wt.to(dev), L.PACK_FWD, 64)
+        ref = F.conv2d(x, wt, bias, 1, 1)
+        # plain + LeakyReLU + pre-activation copy
+        y, pre, _ = ops.conv3x3_raw(cd, xd, wpk, cout, bias=bias.to(dev), act=L.ACT_LEAKY, slope=0.2, want_preact=True)
+        assert ops._last_kernel().startswith("conv64")
+        assert relerr(_nchw(pre), ref) < 1e-2 and relerr(_nchw(y), F.leaky_relu(ref, 0.2)) < 1e-2
+        # statistics
+        y, _, stats = ops.conv3x3_raw(cd, xd, wpk, cout, bias=bias.to(dev), want_stats=True)
+        assert relerr(_nchw(y), ref) < 1e-2
+        assert relerr(stats.cpu()[..., 0], ref.sum((2, 3))) < 2e-3 and relerr(stats.cpu()[..., 1], (ref * ref).sum((2, 3))) < 2e-3
+        # fused activation-gradient mask (data-gradient form: the mask is the layer's input activation)
+        mask = _q(torch.randn(n, cout, h, w), cd)
+        y, _, _ = ops.conv3x3_raw(cd, xd, wpk, cout, dact_mask=_nhwc(mask, cd, dev), dact_slope=0.2)
+        want = F.conv2d(x, wt, None, 1, 1) * torch.where(mask > 0, torch.ones(()), torch.tensor(0.2))
+        assert relerr(_nchw(y), want) < 1e-2
+        # fused max-pool (even sizes only)
+        if h % 2 == 0 and w % 2 == 0:
+            y, _, _ = ops.conv3x3_raw(cd, xd, wpk, cout, bias=bias.to(dev), act=L.ACT_RELU, pool2=True)
+            assert relerr(_nchw(y), F.max_pool2d(F.relu(ref), 2)) < 1e-2
+    # fused PixelShuffle + PReLU (64 -> 256)
+    wt = _q(torch.randn(256, 64, 3, 3) * 0.1, cd)
+    bias = torch.randn(256) * 0.1
+    wpk = ops.packed_filter(cd, wt.to(dev), L.PACK_FWD_PS, 64)
+    y, _, _ = ops.conv3x3_raw(cd, xd, wpk, 256, bias=bias.to(dev), pixel_shuffle=True, act=L.ACT_PRELU, prelu=torch.tensor([0.25]).to(dev))
+    want = F.prelu(F.pixel_shuffle(F.conv2d(x, wt, bias, 1, 1), 2), torch.tensor([0.25]))
+    assert relerr(_nchw(y), want) < 1e-2
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("cdn", ["f32", "bf16"])
 def test_reductions_are_bit_reproducible(cdn):
