@@ -17,7 +17,7 @@ ACT_NONE, ACT_RELU, ACT_LEAKY, ACT_PRELU, ACT_TANH = 0, 1, 2, 3, 4
 CONV_FWD, CONV_DGRAD = 0, 1
 PACK_FWD, PACK_FWD_PS, PACK_DGRAD, PACK_DGRAD_PS = 0, 1, 2, 3
 OUT_DTYPE, OUT_F32, OUT_U8 = 0, 1, 2
-ABI_VERSION = 6
+ABI_VERSION = 7
 
 c_int, c_float, c_void_p, c_size_t, c_ll = ctypes.c_int, ctypes.c_float, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_longlong
 

@@ -38,7 +38,7 @@
 extern "C" {
 #endif
 
-#define FSR_ABI_VERSION 6
+#define FSR_ABI_VERSION 7
 
 enum { FSR_F32 = 0, FSR_BF16 = 1, FSR_F16 = 2 };
 enum { FSR_ACT_NONE = 0, FSR_ACT_RELU = 1, FSR_ACT_LEAKY = 2, FSR_ACT_PRELU = 3, FSR_ACT_TANH = 4 };
