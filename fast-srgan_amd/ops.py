@@ -277,6 +277,9 @@ def wgrad_stream_join():
 
 
 def wgrad_stream_end():
+    # an iteration that ran to its optimizer steps has joined (and flushed) already; what is still queued here belongs to an
+    # iteration that raised: drop it instead of launching on its tensors
+    _wgrad_state["pending"] = {}
     wgrad_stream_join()
     _wgrad_state["active"] = False
     _wgrad_state["group"] = False
