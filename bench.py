@@ -12,12 +12,13 @@ one process per GPU, two RCCL gradient all-reduces per step; `python bench.py --
 re-executes itself under torch.distributed.run.  Rank 0 prints ONE JSON line.
 
 Extra keys of that line:
-  roofline      the implicit-GEMM 3x3 convolution family (forward + data-gradient launches): algorithmic FLOPs per launch /
-                average launch duration measured with HIP events on the launch stream during an instrumented step, against
-                the dense MFMA peak; `dominant` repeats that for the single kernel configuration with the largest share
-                of the time; `kernels` lists every kernel configuration of the family against both the MFMA and the HBM
-                roof (algorithmic bytes); `traffic` = HBM bytes per launch from the rocprofv3 PMC passes recorded in
-                profiles/conv_traffic.json (null when that file does not belong to the kernel sources being run);
+  roofline      the DOMINANT kernel of the iteration (the kernel symbol with the largest share of its time: the tall implicit-GEMM
+                3x3 convolution configuration): algorithmic FLOPs per launch / its average launch duration, measured with HIP events
+                on the launch stream during an instrumented single-stream step, against the dense MFMA peak; `traffic` = HBM bytes
+                per launch of that kernel from the rocprofv3 PMC passes recorded in profiles/conv_traffic.json (null when that
+                file does not belong to the kernel sources being run); `lds_fed_mfma_ceiling` = the same rate against what a bare
+                LDS-fed MFMA loop of this wave tile reaches (micro-benchmark); `family` repeats the figures for ALL conv forward +
+                data-gradient launches together; `kernels` lists every kernel configuration against both the MFMA and the HBM roof;
   f32_mode      the same iteration in the exact-f32 MFMA parity mode (short run): the precision the reference computes in;
   cpu_baseline  the oracle's CPU restatement of the same iteration, timed on the host cores (N=1, rank 0);
   inference     generator-only FPS at 90x160 and 180x320 (BASELINE.json configs[1]), batch 1 and batch 32, plus the
@@ -42,6 +43,7 @@ sys.path.insert(0, ROOT)
 
 MFMA_PEAK_TFLOPS = {"bf16": 2500.0, "f16": 2500.0, "f32": 157.3}   # /opt/skills/guides/MI355X_MICROARCH.md, dense
 HBM_PEAK_GBS = 8000.0    # same guide: HBM3E ~8 TB/s
+LDS_FED_CEILING_TFLOPS = {"bf16": 1940.0, "f16": 1940.0}   # measured: profiles/r02_ubench_lds_mfma.txt (8+4 reads per 32 MFMAs)
 STEP_GFLOP_PER_IMAGE = 686.71                         # BASELINE.md section 2, as the REFERENCE graph executes it
 TRAFFIC_FILE = os.path.join(ROOT, "profiles", "conv_traffic.json")
 
@@ -249,31 +251,41 @@ def main():
         e[3] += by
     dom_name, dom = max(by_kernel.items(), key=lambda kv: kv[1][1]) if by_kernel else ("?", [0, 1.0, 0.0, 0.0])
     dom_tf = dom[2] / (dom[1] * 1e-3) / 1e12 if dom[1] > 0 else 0.0
-    traffic, traffic_src = None, "no PMC record for these kernel sources (profiles/conv_traffic.json)"
+    # HBM traffic from the PMC passes recorded for exactly these kernel sources (tools/pmc_traffic.py): the dominant kernel's own
+    # dispatches, and the whole family
+    traffic = fam_traffic = None
+    traffic_src = "no PMC record for these kernel sources (profiles/conv_traffic.json)"
     if os.path.exists(TRAFFIC_FILE):
         try:
             t = json.load(open(TRAFFIC_FILE))
             if t.get("kernel_sources_sha16") == kernel_sources_hash() and t.get("dtype") == args.dtype and t.get("batch") == B:
-                traffic = t["bytes_per_launch"]
+                fam_traffic = t["bytes_per_launch"]
+                traffic = t.get("per_kernel", {}).get(dom_name, {}).get("bytes_per_dispatch")
                 traffic_src = ("rocprofv3 --pmc FETCH_SIZE (x2, gfx950 correction) + WRITE_SIZE over one iteration (%s), "
                                "recorded in profiles/conv_traffic.json for kernel sources %s" % (t.get("files", "?"), t["kernel_sources_sha16"]))
             else:
                 traffic_src = "profiles/conv_traffic.json was recorded for other kernel sources / another workload: not quoted"
         except (OSError, ValueError, KeyError):
             pass
-    roofline = {"bound": "mfma", "kernel": "3x3 convolution forward + data-gradient launches (conv_igemm_kernel / conv64_persistent_kernel family)",
-                "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(achieved / peak, 4),
+    # `roofline` = the DOMINANT kernel (the single kernel symbol with the largest share of the iteration); `family` = all conv
+    # forward + data-gradient launches together; `kernels` = every configuration of the family against both roofs
+    roofline = {"bound": "mfma", "kernel": dom_name,
+                "achieved": round(dom_tf, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(dom_tf / peak, 4),
                 "traffic": traffic, "traffic_source": traffic_src,
-                "algorithmic_bytes_per_launch": round(conv_bytes / max(launches, 1)), "launches_per_step": launches,
-                "avg_launch_us": round(conv_ms * 1e3 / max(launches, 1), 2),
-                "algorithmic_gflop_per_launch": round(conv_flops / max(launches, 1) / 1e9, 3),
-                "share_of_step_time": round(conv_ms / ms_per_step, 3),
-                "dominant": {"kernel": dom_name, "launches_per_step": dom[0], "avg_launch_us": round(dom[1] * 1e3 / max(dom[0], 1), 2),
-                             "achieved": round(dom_tf, 2), "frac": round(dom_tf / peak, 4),
-                             "share_of_conv_time": round(dom[1] / conv_ms, 3) if conv_ms > 0 else None,
-                             "algorithmic_bytes_per_launch": round(dom[3] / max(dom[0], 1))},
-                # every kernel configuration of the family against BOTH roofs (algorithmic flops / bytes over its launch time):
-                # the 64-channel persistent kernels sit as close to the HBM roof as to the MFMA roof (profiles/r02_ablation_conv64.txt)
+                "algorithmic_bytes_per_launch": round(dom[3] / max(dom[0], 1)), "launches_per_step": dom[0],
+                "avg_launch_us": round(dom[1] * 1e3 / max(dom[0], 1), 2),
+                "algorithmic_gflop_per_launch": round(dom[2] / max(dom[0], 1) / 1e9, 3),
+                "share_of_step_time": round(dom[1] / ms_per_step, 3),
+                # what a loop whose operands pass through LDS reaches with this kernel's wave tile (64 px x 128 channels, two
+                # waves per SIMD): tools/ubench/lds_mfma.hip, profiles/r02_ubench_lds_mfma.txt
+                "lds_fed_mfma_ceiling": {"tflops": LDS_FED_CEILING_TFLOPS.get(args.dtype), "frac": (round(dom_tf / LDS_FED_CEILING_TFLOPS[args.dtype], 4)
+                                                                                                if args.dtype in LDS_FED_CEILING_TFLOPS else None)},
+                "family": {"kernel": "3x3 convolution forward + data-gradient launches (conv_igemm_kernel / conv64 persistent kernels / first-layer kernels)",
+                           "achieved": round(achieved, 2), "frac": round(achieved / peak, 4), "traffic": fam_traffic,
+                           "algorithmic_bytes_per_launch": round(conv_bytes / max(launches, 1)), "launches_per_step": launches,
+                           "avg_launch_us": round(conv_ms * 1e3 / max(launches, 1), 2),
+                           "algorithmic_gflop_per_launch": round(conv_flops / max(launches, 1) / 1e9, 3),
+                           "share_of_step_time": round(conv_ms / ms_per_step, 3)},
                 "kernels": [{"kernel": k, "launches_per_step": v[0], "ms_per_step": round(v[1], 3),
                              "tflops": round(v[2] / (v[1] * 1e-3) / 1e12, 1), "mfma_frac": round(v[2] / (v[1] * 1e-3) / 1e12 / peak, 3),
                              "algorithmic_gb_per_s": round(v[3] / (v[1] * 1e-3) / 1e9, 1), "hbm_frac": round(v[3] / (v[1] * 1e-3) / 1e9 / HBM_PEAK_GBS, 3)}

@@ -13,7 +13,7 @@ import sys
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
-KERNELS = ("conv_igemm_kernel", "conv64_persistent_kernel", "conv64_s2dgrad_kernel", "conv_c3_fwd_kernel")
+KERNELS = ("conv_igemm_kernel", "conv64_persistent_kernel", "conv64_v2_kernel", "conv64_s2dgrad_kernel", "conv_c3_fwd_kernel")
 
 
 def total_kb(path, counter):
@@ -23,6 +23,22 @@ def total_kb(path, counter):
             tot += float(r["Counter_Value"])
             n += 1
     return tot, n
+
+
+def norm(name):
+    """rocprofv3's demangled kernel name -> the spelling bench.py / fsr_last_kernel use."""
+    n = name.replace("void ", "").replace("(anonymous namespace)::", "").split("(")[0]
+    return n.replace("unsigned short", "bf16").replace("_Float16", "f16").replace("float", "f32").replace(" ", "")
+
+
+def per_kernel_kb(path, counter):
+    out = {}
+    for r in csv.DictReader(open(path)):
+        if r["Counter_Name"] == counter and any(k in r["Kernel_Name"] for k in KERNELS):
+            e = out.setdefault(norm(r["Kernel_Name"]), [0.0, 0])
+            e[0] += float(r["Counter_Value"])
+            e[1] += 1
+    return out
 
 
 fetch, n1 = total_kb(sys.argv[1], "FETCH_SIZE")
@@ -41,5 +57,9 @@ if len(sys.argv) > 5 and api:
            "formula": "2 x FETCH_SIZE (gfx950 counts 64 B per 128-B request) + WRITE_SIZE, conv forward + data-gradient kernels",
            "dtype": "bf16", "batch": 32, "kernel_sources_sha16": bench.kernel_sources_hash(),
            "files": "%s, %s" % (os.path.basename(sys.argv[1]), os.path.basename(sys.argv[2]))}
+    fk, wk = per_kernel_kb(sys.argv[1], "FETCH_SIZE"), per_kernel_kb(sys.argv[2], "WRITE_SIZE")
+    rec["per_kernel"] = {k: {"dispatches_per_iteration": fk[k][1] / iters,
+                             "bytes_per_dispatch": round((2 * fk[k][0] / fk[k][1] + wk[k][0] / wk[k][1]) * 1024)}
+                         for k in sorted(fk) if k in wk and fk[k][1] and wk[k][1]}
     json.dump(rec, open(sys.argv[5], "w"), indent=1)
     print("wrote", sys.argv[5], rec)
