@@ -343,7 +343,13 @@ def conv3x3_raw(cd, x, wpk, cout, *, mode=L.CONV_FWD, out_hw=None, stride=1, bia
         ev1.record()
         k = cin if alg_k is None else alg_k
         pix = oh * ow if mode == L.CONV_FWD else ih * iw      # dgrad: one MAC per forward MAC
+        # every tensor the launch has to read or write once: input, output, filter, and the fused extras (activation-gradient
+        # mask read, pre-activation copy written)
         nbytes = x.numel() * x.element_size() + out.numel() * out.element_size() + wpk.numel() * wpk.element_size()
+        if dact_mask is not None:
+            nbytes += dact_mask.numel() * dact_mask.element_size()
+        if pre is not None:
+            nbytes += pre.numel() * pre.element_size()
         prof.append((ev0, ev1, 2.0 * n * pix * cout * k * 9, nbytes, _last_kernel(), "fwd" if mode == L.CONV_FWD else "dgrad"))
     return out, pre, stats
 
