@@ -10,8 +10,8 @@
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
-template <int NA, int NB>   // NA + NB reads, NA * NB MFMAs per step
-__global__ __launch_bounds__(512) void k(float* out, int iters) {
+template <int NA, int NB, int BOUND = 512>   // NA + NB reads, NA * NB MFMAs per step
+__global__ __launch_bounds__(BOUND) void k(float* out, int iters) {
   extern __shared__ char smem[];
   for (int i = threadIdx.x; i < 100 * 1024 / 4; i += blockDim.x) ((float*)smem)[i] = (float)(i & 255) * 0.001f;
   __syncthreads();
@@ -124,6 +124,14 @@ int main() {
   CASE(8, 4, 256)
   CASE(8, 4, 512)
   CASE(2, 2, 512)
+  {   // 8 x 8 tile: 256 accumulator registers, one wave per SIMD (512-register budget)
+    (void)hipFuncSetAttribute((const void*)k<8, 8, 256>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    run("8+8 reads, 64 MFMAs per step, 4 waves/WG (1 per SIMD)", [&] { hipLaunchKernelGGL((k<8, 8, 256>), dim3(grid), dim3(256), lds, 0, out, iters); },
+        (double)grid * 4 * iters * 64 * 16384.0);
+    (void)hipFuncSetAttribute((const void*)k<8, 6, 256>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    run("8+6 reads, 48 MFMAs per step, 4 waves/WG (1 per SIMD)", [&] { hipLaunchKernelGGL((k<8, 6, 256>), dim3(grid), dim3(256), lds, 0, out, iters); },
+        (double)grid * 4 * iters * 48 * 16384.0);
+  }
 #define CASE32(NA, NB, THREADS)                                                                                 \
   {                                                                                                              \
     (void)hipFuncSetAttribute((const void*)k32<NA, NB>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);     \
