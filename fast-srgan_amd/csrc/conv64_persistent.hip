@@ -55,7 +55,7 @@ __global__ __launch_bounds__(NTHR64, 2) void conv64_persistent_kernel(const Conv
   T* halo = (T*)(smem + WB);
   float* sred = (float*)(smem + WB + H_BYTES);          // [8 waves][64][2] statistics of the tiles walked so far in this image
 
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int l15 = lane & 15, lg = lane >> 4;
   const T* in = (const T*)a.in;
   const int tiles_per_img = a.tiles_x * a.tiles_y;
@@ -352,7 +352,7 @@ __global__ __launch_bounds__(NTHR64) void conv64_v2_kernel(const ConvKArgs a) {
   T* halo0 = (T*)(smem + W2_BYTES);
   float* sred = (float*)(smem + W2_BYTES + 2 * H2_BYTES);
 
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int l15 = lane & 15, lg = lane >> 4;
   const int l8 = lane >> 3, s8 = lane & 7;
   const T* in = (const T*)a.in;
@@ -673,7 +673,7 @@ __global__ __launch_bounds__(NTHR64, 2) void conv64_s2dgrad_kernel(const ConvKAr
   T* wl = (T*)smem;
   T* halo = (T*)(smem + W_BYTES);
 
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int l15 = lane & 15, lg = lane >> 4;
   const T* in = (const T*)a.in;
   const int tiles_per_img = a.tiles_x * a.tiles_y;

@@ -88,7 +88,7 @@ template <typename T>
 __global__ __launch_bounds__(256) void conv_c3_fwd_kernel(const C3Args a) {
   constexpr int TH = 16;
   __shared__ float patch[(TH + 2) * PW * 3];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int l15 = lane & 15, lg = lane >> 4;
   int bid = blockIdx.x;
   const int tx = bid % a.tiles_x;
@@ -243,7 +243,7 @@ __global__ __launch_bounds__(256) void conv_c3_wgrad_kernel(const C3Args a) {
   constexpr int PA = 64 + 16;                     // dz tile pitch (elements): [128 px][64 co]
   __shared__ float patch[(TH + 2) * PW * 3];
   __shared__ __attribute__((aligned(16))) T dzt[TH * 16 * PA];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int l15 = lane & 15, lg = lane >> 4;
   const int slab = blockIdx.x, nb = blockIdx.y;
   const int cvalid = a.cout - nb * 64;            // channels of this block that exist (multiple of 16)

@@ -101,7 +101,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv_igemm_kernel(const ConvK
   constexpr int HH = (TH - 1) * S + 3, HW = 15 * S + 3;  // halo extent for the full 3x3 footprint (fewer taps use less)
   T* wl = halo + HH * HW * PITCHX;
 
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform: addresses derived from it stay scalar
   const int wm = wave / WN, wn = wave % WN;
   const int l15 = lane & 15, lg = lane >> 4;
 

@@ -66,7 +66,7 @@ __global__ __launch_bounds__((BM == 64 && BN == 64) ? 512 : 256) void conv_wgrad
   T* dyt = (T*)smem;              // [TPIX][PA]
   T* halo = dyt + TPIX * PA;      // [HH*HW][PB]
 
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int l15 = lane & 15, lg = lane >> 4;
   int bid = (int)blockIdx.x;
   const int layer = a.group_n > 0 ? bid / a.nslab : 0;
