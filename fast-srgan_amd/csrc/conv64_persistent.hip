@@ -361,6 +361,7 @@ __global__ __launch_bounds__(NTHR64) void conv64_v2_kernel(const ConvKArgs a) {
   const int nblk = a.CoutPad >> 6;
   const int nb = (int)blockIdx.x % nblk;
   const T* zero = (const T*)conv64_zero_page;
+  const fsr_lds_addr_t lds_addr = FSR_LDS_ADDR(smem);      // LDS byte address of the filter; halos follow at W2_BYTES
 
   // ---- filter block nb, all nine taps: LDS row r = slice * 64 + row; 72 wave instructions of 8 rows
   {
@@ -371,7 +372,7 @@ __global__ __launch_bounds__(NTHR64) void conv64_v2_kernel(const ConvKArgs a) {
       const int r = k * 8 + l8;
       const int slice = r >> 6, j = r & 63;
       const int row = ((j & 12) << 2) + ((j >> 4) << 2) + (j & 3);   // MFMA row i of tile n <- channel (i >> 2) * 16 + n * 4 + (i & 3)
-      FSR_GLDS16(wpk + ((size_t)slice * a.CoutPad * 64 + (size_t)(row * 64 + ((s8 ^ (r & 7)) * 8))), wl + k * 8 * 64);
+      FSR_GLDS16_AT(wpk + ((size_t)slice * a.CoutPad * 64 + (size_t)(row * 64 + ((s8 ^ (r & 7)) * 8))), lds_addr + (fsr_lds_addr_t)(k * 8 * 64) * sizeof(T));
     }
   }
   // halo of `tile` -> buffer `buf`: wave instruction k fills pixels 8k .. 8k+7 (this wave: k = wid, wid + nw, ...)
@@ -380,14 +381,14 @@ __global__ __launch_bounds__(NTHR64) void conv64_v2_kernel(const ConvKArgs a) {
     const int rem = tile - img * tiles_per_img;
     const int ty = rem / a.tiles_x, tx = rem - ty * a.tiles_x;
     const int iy0 = ty * 16 + a.org_y, ix0 = tx * 16 + a.org_x;
-    T* hb = halo0 + buf * (HPIX2 * 64);
+    const fsr_lds_addr_t hb = lds_addr + W2_BYTES + (fsr_lds_addr_t)buf * H2_BYTES;
     for (int k = wid; k < NDMA2; k += nw) {
       const int p = k * 8 + l8;
       const int hy = p / HT, hx = p - hy * HT;
       const int iy = iy0 + hy, ix = ix0 + hx;
       const bool ok = p < HT * HT && iy >= 0 && iy < a.IH && ix >= 0 && ix < a.IW;
       const T* src = ok ? in + ((unsigned)((img * a.IH + iy) * a.IW + ix) * 64u + (unsigned)((s8 ^ (p & 7)) * 8)) : zero + s8 * 8;
-      FSR_GLDS16(src, hb + k * 8 * 64);
+      FSR_GLDS16_AT(src, hb + (fsr_lds_addr_t)(k * 8 * 64) * sizeof(T));
     }
   };
 

@@ -339,21 +339,27 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv_igemm_kernel(const ConvK
     const int rib = lane / UNITS, up = lane % UNITS;       // this lane's row inside a block / LDS unit
     const int spc = (a.ntaps + G - 1) / G;
     const int nstages = nchunks * spc;
+    // source = wave-uniform slice base (SGPRs) + this lane's byte offset (loop invariant); destination = LDS byte address
+    // (one address-space cast here, integer offsets in the loop): a piece costs a few scalar instructions
+    constexpr int NPIECE = (NBLK + NWV - 1) / NWV;
+    const fsr_lds_addr_t wl_addr = FSR_LDS_ADDR(wl);
+    unsigned voff[NPIECE];
+#pragma unroll
+    for (int i = 0; i < NPIECE; ++i) {
+      const int row = (wave + i * NWV) * ROWS + rib;
+      voff[i] = (unsigned)(row * a.Cin + ((up ^ swz(row & 15)) * EPB)) * (unsigned)sizeof(T);
+    }
     auto dma_stage = [&](int c, int g, int buf) {
       static_for<0, G>([&](auto jc) {
         constexpr int j = decltype(jc)::value;
         const int t = g * G + j;
         if (EXACT || t < a.ntaps) {
           const T* src = wnb + ((tap_code(a, t) >> 4) * slice_stride + (unsigned)(c * KC));
-          T* dst = wl + (size_t)((buf * G + j) * BN) * KC;
+          const fsr_lds_addr_t dst = wl_addr + (fsr_lds_addr_t)((buf * G + j) * BN * KC) * sizeof(T);
 #pragma unroll
-          for (int i = 0; i < (NBLK + NWV - 1) / NWV; ++i) {
+          for (int i = 0; i < NPIECE; ++i) {
             const int blk = wave + i * NWV;
-            if (NBLK % NWV == 0 || blk < NBLK) {
-              const int row = blk * ROWS + rib;
-              const T* g16 = src + (unsigned)(row * a.Cin + ((up ^ swz(row & 15)) * EPB));
-              FSR_GLDS16(g16, dst + blk * ROWS * KC);
-            }
+            if (NBLK % NWV == 0 || blk < NBLK) FSR_GLDS16_SAT(src, voff[i], dst + (fsr_lds_addr_t)(blk * ROWS * KC) * sizeof(T));
           }
         }
       });

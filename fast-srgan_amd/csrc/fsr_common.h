@@ -55,6 +55,24 @@ __device__ __forceinline__ void fsr_glds16(const void* gsrc, void* lds_wave_base
 #define FSR_GLDS16(g, l) fsr_glds16((g), (l))
 #define FSR_WAIT_DMA() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
 #endif
+// The same piece addressed the way the hardware wants it: destination = a 32-bit LDS byte address (FSR_LDS_ADDR of a shared
+// pointer, taken ONCE per kernel, plus integer offsets -- every generic-pointer -> LDS cast in a loop costs a null check and
+// 64-bit scalar adds), source = a wave-uniform 64-bit base in SGPRs + a 32-bit per-lane byte offset (no vector 64-bit add).
+// M0 is declared clobbered instead of saved and restored.
+#ifndef FSR_GLDS16_AT
+typedef unsigned fsr_lds_addr_t;
+#define FSR_LDS_ADDR(p) ((unsigned)(size_t)FSR_LDS_PTR(char, (p)))
+__device__ __forceinline__ void fsr_glds16_at(const void* gsrc, unsigned lds_addr) {
+  const unsigned dst = __builtin_amdgcn_readfirstlane(lds_addr);
+  asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(gsrc), "s"(dst) : "memory", "m0");
+}
+__device__ __forceinline__ void fsr_glds16_sat(const void* sbase, unsigned voff, unsigned lds_addr) {
+  const unsigned dst = __builtin_amdgcn_readfirstlane(lds_addr);
+  asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %0" ::"s"(sbase), "v"(voff), "s"(dst) : "memory", "m0");
+}
+#define FSR_GLDS16_AT(g, a) fsr_glds16_at((g), (a))
+#define FSR_GLDS16_SAT(sb, vo, a) fsr_glds16_sat((sb), (vo), (a))
+#endif
 // A register "use" with no instruction: pins where the compiler places its s_waitcnt for a load's result.
 #ifndef FSR_TOUCH
 #define FSR_TOUCH(v) asm volatile("" : "+v"(v))

@@ -31,6 +31,10 @@
 #define FSR_WAIT_LOADS() ((void)0)
 #define FSR_GLDS16(g, l) emu::global_load_lds((const void*)(g), (void*)(l), 16, 0)
 #define FSR_WAIT_DMA() ((void)0)
+typedef uintptr_t fsr_lds_addr_t;
+#define FSR_LDS_ADDR(p) ((uintptr_t)(p))
+#define FSR_GLDS16_AT(g, a) emu::global_load_lds((const void*)(g), (void*)(a), 16, 0)
+#define FSR_GLDS16_SAT(sb, vo, a) emu::global_load_lds((const void*)((const char*)(sb) + (vo)), (void*)(a), 16, 0)
 #define FSR_TOUCH(v) ((void)(v))
 
 struct dim3 {
