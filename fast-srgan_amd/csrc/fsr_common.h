@@ -37,25 +37,16 @@ typedef __bf16 bf16x8_hw __attribute__((ext_vector_type(8)));
 #ifndef FSR_GLOBAL_PTR
 #define FSR_GLOBAL_PTR(T, p) ((__attribute__((address_space(1))) T*)(p))
 #endif
-// One LDS-DMA piece: every lane copies 16 bytes from ITS global address to `lds_wave_base` + 16 * lane (global_load_lds_dwordx4).
+// One LDS-DMA piece: every lane copies 16 bytes from ITS global address to (LDS address) + 16 * lane (global_load_lds_dwordx4).
 // Issued from inline asm ON PURPOSE.  hipcc's waitcnt pass treats the builtin as a FLAT operation that touches two address
 // spaces ("pending flat"): while one is in flight on vmcnt -- by design the whole stage -- every s_waitcnt lgkmcnt it emits is
 // forced to 0, so software-pipelined ds_read -> MFMA sequences collapse into {reads, wait for ALL of them, MFMAs}.  Hidden in
 // asm, the DMA is invisible to that pass: the fragment reads get counted lgkmcnt(N) waits, and the kernel waits for its DMA
-// pieces itself (FSR_WAIT_DMA before the barrier that publishes the buffer).  M0 carries the LDS base and is restored.
-#ifndef FSR_GLDS16
-__device__ __forceinline__ void fsr_glds16(const void* gsrc, void* lds_wave_base) {
-  unsigned keep;
-  const unsigned dst = __builtin_amdgcn_readfirstlane((unsigned)(size_t)FSR_LDS_PTR(void, lds_wave_base));
-  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
-               : "=&s"(keep)
-               : "v"(gsrc), "s"(dst)
-               : "memory");
-}
-#define FSR_GLDS16(g, l) fsr_glds16((g), (l))
+// pieces itself (FSR_WAIT_DMA before the barrier that publishes the buffer).
+#ifndef FSR_WAIT_DMA
 #define FSR_WAIT_DMA() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
 #endif
-// The same piece addressed the way the hardware wants it: destination = a 32-bit LDS byte address (FSR_LDS_ADDR of a shared
+// The piece is addressed the way the hardware wants it: destination = a 32-bit LDS byte address (FSR_LDS_ADDR of a shared
 // pointer, taken ONCE per kernel, plus integer offsets -- every generic-pointer -> LDS cast in a loop costs a null check and
 // 64-bit scalar adds), source = a wave-uniform 64-bit base in SGPRs + a 32-bit per-lane byte offset (no vector 64-bit add).
 // M0 is declared clobbered instead of saved and restored.

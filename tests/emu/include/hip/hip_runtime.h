@@ -29,7 +29,6 @@
 #define FSR_LDS_PTR(T, p) ((T*)(p))
 #define FSR_GLOBAL_PTR(T, p) ((T*)(p))
 #define FSR_WAIT_LOADS() ((void)0)
-#define FSR_GLDS16(g, l) emu::global_load_lds((const void*)(g), (void*)(l), 16, 0)
 #define FSR_WAIT_DMA() ((void)0)
 typedef uintptr_t fsr_lds_addr_t;
 #define FSR_LDS_ADDR(p) ((uintptr_t)(p))
