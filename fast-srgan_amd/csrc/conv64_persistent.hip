@@ -659,6 +659,194 @@ __global__ __launch_bounds__(NTHR64) void conv64_v2_kernel(const ConvKArgs a) {
 }
 
 // ---------------------------------------------------------------------------------------------------------------
+// FORWARD of the 64 -> 64 STRIDE-2 convolution (Discriminator block 0, /root/reference/model.py:148-152: 384^2 -> 192^2, the
+// largest activation of the network).  In the generic kernel a workgroup lives for two 36 KB halo chunks and 144 MFMAs per wave:
+// 9216 workgroups of ~17 us each move 755 MB in 308 us (2.45 TB/s) -- the layer is HBM-bound (87 GFLOP are 35 us of MFMA) and
+// latency-bound per workgroup.  Here a persistent workgroup keeps the whole filter in LDS (as conv64_v2_kernel) and streams
+// 8 x 16-pixel output tiles: the 17 x 33-pixel input halo arrives by LDS-DMA in two 32-channel chunks (64-byte pixels, unit
+// swizzled by (pixel >> 2) & 3: the stride-2 fragment read is then 2-way conflicted, the minimum for 64-byte pixels), each
+// chunk in its own buffer, the DMA of the next half step always in flight under the MFMAs and the epilogue of the current one.
+// Wave w = output row w of the tile (16 pixels x 64 channels); epilogue and statistics as in conv64_v2_kernel.
+constexpr int S2F_HH = 17, S2F_HW = 33;
+constexpr int S2F_NDMA = (S2F_HH * S2F_HW + 15) / 16;          // wave instructions per chunk (16 pixels of 64 bytes each)
+constexpr int S2F_CHUNK_BYTES = S2F_NDMA * 1024;
+constexpr int LDS64S2F = W2_BYTES + 2 * S2F_CHUNK_BYTES + SRED_BYTES;
+
+template <typename T, bool STATS>
+__global__ __launch_bounds__(NTHR64) void conv64_s2fwd_kernel(const ConvKArgs a) {
+  constexpr int NT = 4;
+  HIP_DYNAMIC_SHARED(char, smem)
+  T* wl = (T*)smem;
+  T* chunk0 = (T*)(smem + W2_BYTES);
+  float* sred = (float*)(smem + W2_BYTES + 2 * S2F_CHUNK_BYTES);
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l15 = lane & 15, lg = lane >> 4;
+  const int l8 = lane >> 3, s8 = lane & 7;
+  const int l4 = lane >> 2, s4 = lane & 3;
+  const T* in = (const T*)a.in;
+  const int tiles_per_img = a.tiles_x * a.tiles_y;
+  const int ntiles = tiles_per_img * a.N;
+  const T* zero = (const T*)conv64_zero_page;
+  const fsr_lds_addr_t lds_addr = FSR_LDS_ADDR(smem);
+
+  // ---- the whole filter: LDS row r = slice * 64 + j, MFMA row permutation as in conv64_v2_kernel
+  {
+    const T* wpk = (const T*)a.wpk;
+#pragma unroll
+    for (int i = 0; i < 9; ++i) {
+      const int k = wave + i * 8;
+      const int r = k * 8 + l8;
+      const int slice = r >> 6, j = r & 63;
+      const int row = ((j & 12) << 2) + ((j >> 4) << 2) + (j & 3);
+      FSR_GLDS16_AT(wpk + ((size_t)slice * 64 * 64 + (size_t)(row * 64 + ((s8 ^ (r & 7)) * 8))), lds_addr + (fsr_lds_addr_t)(k * 8 * 64) * sizeof(T));
+    }
+  }
+  // 32-channel chunk c of the halo of `tile` -> buffer c: wave instruction k fills pixels 16k .. 16k+15 (4 units each)
+  auto chunk_dma = [&](int tile, int c) {
+    const int img = tile / tiles_per_img;
+    const int rem = tile - img * tiles_per_img;
+    const int ty = rem / a.tiles_x, tx = rem - ty * a.tiles_x;
+    const int iy0 = ty * 16 + a.org_y, ix0 = tx * 32 + a.org_x;
+    const fsr_lds_addr_t cb = lds_addr + W2_BYTES + (fsr_lds_addr_t)c * S2F_CHUNK_BYTES;
+    for (int k = wave; k < S2F_NDMA; k += 8) {
+      const int p = k * 16 + l4;
+      const int hy = p / S2F_HW, hx = p - hy * S2F_HW;
+      const int iy = iy0 + hy, ix = ix0 + hx;
+      const bool ok = p < S2F_HH * S2F_HW && iy >= 0 && iy < a.IH && ix >= 0 && ix < a.IW;
+      const T* src = ok ? in + ((unsigned)((img * a.IH + iy) * a.IW + ix) * 64u + (unsigned)(c * 32 + ((s4 ^ ((p >> 2) & 3)) * 8))) : zero + s4 * 8;
+      FSR_GLDS16_AT(src, cb + (fsr_lds_addr_t)(k * 1024));
+    }
+  };
+
+  float slope = (a.act == FSR_ACT_PRELU) ? a.prelu[0] : a.slope;
+  if (a.act == FSR_ACT_NONE || a.act == FSR_ACT_TANH) slope = 1.f;
+  if (a.act == FSR_ACT_RELU) slope = 0.f;
+  T* outp = (T*)a.out;
+  T* prep = (T*)a.preact;
+
+  int wofs[2];
+#pragma unroll
+  for (int ks = 0; ks < 2; ++ks) wofs[ks] = l15 * 64 + (((ks * 4 + lg) ^ (l15 & 7)) * 8);
+  f32x4 bias[NT];
+#pragma unroll
+  for (int n = 0; n < NT; ++n) {
+    bias[n] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    if (a.bias) bias[n] = *(const f32x4*)(a.bias + lg * 16 + n * 4);
+  }
+  const int tile_begin = (int)blockIdx.x * a.nblk_n;
+  const int tile_end = (tile_begin + a.nblk_n < ntiles) ? tile_begin + a.nblk_n : ntiles;
+  f32x4 s1acc[STATS ? NT : 1], s2acc[STATS ? NT : 1];
+#pragma unroll
+  for (int n = 0; n < (STATS ? NT : 1); ++n) s1acc[n] = s2acc[n] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  if (tile_begin < tile_end) chunk_dma(tile_begin, 0);
+  FSR_WAIT_DMA();
+  __syncthreads();
+
+  int pend_img = -1;
+  auto stats_store = [&]() {
+    if (tid < 128) {
+      float sum = sred[tid];
+#pragma unroll
+      for (int w = 1; w < 8; ++w) sum += sred[w * 128 + tid];
+      const int slot = (int)blockIdx.x - (pend_img * tiles_per_img) / a.nblk_n;
+      a.stats[(((size_t)pend_img * a.stats_P + slot) * a.Cout + (tid >> 1)) * 2 + (tid & 1)] = sum;
+    }
+  };
+
+  f32x4 acc[NT];
+  for (int tile = tile_begin; tile < tile_end; ++tile) {
+#pragma unroll
+    for (int n = 0; n < NT; ++n) acc[n] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+      // the next half step's chunk: the other buffer, last read one half step (and one barrier) ago
+      if (c == 0) chunk_dma(tile, 1);
+      else if (tile + 1 < tile_end) chunk_dma(tile + 1, 0);
+      if (c == 0 && pend_img >= 0) {       // uniform: the previous tile flushed statistics
+        stats_store();
+        __syncthreads();
+        pend_img = -1;
+      }
+      const T* hb = chunk0 + c * (S2F_CHUNK_BYTES / (int)sizeof(T));
+      static_for<0, 9>([&](auto tcn) {
+        constexpr int t = decltype(tcn)::value;
+        constexpr int ky = t / 3, kx = t % 3;
+        const int p = (2 * wave + ky) * S2F_HW + kx + 2 * l15;
+        const s16x8 xf = *(const s16x8*)(hb + (p * 32 + ((lg ^ ((p >> 2) & 3)) * 8)));
+        const T* wsl = wl + t * (64 * 64);
+        s16x8 wf[NT];
+#pragma unroll
+        for (int n = 0; n < NT; ++n) wf[n] = *(const s16x8*)(wsl + wofs[c] + n * (16 * 64));
+#pragma unroll
+        for (int n = 0; n < NT; ++n) acc[n] = mfma16<T>(wf[n], xf, acc[n]);
+      });
+      if (c == 1) {
+        // ---- epilogue: the lane holds channels lg * 16 .. lg * 16 + 15 of pixel (row `wave`, column l15): two 16-byte stores
+        const int img = tile / tiles_per_img;
+        const int rem = tile - img * tiles_per_img;
+        const int ty = rem / a.tiles_x, tx = rem - ty * a.tiles_x;
+        const int gx = tx * 16 + l15, gy = ty * 8 + wave;
+        const bool flush = STATS && (tile + 1 >= tile_end || (tile + 1) / tiles_per_img != img);
+        if (gx < a.GW && gy < a.GH) {
+          const unsigned off = (unsigned)((img * a.FOH + gy) * a.FOW + gx) * 64u + (unsigned)(lg * 16);
+          u32x4 pk[2], pp[2];
+          static_for<0, NT>([&](auto nc) {
+            constexpr int n = decltype(nc)::value;
+            f32x4 v = acc[n] + bias[n];
+            if constexpr (STATS) {
+              s1acc[n] += v;
+              s2acc[n] += v * v;
+            }
+            if (prep) {
+              pp[n >> 1][(n & 1) * 2] = pack2<T>(v[0], v[1]);
+              pp[n >> 1][(n & 1) * 2 + 1] = pack2<T>(v[2], v[3]);
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f) + slope * fminf(v[r], 0.f);
+            pk[n >> 1][(n & 1) * 2] = pack2<T>(v[0], v[1]);
+            pk[n >> 1][(n & 1) * 2 + 1] = pack2<T>(v[2], v[3]);
+          });
+          if (prep) {
+            *(u32x4*)(prep + off) = pp[0];
+            *(u32x4*)(prep + off + 8) = pp[1];
+          }
+          *(u32x4*)(outp + off) = pk[0];
+          *(u32x4*)(outp + off + 8) = pk[1];
+        }
+        if constexpr (STATS) {
+          if (flush) {
+            static_for<0, NT>([&](auto nc) {
+              constexpr int n = decltype(nc)::value;
+#pragma unroll
+              for (int r = 0; r < 4; ++r) {
+                float x1 = s1acc[n][r], x2 = s2acc[n][r];
+#pragma unroll
+                for (int o = 8; o >= 1; o >>= 1) {
+                  x1 += __shfl_xor(x1, o, 64);
+                  x2 += __shfl_xor(x2, o, 64);
+                }
+                if (l15 == 0) {
+                  const int cl = lg * 16 + n * 4 + r;
+                  sred[(wave * 64 + cl) * 2] = x1;
+                  sred[(wave * 64 + cl) * 2 + 1] = x2;
+                }
+              }
+              s1acc[n] = s2acc[n] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            });
+            pend_img = img;
+          }
+        }
+      }
+      FSR_WAIT_DMA();
+      __syncthreads();
+    }
+  }
+  if (pend_img >= 0) stats_store();
+}
+
+// ---------------------------------------------------------------------------------------------------------------
 // Data gradient of the 64 -> 64 STRIDE-2 convolution (Discriminator block 0, /root/reference/model.py:148-152), all four
 // output-parity classes in one pass.  As four class launches of the generic kernel the layer is latency-bound (K is only
 // 64..256 per class, a workgroup lives for a prologue and an epilogue) at ~2 TB/s.  Here a persistent workgroup keeps
@@ -858,6 +1046,46 @@ int fsr_conv64_s2dgrad_try(int dtype, ConvKArgs& a, hipStream_t stream) {
   else hipLaunchKernelGGL(conv64_s2dgrad_kernel<bf16_t>, dim3(grid), dim3(NTHR64), LDS64, stream, a);
   fsr_note_kernel("conv64_s2dgrad_kernel");
   int rc = fsr_check_launch("conv64_s2dgrad_kernel");
+  return rc ? rc : 1;
+}
+
+// Stride-2 forward, 64 -> 64 channels: 1 = launched, 0 = not this kernel's shape, < 0 = error.
+int fsr_conv64_s2fwd_try(int dtype, ConvKArgs& a, int S, hipStream_t stream) {
+  static const bool off = getenv("FSR_CONV64_S2FWD") && atoi(getenv("FSR_CONV64_S2FWD")) == 0;   // A/B switch
+  if (off || (dtype != FSR_BF16 && dtype != FSR_F16) || S != 2 || a.Cin != 64 || a.Cout != 64 || a.CoutPad != 64 || a.ntaps != 9) return 0;
+  if (a.ps || a.in_ps || a.out_f32 || a.oscale || a.dmask || a.pool2) return 0;
+  if (a.osy != 1 || a.osx != 1 || a.ooy != 0 || a.oox != 0 || a.org_y != -1 || a.org_x != -1) return 0;
+  for (int t = 0; t < 9; ++t)
+    if (a.tdy[t] != t / 3 || a.tdx[t] != t % 3 || a.tw[t] != t) return 0;     // the forward tap table
+  if ((long long)a.N * a.IH * a.IW * 64 >= (1LL << 31)) return 0;
+  a.tiles_x = (a.GW + 15) / 16;
+  a.tiles_y = (a.GH + 7) / 8;
+  const long long ntiles = (long long)a.tiles_x * a.tiles_y * a.N;
+  if (ntiles <= 0 || ntiles > 0x7fffffffLL) return 0;
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute((const void*)conv64_s2fwd_kernel<bf16_t, false>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS64S2F);
+    (void)hipFuncSetAttribute((const void*)conv64_s2fwd_kernel<bf16_t, true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS64S2F);
+    (void)hipFuncSetAttribute((const void*)conv64_s2fwd_kernel<f16_t, false>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS64S2F);
+    (void)hipFuncSetAttribute((const void*)conv64_s2fwd_kernel<f16_t, true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS64S2F);
+    attr_set = true;
+  }
+  const int cus = persistent_slots();
+  const int per = (int)((ntiles + cus - 1) / cus);
+  a.nblk_n = per;
+  a.stats_tpi = a.tiles_x * a.tiles_y;
+  a.stats_per = per;
+  a.stats_P = (a.stats_tpi + per - 1) / per + 1;
+  const int grid = (int)((ntiles + per - 1) / per);
+  if (dtype == FSR_F16) {
+    if (a.stats) hipLaunchKernelGGL((conv64_s2fwd_kernel<f16_t, true>), dim3(grid), dim3(NTHR64), LDS64S2F, stream, a);
+    else hipLaunchKernelGGL((conv64_s2fwd_kernel<f16_t, false>), dim3(grid), dim3(NTHR64), LDS64S2F, stream, a);
+  } else {
+    if (a.stats) hipLaunchKernelGGL((conv64_s2fwd_kernel<bf16_t, true>), dim3(grid), dim3(NTHR64), LDS64S2F, stream, a);
+    else hipLaunchKernelGGL((conv64_s2fwd_kernel<bf16_t, false>), dim3(grid), dim3(NTHR64), LDS64S2F, stream, a);
+  }
+  fsr_note_kernel("conv64_s2fwd_kernel");
+  int rc = fsr_check_launch("conv64_s2fwd_kernel");
   return rc ? rc : 1;
 }
 

@@ -786,6 +786,8 @@ int fsr_conv_igemm_dispatch_classes(int dtype, ConvKArgs* cls, int n, hipStream_
 int fsr_conv_igemm_dispatch(int dtype, ConvKArgs& a, int S, hipStream_t stream) {
   // 64 -> 64 channel stride-1 layers: persistent kernel with the whole filter resident in LDS (conv64_persistent.hip)
   if (const int rc = fsr_conv64_persistent_try(dtype, a, S, stream)) return rc < 0 ? rc : 0;
+  // 64 -> 64 channel stride-2 forward (Discriminator block 0): persistent streaming kernel (conv64_persistent.hip)
+  if (const int rc = fsr_conv64_s2fwd_try(dtype, a, S, stream)) return rc < 0 ? rc : 0;
   if (dtype == FSR_BF16) return dispatch_T<bf16_t, 64, 32>(a, S, stream);
   if (dtype == FSR_F16) return dispatch_T<f16_t, 64, 32>(a, S, stream);
   if (dtype == FSR_F32) return dispatch_T<float, 16, 16>(a, S, stream);

@@ -535,6 +535,31 @@ def test_persistent_conv_variants_on_ragged_shapes(dev, cus, shape, monkeypatch)
     assert relerr(_nchw(y), want) < 1e-2
 
 
+@pytest.mark.parametrize("cus", [1, 5, 256])
+@pytest.mark.parametrize("shape", [(1, 7, 9), (3, 16, 32), (2, 33, 47), (5, 20, 64)])
+def test_persistent_stride2_forward_64(dev, cus, shape, monkeypatch):
+    """The persistent 64 -> 64 stride-2 forward kernel (Discriminator block 0, model.py:148-152): output, pre-activation copy
+    and InstanceNorm statistics against torch on odd / even / sub-tile shapes, with one, a few and more tile ranges than
+    tiles; and the generic kernel (FSR_CONV64_S2FWD=0 is read once per process, so: by channel count) gives the same."""
+    monkeypatch.setenv("FSR_PERSIST_CUS", str(cus))
+    n, h, w = shape
+    for cdn in ("bf16", "f16"):
+        cd = ops.Compute(cdn)
+        torch.manual_seed(31)
+        x = _q(torch.randn(n, 64, h, w), cd)
+        wt = _q(torch.randn(64, 64, 3, 3) * 0.1, cd)
+        bias = torch.randn(64) * 0.1
+        xd = _nhwc(x, cd, dev)
+        wpk = ops.packed_filter(cd, wt.to(dev), L.PACK_FWD, 64)
+        ref = F.conv2d(x, wt, bias, 2, 1)
+        y, _, stats = ops.conv3x3_raw(cd, xd, wpk, 64, stride=2, bias=bias.to(dev), want_stats=True)
+        assert ops._last_kernel() == "conv64_s2fwd_kernel"
+        assert relerr(_nchw(y), ref) < 1e-2
+        assert relerr(stats.cpu()[..., 0], ref.sum((2, 3))) < 2e-3 and relerr(stats.cpu()[..., 1], (ref * ref).sum((2, 3))) < 2e-3
+        y, pre, _ = ops.conv3x3_raw(cd, xd, wpk, 64, stride=2, bias=bias.to(dev), act=L.ACT_LEAKY, slope=0.2, want_preact=True)
+        assert relerr(_nchw(pre), ref) < 1e-2 and relerr(_nchw(y), F.leaky_relu(ref, 0.2)) < 1e-2
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("cdn", ["f32", "bf16"])
 def test_reductions_are_bit_reproducible(cdn):
