@@ -13,7 +13,7 @@ import sys
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
-KERNELS = ("conv_igemm_kernel", "conv64_persistent_kernel", "conv64_v2_kernel", "conv64_s2dgrad_kernel", "conv_c3_fwd_kernel")
+KERNELS = ("conv_igemm_kernel", "conv64_", "conv_c3_fwd_kernel")      # every forward / data-gradient convolution kernel (conv64_*: all persistent forms)
 
 
 def total_kb(path, counter):
@@ -47,6 +47,8 @@ iters = int(sys.argv[3]) if len(sys.argv) > 3 else 4
 api = int(sys.argv[4]) if len(sys.argv) > 4 else 0
 byt = (2 * fetch + write) * 1024 / iters
 print("conv kernel dispatches per iteration: %.1f / %.1f" % (n1 / iters, n2 / iters))
+if api and (abs(n1 / iters - api) > 0.01 or abs(n2 / iters - api) > 0.01):
+    sys.exit("the kernel-name filter matched %.1f / %.1f dispatches per iteration, the bench counted %d launches: update KERNELS" % (n1 / iters, n2 / iters, api))
 print("FETCH_SIZE %.0f KB (x2) + WRITE_SIZE %.0f KB per iteration -> %.3e bytes per iteration" % (fetch / iters, write / iters, byt))
 if api:
     print("per API-level conv launch (%d per iteration): %.3e bytes" % (api, byt / api))
