@@ -76,7 +76,7 @@ def test_conv_fwd_dgrad_wgrad(dev, cdn, stride, cin, cout, ps):
 
 
 @pytest.mark.parametrize("cdn", ["f32", "bf16", "f16"])
-@pytest.mark.parametrize("nlayers", [1, 3, 17])
+@pytest.mark.parametrize("nlayers", [1, 3, 17, 33])
 def test_conv_wgrad_grouped(dev, cdn, nlayers):
     """The deferred grouped weight gradient (ops.wgrad_stream_begin .. join: the generator's 64 -> 64 layers in ONE
     launch) against torch per layer, accumulating into the arenas, and bit-reproducible."""
@@ -84,7 +84,7 @@ def test_conv_wgrad_grouped(dev, cdn, nlayers):
     cd = ops.Compute(cdn)
     torch.manual_seed(9)
     n, h, w = (4, 40, 56) if _big(dev) else (1, 9, 20)
-    if nlayers == 17 and not _big(dev):
+    if nlayers >= 17 and not _big(dev):
         h = 5
     xs = [_q(torch.randn(n, 64, h, w), cd) for _ in range(nlayers)]
     gs = [_q(torch.randn(n, 64, h, w), cd) for _ in range(nlayers)]
