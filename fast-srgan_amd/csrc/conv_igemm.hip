@@ -788,6 +788,8 @@ int fsr_conv_igemm_dispatch(int dtype, ConvKArgs& a, int S, hipStream_t stream) 
   if (const int rc = fsr_conv64_persistent_try(dtype, a, S, stream)) return rc < 0 ? rc : 0;
   // 64 -> 64 channel stride-2 forward (Discriminator block 0): persistent streaming kernel (conv64_persistent.hip)
   if (const int rc = fsr_conv64_s2fwd_try(dtype, a, S, stream)) return rc < 0 ? rc : 0;
+  // 128..512-channel stride-1 layers without statistics: 32x32x16 MFMA, both operands by LDS-DMA (conv_tall3.hip)
+  if (const int rc = fsr_conv_tall3_try(dtype, a, S, stream)) return rc < 0 ? rc : 0;
   if (dtype == FSR_BF16) return dispatch_T<bf16_t, 64, 32>(a, S, stream);
   if (dtype == FSR_F16) return dispatch_T<f16_t, 64, 32>(a, S, stream);
   if (dtype == FSR_F32) return dispatch_T<float, 16, 16>(a, S, stream);

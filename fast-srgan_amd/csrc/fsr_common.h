@@ -64,6 +64,29 @@ __device__ __forceinline__ void fsr_glds16_sat(const void* sbase, unsigned voff,
 #define FSR_GLDS16_AT(g, a) fsr_glds16_at((g), (a))
 #define FSR_GLDS16_SAT(sb, vo, a) fsr_glds16_sat((sb), (vo), (a))
 #endif
+// ---- buffer-addressed LDS-DMA (conv_tall3.hip).  buffer_load_dwordx4 ... offen lds: every lane copies 16 bytes from
+// (descriptor base + voffset + soffset) to (LDS address in M0) + 16 * lane; a lane whose voffset lies beyond the descriptor's
+// byte count gets ZEROS (hardware range check on voffset only -- soffset is not checked): image borders need no zero page and
+// no branch.  Issued from inline asm for the same reason as FSR_GLDS16_*: hipcc never sees the piece, so its own
+// lgkmcnt / vmcnt bookkeeping stays counted, and the kernel waits for its pieces itself (FSR_WAIT_VM(n): at most n of the
+// YOUNGEST vector-memory operations of this wave are still in flight; loads retire in order).
+#ifndef FSR_BLDS16
+struct fsr_buf_t { u32x4 v; };
+__device__ __forceinline__ fsr_buf_t fsr_make_buf(const void* p, unsigned bytes) {
+  const unsigned long long x = (unsigned long long)(size_t)p;
+  fsr_buf_t b;
+  b.v = (u32x4){(unsigned)x, (unsigned)(x >> 32) & 0xffffu, bytes, 0x00020000u};   // raw buffer, stride 0, 32-bit data format
+  return b;
+}
+__device__ __forceinline__ void fsr_blds16(fsr_buf_t b, unsigned voff, unsigned soff, unsigned lds_addr) {
+  asm volatile("s_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %0, %2 offen lds" ::"s"(b.v), "v"(voff), "s"(soff), "s"(lds_addr)
+               : "memory", "m0");
+}
+#define FSR_BLDS16(b, vo, so, a) fsr_blds16((b), (vo), (so), (a))
+#define FSR_WAIT_VM(n) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(n) : "memory")
+#define FSR_WAIT_LGKM0() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
+#define FSR_BARRIER() __builtin_amdgcn_s_barrier()
+#endif
 // A register "use" with no instruction: pins where the compiler places its s_waitcnt for a load's result.
 #ifndef FSR_TOUCH
 #define FSR_TOUCH(v) asm volatile("" : "+v"(v))

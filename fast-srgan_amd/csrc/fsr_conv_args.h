@@ -41,6 +41,10 @@ struct ConvKArgs {
   int pool2;            // epilogue stores MaxPool2d(2,2) of the activated result ([N][FOH/2][FOW/2][Cout]) instead of the result
   int tiles_x, tiles_y, nblk_n;
   int premask;          // epilogue loads every mask value before its first store
+  // conv_tall3.hip: byte offset of the filter slice that serves canonical tap ky*3+kx, and the launch's tile count
+  unsigned t3_woff[9];
+  int t3_ntiles;
+  int t3_dbg;           // FSR_T3_DBG (debug builds of the bench only): 1 no stores, 2 no DMA, 4 no main loop
 };
 
 // A launch may cover up to four "classes" that differ only in their output grid, tap table and output offset (the

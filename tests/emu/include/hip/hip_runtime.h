@@ -35,6 +35,13 @@ typedef uintptr_t fsr_lds_addr_t;
 #define FSR_GLDS16_AT(g, a) emu::global_load_lds((const void*)(g), (void*)(a), 16, 0)
 #define FSR_GLDS16_SAT(sb, vo, a) emu::global_load_lds((const void*)((const char*)(sb) + (vo)), (void*)(a), 16, 0)
 #define FSR_TOUCH(v) ((void)(v))
+// buffer-addressed LDS-DMA (conv_tall3.hip): base pointer + byte count; a voffset beyond the count reads zeros
+struct fsr_buf_t { const char* p; unsigned bytes; };
+#define fsr_make_buf(ptr, nbytes) (fsr_buf_t{(const char*)(ptr), (unsigned)(nbytes)})
+#define FSR_BLDS16(b, vo, so, a) emu::buffer_load_lds16((b).p, (b).bytes, (vo), (so), (void*)(a))
+#define FSR_WAIT_VM(n) ((void)0)
+#define FSR_WAIT_LGKM0() ((void)0)
+#define FSR_BARRIER() emu::block_sync()
 
 struct dim3 {
   unsigned x, y, z;
@@ -271,6 +278,55 @@ inline void global_load_lds(const void* gsrc, void* lds_base, unsigned size, int
   memcpy(base + offset + (size_t)ctx.lane * size, gsrc, size);
 }
 
+// buffer_load_dwordx4 ... offen lds: 16 bytes per lane from base + voffset + soffset; the range check covers voffset only
+inline void buffer_load_lds16(const char* base, unsigned bytes, unsigned voff, unsigned soff, void* lds_base) {
+  ctx.w->u64[ctx.lane] = (uint64_t)(uintptr_t)lds_base;
+  wave_sync();
+  char* dst = (char*)(uintptr_t)ctx.w->u64[0];
+  wave_sync();
+  if ((uint64_t)voff + 16 <= (uint64_t)bytes) memcpy(dst + (size_t)ctx.lane * 16, base + voff + soff, 16);
+  else memset(dst + (size_t)ctx.lane * 16, 0, 16);
+}
+
+typedef float f32x16_e __attribute__((ext_vector_type(16)));
+// v_mfma_f32_32x32x16_{bf16,f16}: A[i][k] held by lane i+32*(k/8) element k%8; B[k][j] by lane j+32*(k/8) element k%8;
+// D[i][j] -> lane j+32*((i/4)%2), reg (i%4) + 4*(i/8)
+inline f32x16_e mfma_32x32x16_core(f32x16_e c) {
+  WaveState* w = ctx.w;
+  wave_sync();
+  const int j = ctx.lane & 31;
+  for (int r = 0; r < 16; ++r) {
+    const int i = (r & 3) + 8 * (r >> 2) + 4 * (ctx.lane >> 5);
+    float acc = c[r];
+    for (int k = 0; k < 16; ++k) acc = fmaf(w->fa[i + 32 * (k >> 3)][k & 7], w->fb[j + 32 * (k >> 3)][k & 7], acc);
+    c[r] = acc;
+  }
+  wave_sync();
+  return c;
+}
+template <class VA, class VB>
+inline f32x16_e mfma_bf16_32x32x16(VA a, VB b, f32x16_e c) {
+  uint16_t ua[8], ub[8];
+  memcpy(ua, &a, 16);
+  memcpy(ub, &b, 16);
+  for (int e = 0; e < 8; ++e) {
+    ctx.w->fa[ctx.lane][e] = bf16_bits_to_float(ua[e]);
+    ctx.w->fb[ctx.lane][e] = bf16_bits_to_float(ub[e]);
+  }
+  return mfma_32x32x16_core(c);
+}
+template <class VA, class VB>
+inline f32x16_e mfma_f16_32x32x16(VA a, VB b, f32x16_e c) {
+  _Float16 ha[8], hb[8];
+  memcpy(ha, &a, 16);
+  memcpy(hb, &b, 16);
+  for (int e = 0; e < 8; ++e) {
+    ctx.w->fa[ctx.lane][e] = (float)ha[e];
+    ctx.w->fb[ctx.lane][e] = (float)hb[e];
+  }
+  return mfma_32x32x16_core(c);
+}
+
 inline float atomic_add_f32(float* addr, float v) {
   uint32_t* p = (uint32_t*)addr;
   uint32_t old = __atomic_load_n(p, __ATOMIC_RELAXED);
@@ -315,6 +371,10 @@ inline float __logf(float x) { return logf(x); }
 #define __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, x, y, z) emu::mfma_bf16_16x16x32((a), (b), (c))
 #define __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, x, y, z) emu::mfma_f16_16x16x32((a), (b), (c))
 #define __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, x, y, z) emu::mfma_f32_16x16x4((a), (b), (c))
+#define __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, x, y, z) emu::mfma_bf16_32x32x16((a), (b), (c))
+#define __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, x, y, z) emu::mfma_f16_32x32x16((a), (b), (c))
+#define __builtin_amdgcn_sched_group_barrier(mask, n, id) ((void)0)
+#define __builtin_amdgcn_s_setprio(p) ((void)0)
 #define __builtin_amdgcn_ds_read_tr16_b64_v4i16(p) emu::ds_read_tr16((const void*)(p))
 #define __builtin_amdgcn_readfirstlane(x) (x)
 #define __builtin_amdgcn_sched_barrier(mask) ((void)0)

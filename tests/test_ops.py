@@ -667,3 +667,40 @@ def test_conv_at_bench_shapes_gpu(shape):
     assert relerr(_nchw(dx)[:, :cin], xr.grad) < (1e-2 if cin != 3 else 1e-4)
     dw = ops.conv3x3_wgrad_raw(cd, xd, gd, cout, cin, stride, dy_pixel_shuffled=ps)
     assert relerr(dw, wr.grad) < 2e-3
+
+
+@pytest.mark.parametrize("cdn", ["bf16", "f16"])
+@pytest.mark.parametrize("cin,cout,variant", [(128, 256, "plain"), (128, 128, "plain"), (160, 256, "mask"), (128, 128, "pool"), (128, 256, "pool")])
+def test_conv_tall3(dev, cdn, cin, cout, variant, monkeypatch):
+    """conv_tall3.hip (32x32x16 MFMA, both operands by LDS-DMA, persistent tiles): forward with bias + ReLU, the fused
+    2x2 max-pool, and the data gradient with the fused activation mask, on maps that are not multiples of the 16 x 16 tile
+    and with more tiles than workgroups (FSR_PERSIST_CUS: every workgroup walks several tiles, borders included)."""
+    monkeypatch.setenv("FSR_PERSIST_CUS", "3" if _big(dev) else "1")
+    monkeypatch.setenv("FSR_TALL3", "5")          # also take maps whose last tile row is mostly padding
+    cd = ops.Compute(cdn)
+    torch.manual_seed(11)
+    n, h, w = (3, 50, 44) if _big(dev) else (1, 18, 20)
+    x = _q(torch.randn(n, cin, h, w), cd)
+    wt = _q(torch.randn(cout, cin, 3, 3) * 0.05, cd)
+    bias = torch.randn(cout) * 0.1
+    xd = _nhwc(x, cd, dev)
+    wpk = ops.packed_filter(cd, wt.to(dev), L.PACK_FWD, cin)
+    pool = variant == "pool"
+    y, _, _ = ops.conv3x3_raw(cd, xd, wpk, cout, bias=bias.to(dev), act=L.ACT_RELU, pool2=pool)
+    assert L.lib().fsr_last_kernel().decode().startswith("conv_tall3_kernel"), L.lib().fsr_last_kernel()
+    ref = F.relu(F.conv2d(x, wt, bias, 1, 1))
+    if pool:
+        ref = F.max_pool2d(ref, 2, 2)
+    assert relerr(_nchw(y), ref) < tol(cdn, 1e-5, 1e-2)
+    # data gradient on the transposed filter, with the LeakyReLU backward of the producing layer fused (mask = its output)
+    g = _q(torch.randn(n, cout, h, w), cd)
+    mask = _q(torch.randn(n, cin, h, w), cd)
+    xr = leaf(x)
+    F.conv2d(xr, wt, None, 1, 1).backward(g)
+    want = xr.grad * torch.where(mask > 0, torch.ones_like(mask), torch.full_like(mask, 0.2)) if variant == "mask" else xr.grad
+    wpk_d = ops.packed_filter(cd, wt.to(dev), L.PACK_DGRAD, cout)
+    dx, _, _ = ops.conv3x3_raw(cd, _nhwc(g, cd, dev), wpk_d, cin, mode=L.CONV_DGRAD, out_hw=(h, w),
+                               dact_mask=_nhwc(mask, cd, dev) if variant == "mask" else None, dact_slope=0.2)
+    if cin % 128 == 0:
+        assert L.lib().fsr_last_kernel().decode().startswith("conv_tall3_kernel"), L.lib().fsr_last_kernel()
+    assert relerr(_nchw(dx), want) < tol(cdn, 1e-5, 1e-2)
