@@ -50,13 +50,14 @@ template <> struct Mfma32<f16_t> {
   }
 };
 
-constexpr int T3_P = 18;                           // halo rows and columns (16 x 16 outputs + the 3 x 3 footprint)
-constexpr int T3_HUNITS = T3_P * T3_P * 4;         // 16-byte units of one halo chunk
-constexpr int T3_NHP = (T3_HUNITS + 63) / 64;      // DMA pieces per halo chunk (21)
-constexpr int T3_HALO_BYTES = T3_NHP * 1024;
+constexpr int T3_P = 18;                           // halo columns (16 outputs + the 3 x 3 footprint)
 constexpr int T3_PIXB = 64, T3_ROWB = T3_P * T3_PIXB;   // bytes per halo pixel / halo row
+// A tile is TH = 4 * MB output rows x 16 columns (MB = pixel fragments of two rows per wave: 4, 3 or 2 -> 16, 12, 8 rows)
+template <int MB> constexpr int t3_hunits() { return (4 * MB + 2) * T3_P * 4; }          // 16-byte units of one halo chunk
+template <int MB> constexpr int t3_nhp() { return (t3_hunits<MB>() + 63) / 64; }         // DMA pieces per halo chunk
+template <int MB> constexpr int t3_halo_bytes() { return t3_nhp<MB>() * 1024; }
 
-template <int BN, int G, int NSLOT> constexpr int t3_lds_bytes() { return 2 * T3_HALO_BYTES + NSLOT * G * BN * 64; }
+template <int BN, int G, int NSLOT, int MB> constexpr int t3_lds_bytes() { return 2 * t3_halo_bytes<MB>() + NSLOT * G * BN * 64 + 2 * 1024; }   // + two bias pieces
 
 __device__ __forceinline__ int t3_swz_row(int R) { return (R >> 2) & 3; }
 __device__ __forceinline__ int t3_swz_col(int x) { return (x >> 1) & 3; }
@@ -66,9 +67,14 @@ __device__ __forceinline__ V t3_lds_read(const char* smem, unsigned off) {
   return *FSR_LDS_PTR(const V, smem + off);
 }
 
-template <typename T, int BN, int NW, int G, int NSLOT>
+template <typename T, int BN, int NW, int G, int NSLOT, int MB>
 __global__ __launch_bounds__(NW * 64, 2) void conv_tall3_kernel(const ConvKArgs a) {
-  static_assert(BN == NW * 32, "a wave owns 128 pixels x 64 channels");
+  static_assert(BN == NW * 32, "a wave owns 32 * MB pixels x 64 channels");
+  static_assert(MB >= 2 && MB <= 4, "8, 12 or 16 tile rows");
+  constexpr int TH = 4 * MB;                       // tile rows
+  constexpr int T3_HUNITS = t3_hunits<MB>(), T3_NHP = t3_nhp<MB>(), T3_HALO_BYTES = t3_halo_bytes<MB>();
+  constexpr int NM = 2 * MB;                       // MFMAs per substep (2 filter x MB pixel fragments)
+  constexpr int NR = 2 + MB;                       // fragment reads per substep
   static_assert(9 % G == 0 && (9 / G) % NSLOT == 1, "stage s lives in slot s % NSLOT == (chunk + stage in chunk) % NSLOT");
   constexpr int WCO = NW / 2;
   constexpr int SPC = 9 / G;                       // stages per chunk
@@ -106,7 +112,7 @@ __global__ __launch_bounds__(NW * 64, 2) void conv_tall3_kernel(const ConvKArgs 
   for (int kx = 0; kx < 3; ++kx)
 #pragma unroll
     for (int j = 0; j < 2; ++j)
-      boff[kx][j] = (unsigned)(((wpx * 8 + lrow) * T3_P + l15 + kx) * T3_PIXB + (((2 * j + hi) ^ t3_swz_col(l15 + kx)) << 4));
+      boff[kx][j] = (unsigned)(((wpx * 2 * MB + lrow) * T3_P + l15 + kx) * T3_PIXB + (((2 * j + hi) ^ t3_swz_col(l15 + kx)) << 4));
   // DMA source of filter piece k (rows 16*(wave + k*NW) .. +15 of a slice block): byte offset of this lane's 16 bytes
   unsigned wvoff[FP];
 #pragma unroll
@@ -116,52 +122,87 @@ __global__ __launch_bounds__(NW * 64, 2) void conv_tall3_kernel(const ConvKArgs 
     wvoff[k] = (unsigned)((co * a.Cin + ((ul ^ t3_swz_row(R)) << 3)) * (int)sizeof(T));
   }
 
-  f32x16 acc[2][4];
-  s16x8 fa[2][2], fb[2][4];
+  f32x16 acc[2][MB];
+  s16x8 fa[2][2], fb[2][MB];
 
-  // ---- per-tile state ----------------------------------------------------------------------------------------------
-  int img = 0, gy0 = 0, gx0 = 0, nb = 0;
-  unsigned hvoff[HPW];
-  unsigned wsoff = 0;             // byte offset of this tile's channel block inside a filter slice
-  auto setup = [&](int tile) {
+  // ---- per-tile state: the tile being accumulated (`cur`) and the tile the DMA stream moves on to once the current
+  // tile's last stages have their pieces (`nxt`).  The pipeline NEVER drains between tiles: halo chunks keep alternating
+  // buffers and stages keep rotating through the ring across the tile boundary (global chunk counter `gc`).
+  struct TileC { int img, gy0, gx0, nb; };
+  TileC cur = {0, 0, 0, 0}, nxt = {0, 0, 0, 0};
+  unsigned hv_cur[HPW], hv_nxt[HPW];      // halo source offsets of this lane's pieces
+  unsigned ws_cur = 0, ws_nxt = 0;        // byte offset of the tile's channel block inside a filter slice
+  auto setup = [&](int tile, TileC& tc, unsigned (&hv)[HPW], unsigned& ws) {
     int L = tile;
-    nb = L % a.nblk_n; L /= a.nblk_n;
+    tc.nb = L % a.nblk_n; L /= a.nblk_n;
     const int tx = L % a.tiles_x; L /= a.tiles_x;
     const int ty = L % a.tiles_y;
-    img = L / a.tiles_y;
-    gy0 = ty * 16;
-    gx0 = tx * 16;
-    wsoff = (unsigned)(nb * BN * a.Cin * (int)sizeof(T));
+    tc.img = L / a.tiles_y;
+    tc.gy0 = ty * TH;
+    tc.gx0 = tx * 16;
+    ws = (unsigned)(tc.nb * BN * a.Cin * (int)sizeof(T));
 #pragma unroll
     for (int k = 0; k < HPW; ++k) {
       const int U = (wave + k * NW) * 64 + lane;
       const int hp = U >> 2, ul = U & 3;
       const int hy = hp / T3_P, hx = hp - hy * T3_P;
-      const int iy = gy0 - 1 + hy, ix = gx0 - 1 + hx;
+      const int iy = tc.gy0 - 1 + hy, ix = tc.gx0 - 1 + hx;
       unsigned o = ~0u;                                          // beyond the buffer: the DMA writes zeros
       if (U < T3_HUNITS && iy >= 0 && iy < a.IH && ix >= 0 && ix < a.IW)
-        o = (unsigned)((((img * a.IH + iy) * a.IW + ix) * a.Cin + ((ul ^ t3_swz_col(hx)) << 3)) * (int)sizeof(T));
-      hvoff[k] = o;
+        o = (unsigned)((((tc.img * a.IH + iy) * a.IW + ix) * a.Cin + ((ul ^ t3_swz_col(hx)) << 3)) * (int)sizeof(T));
+      hv[k] = o;
     }
   };
-  // DMA pieces: halo piece k of chunk c -> buffer c & 1; filter pieces of tap t (canonical ky*3+kx) of chunk c -> ring slot
-  auto dma_halo = [&](int c, int k) {
+  // DMA pieces.  Halo piece k of tile-chunk c -> halo buffer (global chunk parity); filter pieces of tap t of chunk c -> ring
+  auto dma_halo = [&](const unsigned (&hv)[HPW], int c, int k, unsigned par) {
     if (wave + k * NW < T3_NHP && !(a.t3_dbg & 2))
-      FSR_BLDS16(in_buf, hvoff[k], (unsigned)(c * 64), halo_addr + (fsr_lds_addr_t)((c & 1) * T3_HALO_BYTES + (wave + k * NW) * 1024));
+      FSR_BLDS16(in_buf, hv[k], (unsigned)(c * 64), halo_addr + (fsr_lds_addr_t)(par * T3_HALO_BYTES + (wave + k * NW) * 1024));
   };
-  auto dma_filter = [&](int c, int t, int k, unsigned slot_tap_off) {
-    if (!(a.t3_dbg & 2)) FSR_BLDS16(w_buf, wvoff[k], a.t3_woff[t] + wsoff + (unsigned)(c * 64),
+  auto dma_filter = [&](unsigned ws, int c, int t, int k, unsigned slot_tap_off) {
+    if (!(a.t3_dbg & 2)) FSR_BLDS16(w_buf, wvoff[k], a.t3_woff[t] + ws + (unsigned)(c * 64),
                ring_addr + (fsr_lds_addr_t)(slot_tap_off + (wave + k * NW) * 1024));
   };
-  auto slot_of = [&](int c, int si) { return (unsigned)(((c + si) & (NSLOT - 1)) * SLOT_BYTES); };
+  // The bias of a tile's channel block comes by DMA as well (one piece of BN floats, wave 0, double buffered by tile parity):
+  // an ordinary global load next to the epilogue's stores would make hipcc drain vmcnt -- the whole DMA pipeline -- per tile.
+  constexpr int BIAS_BYTES = BN * 4;                       // <= 1024: one piece
+  const fsr_lds_addr_t bias_addr = ring_addr + NSLOT * SLOT_BYTES;
+  const fsr_buf_t bias_buf = fsr_make_buf(a.bias, a.bias ? (unsigned)(a.Cout * 4) : 0u);
+  auto dma_bias = [&](int nbk, unsigned par) {
+    if (wave == 0 && a.bias && !(a.t3_dbg & 2)) {
+      const unsigned vo = lane * 16 < BIAS_BYTES ? (unsigned)(nbk * BIAS_BYTES + lane * 16) : ~0u;
+      FSR_BLDS16(bias_buf, vo, 0u, bias_addr + (fsr_lds_addr_t)(par * 1024));
+    }
+  };
+  auto acc_init = [&](unsigned par) {
+    // the accumulators start at the bias (a lane's 16 registers of fragment row n are 16 consecutive channels): the epilogue
+    // has no bias pass
+#pragma unroll
+    for (int n = 0; n < 2; ++n) {
+      f32x16 b0;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) b0[e] = 0.f;
+      if (a.bias) {
+        const unsigned bo = (unsigned)(2 * T3_HALO_BYTES + NSLOT * SLOT_BYTES) + par * 1024 + (unsigned)((wco * 64 + n * 32 + hi * 16) * 4);
+#pragma unroll
+        for (int e4 = 0; e4 < 4; ++e4) {
+          const f32x4 b = t3_lds_read<f32x4>(smem, bo + 16 * e4);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) b0[4 * e4 + e] = b[e];
+        }
+      }
+#pragma unroll
+      for (int m = 0; m < MB; ++m) acc[n][m] = b0;
+    }
+  };
+  auto slot_of = [&](int gchunk, int si) { return (unsigned)(((gchunk + si) & (NSLOT - 1)) * SLOT_BYTES); };
 
   // reads of substep (tap t = ky*3+kx in ring position g of its stage, k half j): fragment r in the MFMA's need order
-  // a0 b0 b1 b2 b3 a1
-  auto read_frag = [&](auto rc, auto bufc, auto tc, auto gc, auto jc, unsigned sl, unsigned hb) {
-    constexpr int r = decltype(rc)::value, buf = decltype(bufc)::value, t = decltype(tc)::value, g = decltype(gc)::value,
+  // a0 b0 .. b(MB-1) a1
+  auto read_frag = [&](auto rc, auto bufc, auto tc, auto gc_, auto jc, unsigned sl, unsigned hb) {
+    constexpr int r = decltype(rc)::value, buf = decltype(bufc)::value, t = decltype(tc)::value, g = decltype(gc_)::value,
                   j = decltype(jc)::value;
     constexpr int ky = t / 3, kx = t % 3;
-    if constexpr (r == 0 || r == 5) {
+    if constexpr (r == 0 || r == NR - 1) {
       constexpr int n = r == 0 ? 0 : 1;
       fa[buf][n] = t3_lds_read<s16x8>(smem, aoff[j] + sl + (unsigned)(g * BN * 64 + n * 2048));
     } else {
@@ -179,199 +220,203 @@ __global__ __launch_bounds__(NW * 64, 2) void conv_tall3_kernel(const ConvKArgs 
     const int cnt = a.t3_ntiles - r0 < nround ? a.t3_ntiles - r0 : nround;
     return r0 + xcd_remap(t - r0, cnt);
   };
+  if (tile >= a.t3_ntiles) return;
 
-  if (tile < a.t3_ntiles) {
-    setup(logical(tile));
-    // prologue of the first tile: halo chunk 0 and the first D stages
+  // ---- prologue of the workgroup's first tile: bias, halo chunk 0, the first D stages ------------------------------------
+  setup(logical(tile), cur, hv_cur, ws_cur);
+  int gc = 0;                      // global chunk counter of this workgroup (halo buffer = gc & 1, ring slot = (gc + si) % NSLOT)
+  unsigned tpar = 0;               // tile parity (bias buffer)
+  dma_bias(cur.nb, tpar);
 #pragma unroll
-    for (int k = 0; k < HPW; ++k) dma_halo(0, k);
-    static_for<0, D>([&](auto sc) {
-      constexpr int s = decltype(sc)::value;
-      static_for<0, G>([&](auto gc) {
-        constexpr int g = decltype(gc)::value;
+  for (int k = 0; k < HPW; ++k) dma_halo(hv_cur, 0, k, 0u);
+  static_for<0, D>([&](auto sc) {
+    constexpr int s = decltype(sc)::value;
+    static_assert(D < SPC, "the first D stages lie in chunk 0");
+    static_for<0, G>([&](auto gc_) {
+      constexpr int g = decltype(gc_)::value;
 #pragma unroll
-        for (int k = 0; k < FP; ++k) dma_filter(s / SPC, (s % SPC) * G + g, k, slot_of(s / SPC, s % SPC) + g * BN * 64);
-      });
+      for (int k = 0; k < FP; ++k) dma_filter(ws_cur, 0, s * G + g, k, slot_of(0, s) + g * BN * 64);
     });
-  }
+  });
+  int next = tile + nround;
+  bool has_nxt = next < a.t3_ntiles;
+  FSR_WAIT_VM(0);
+  FSR_BARRIER();
+  acc_init(tpar);
+  static_for<0, NR>([&](auto rc) {   // fragments of substep 0
+    read_frag(rc, std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{},
+              std::integral_constant<int, 0>{}, slot_of(0, 0), 0u);
+  });
+  int issued_prev = 1;             // did the preceding stage issue filter pieces (counted waits, D = 3)
 
-  while (tile < a.t3_ntiles) {
-#pragma unroll
-    for (int n = 0; n < 2; ++n)
-#pragma unroll
-      for (int m = 0; m < 4; ++m)
-#pragma unroll
-        for (int e = 0; e < 16; ++e) acc[n][m][e] = 0.f;
-    FSR_WAIT_VM(0);                 // the prologue pieces of this wave (and the previous tile's stores)
-    FSR_BARRIER();
-    // fragments of substep 0
-    static_for<0, 6>([&](auto rc) {
-      read_frag(rc, std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{},
-                std::integral_constant<int, 0>{}, slot_of(0, 0), 0u);
-    });
-
-    for (int c = 0; c < ((a.t3_dbg & 4) ? 0 : nchunks); ++c) {
+  for (;;) {
+    for (int c = 0; c < ((a.t3_dbg & 4) ? 0 : nchunks); ++c, ++gc) {
+      const bool last = c + 1 == nchunks;
+      if (last && has_nxt) {         // from here on the DMA feeds the next tile
+        setup(logical(next), nxt, hv_nxt, ws_nxt);
+        dma_bias(nxt.nb, tpar ^ 1u);
+      }
       static_for<0, SPC>([&](auto sic) {
         constexpr int si = decltype(sic)::value;
-        const unsigned sl = slot_of(c, si);
-        const unsigned hb = (unsigned)((c & 1) * T3_HALO_BYTES);
-        // the stage whose pieces this stage issues
-        constexpr int siD = (si + D) % SPC;
-        const int cD = c + (si + D) / SPC;
-        const bool issue = cD < nchunks;
-        const unsigned slD = slot_of(cD, siD);
+        const unsigned sl = slot_of(gc, si);
+        const unsigned hb = (unsigned)((gc & 1) * T3_HALO_BYTES);
+        // the stage whose pieces this stage issues: D stages ahead, possibly in the next tile
+        constexpr int siD = (si + D) % SPC, dcD = (si + D) / SPC;
+        const bool crossD = c + dcD >= nchunks;
+        const int cD = crossD ? c + dcD - nchunks : c + dcD;
+        const bool issue = crossD ? has_nxt : true;
+        const unsigned wsD = crossD ? ws_nxt : ws_cur;
+        const unsigned slD = slot_of(gc + dcD, siD);
         // the stage after this one (its first fragments are read in this stage's last substep)
-        constexpr int siN = (si + 1) % SPC;
-        const int cN = c + (si + 1) / SPC;
-        const bool has_next = cN < nchunks;
-        const unsigned slN = slot_of(cN, siN);
-        const unsigned hbN = (unsigned)((cN & 1) * T3_HALO_BYTES);
+        constexpr int siN = (si + 1) % SPC, dcN = (si + 1) / SPC;
+        const bool has_next_stage = (c + dcN < nchunks) || has_nxt;
+        const unsigned slN = slot_of(gc + dcN, siN);
+        const unsigned hbN = (unsigned)(((gc + dcN) & 1) * T3_HALO_BYTES);
 
         static_for<0, NQ>([&](auto qc) {
           constexpr int q = decltype(qc)::value;
-          constexpr int g = q / 2, j = q % 2, t = si * G + g;
           constexpr int buf = q & 1;
           if constexpr (q == NQ - 1) {
             // publish the next stage: this wave's pieces of stage s+1 have landed when at most the pieces of the D-1 younger
-            // stages are outstanding (halo pieces among them only make the wait longer, never shorter)
-            if constexpr (D == 1) {
+            // stages are outstanding.  Loads retire in order, so halo / bias pieces and the previous tile's stores in the
+            // queue can only make the wait longer, never shorter.
+            if (a.t3_dbg & 64) {
+              // EXPERIMENT (wrong results): no wait for the DMA
+            } else if constexpr (D == 1) {
               FSR_WAIT_VM(0);
             } else {
-              const int s = c * SPC + si, nst = nchunks * SPC;
-              const int lo = s - D + 2 > 0 ? s - D + 2 : 0;
-              const int young = (s < nst - 1 - D ? s : nst - 1 - D) - lo + 1;   // stages in [s-D+2, s] that issued pieces
-              if (young <= 0) FSR_WAIT_VM(0);
+              static_assert(D <= 3, "add cases for deeper rings");
+              const int young = (issue ? 1 : 0) + (D == 3 ? issued_prev : 0);
+              if (young == 0) FSR_WAIT_VM(0);
               else if (young == 1) FSR_WAIT_VM(G * FP);
               else FSR_WAIT_VM(2 * G * FP);
-              static_assert(D <= 3, "add cases for deeper rings");
             }
-            FSR_WAIT_LGKM0();
-            FSR_BARRIER();
+            if (a.t3_dbg & 16) FSR_WAIT_LGKM0();   // (strict form; the reads of a slot are >= 400 cycles older than any DMA into it)
+            if (!(a.t3_dbg & 32)) FSR_BARRIER();   // (EXPERIMENT bit 32: no barrier, wrong results)
           }
-          static_for<0, 8>([&](auto ic) {
+          static_for<0, NM>([&](auto ic) {
             constexpr int i = decltype(ic)::value;
-            constexpr int n = i / 4, m = i % 4;
+            constexpr int n = i / MB, m = i % MB;
             acc[n][m] = Mfma32<T>::run(fa[buf][n], fb[buf][m], acc[n][m]);
-            if constexpr (i < 6) {
+            if constexpr (i < NR) {
               if constexpr (q + 1 < NQ) {
                 constexpr int q1 = q + 1;
                 read_frag(ic, std::integral_constant<int, buf ^ 1>{}, std::integral_constant<int, si * G + q1 / 2>{},
                           std::integral_constant<int, q1 / 2>{}, std::integral_constant<int, q1 % 2>{}, sl, hb);
               } else {
-                if (has_next)
+                if (has_next_stage)
                   read_frag(ic, std::integral_constant<int, buf ^ 1>{}, std::integral_constant<int, siN * G>{},
                             std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{}, slN, hbN);
               }
             }
             // DMA pieces of stage s+D: the halo piece first (the likeliest HBM miss), then two filter pieces per substep
             if constexpr (q == 0 && i == 1 && si < HPW) {
-              if (c + 1 < nchunks) dma_halo(c + 1, si);
+              if (!last) dma_halo(hv_cur, c + 1, si, (unsigned)((gc + 1) & 1));
+              else if (has_nxt) dma_halo(hv_nxt, 0, si, (unsigned)((gc + 1) & 1));
             }
-            if constexpr (q < G && i >= 6) {
-              if (issue) dma_filter(cD, siD * G + q, i - 6, slD + q * BN * 64);
+            if constexpr (q < G && i >= NM - 2) {
+              if (issue) dma_filter(wsD, cD, siD * G + q, i - (NM - 2), slD + q * BN * 64);
             }
             __builtin_amdgcn_sched_barrier(0);
           });
         });
-      });
-    }
-
-    // ---- next tile's prologue goes out before this tile's stores ---------------------------------------------------
-    const int oimg = img, ogy0 = gy0, ogx0 = gx0, onb = nb;
-    const int next = tile + nround;
-    FSR_BARRIER();                                  // every wave has left the last substep's LDS reads behind
-    if (next < a.t3_ntiles) {
-      setup(logical(next));
-#pragma unroll
-      for (int k = 0; k < HPW; ++k) dma_halo(0, k);
-      static_for<0, D>([&](auto sc) {
-        constexpr int s = decltype(sc)::value;
-        static_for<0, G>([&](auto gc) {
-          constexpr int g = decltype(gc)::value;
-#pragma unroll
-          for (int k = 0; k < FP; ++k) dma_filter(s / SPC, (s % SPC) * G + g, k, slot_of(s / SPC, s % SPC) + g * BN * 64);
-        });
+        issued_prev = issue ? 1 : 0;
       });
     }
 
     // ---- epilogue -----------------------------------------------------------------------------------------------------
-    float slope = a.slope;
-    if (a.act == FSR_ACT_NONE) slope = 1.f;
-    if (a.act == FSR_ACT_RELU) slope = 0.f;
+    // activation as ONE instruction per element: ReLU = max(v, 0), LeakyReLU = max(v, slope * v) (0 <= slope <= 1: host
+    // checked), identity = nothing.  The three forms are separate instantiations of the store loop (one wave-uniform branch).
     T* outp = (T*)a.out;
     const T* maskp = (const T*)a.dmask;
+    const int oimg = cur.img, ogy0 = cur.gy0, ogx0 = cur.gx0, onb = cur.nb;
     const int gx = ogx0 + l15;
-    static_for<0, 2>([&](auto nc) {
-      constexpr int n = decltype(nc)::value;
-      const int co = onb * BN + wco * 64 + n * 32 + hi * 16;
-      float bv[16];
+    auto store_tile = [&](auto actc) {
+      constexpr int ACT = decltype(actc)::value;
+      const float slope = a.slope;
+      auto activate = [&](float x) {
+        if constexpr (ACT == FSR_ACT_RELU) return fmaxf(x, 0.f);
+        else if constexpr (ACT == FSR_ACT_LEAKY) return fmaxf(x, x * slope);
+        else return x;
+      };
+      static_for<0, 2>([&](auto nc) {
+        constexpr int n = decltype(nc)::value;
+        const int co = onb * BN + wco * 64 + n * 32 + hi * 16;
+        static_for<0, MB>([&](auto mc) {
+          constexpr int m = decltype(mc)::value;
+          const int gy = ogy0 + wpx * 2 * MB + 2 * m + lrow;
+          const bool ok = gy < a.GH && gx < a.GW;
+          float v[16];
 #pragma unroll
-      for (int e = 0; e < 16; ++e) bv[e] = 0.f;
-      if (a.bias) {
+          for (int e = 0; e < 16; ++e) v[e] = acc[n][m][e];
+          if (a.pool2) {
+            // MaxPool2d(2,2) fused: rows (gy, gy^1) sit in lanes (l, l^16), columns in (l, l^1); the activation is monotonic
 #pragma unroll
-        for (int e4 = 0; e4 < 4; ++e4) {
-          const f32x4 b = *(const f32x4*)(a.bias + co + 4 * e4);
+            for (int e = 0; e < 16; ++e) {
+              float x = v[e];
+              x = fmaxf(x, __shfl_xor(x, 16, 64));
+              x = fmaxf(x, __shfl_xor(x, 1, 64));
+              v[e] = activate(x);
+            }
+            if (ok && lrow == 0 && !(l15 & 1) && !(a.t3_dbg & 1)) {
+              const unsigned off = (unsigned)((oimg * (a.FOH >> 1) + (gy >> 1)) * (a.FOW >> 1) + (gx >> 1)) * (unsigned)a.Cout + (unsigned)co;
+              u32x4 p0, p1;
 #pragma unroll
-          for (int e = 0; e < 4; ++e) bv[4 * e4 + e] = b[e];
-        }
-      }
-      static_for<0, 4>([&](auto mc) {
-        constexpr int m = decltype(mc)::value;
-        const int gy = ogy0 + wpx * 8 + 2 * m + lrow;
-        const bool ok = gy < a.GH && gx < a.GW;
-        float v[16];
+              for (int e = 0; e < 4; ++e) {
+                p0[e] = pack2<T>(v[2 * e], v[2 * e + 1]);
+                p1[e] = pack2<T>(v[8 + 2 * e], v[8 + 2 * e + 1]);
+              }
+              *(u32x4*)(outp + off) = p0;
+              *(u32x4*)(outp + off + 8) = p1;
+            }
+          } else if (ok && !(a.t3_dbg & 1)) {
+            const unsigned off = (unsigned)((oimg * a.FOH + gy) * a.FOW + gx) * (unsigned)a.Cout + (unsigned)co;
+            if (maskp) {   // fused activation backward of the producing layer: dz = dx * act'(y), y = the saved forward input
+              const u32x4 k0 = *(const u32x4*)(maskp + off), k1 = *(const u32x4*)(maskp + off + 8);
+              const float ms = a.dmask_slope;
+              // y > 0 on the raw 16-bit pattern: the element moved to the top of a signed word is positive (bf16 and f16 alike)
 #pragma unroll
-        for (int e = 0; e < 16; ++e) v[e] = acc[n][m][e] + bv[e];
-        if (a.pool2) {
-          // MaxPool2d(2,2) fused: rows (gy, gy^1) sit in lanes (l, l^16), columns in (l, l^1); the activation is monotonic
-#pragma unroll
-          for (int e = 0; e < 16; ++e) {
-            float x = v[e];
-            x = fmaxf(x, __shfl_xor(x, 16, 64));
-            x = fmaxf(x, __shfl_xor(x, 1, 64));
-            v[e] = fmaxf(x, 0.f) + slope * fminf(x, 0.f);
-          }
-          if (ok && lrow == 0 && !(l15 & 1) && !(a.t3_dbg & 1)) {
-            const unsigned off = (unsigned)((oimg * (a.FOH >> 1) + (gy >> 1)) * (a.FOW >> 1) + (gx >> 1)) * (unsigned)a.Cout + (unsigned)co;
+              for (int e = 0; e < 4; ++e) {
+                v[2 * e] = (int)(k0[e] << 16) > 0 ? v[2 * e] : v[2 * e] * ms;
+                v[2 * e + 1] = (int)(k0[e] & 0xffff0000u) > 0 ? v[2 * e + 1] : v[2 * e + 1] * ms;
+                v[8 + 2 * e] = (int)(k1[e] << 16) > 0 ? v[8 + 2 * e] : v[8 + 2 * e] * ms;
+                v[8 + 2 * e + 1] = (int)(k1[e] & 0xffff0000u) > 0 ? v[8 + 2 * e + 1] : v[8 + 2 * e + 1] * ms;
+              }
+            }
             u32x4 p0, p1;
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-              p0[e] = pack2<T>(v[2 * e], v[2 * e + 1]);
-              p1[e] = pack2<T>(v[8 + 2 * e], v[8 + 2 * e + 1]);
+              p0[e] = pack2<T>(activate(v[2 * e]), activate(v[2 * e + 1]));
+              p1[e] = pack2<T>(activate(v[8 + 2 * e]), activate(v[8 + 2 * e + 1]));
             }
             *(u32x4*)(outp + off) = p0;
             *(u32x4*)(outp + off + 8) = p1;
           }
-        } else if (ok && !(a.t3_dbg & 1)) {
-          const unsigned off = (unsigned)((oimg * a.FOH + gy) * a.FOW + gx) * (unsigned)a.Cout + (unsigned)co;
-          if (maskp) {   // fused activation backward of the producing layer: dz = dx * act'(y), y = the saved forward input
-            const u32x4 k0 = *(const u32x4*)(maskp + off), k1 = *(const u32x4*)(maskp + off + 8);
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-              v[2 * e] = cvt_lo<T>(k0[e]) > 0.f ? v[2 * e] : v[2 * e] * a.dmask_slope;
-              v[2 * e + 1] = cvt_hi<T>(k0[e]) > 0.f ? v[2 * e + 1] : v[2 * e + 1] * a.dmask_slope;
-              v[8 + 2 * e] = cvt_lo<T>(k1[e]) > 0.f ? v[8 + 2 * e] : v[8 + 2 * e] * a.dmask_slope;
-              v[8 + 2 * e + 1] = cvt_hi<T>(k1[e]) > 0.f ? v[8 + 2 * e + 1] : v[8 + 2 * e + 1] * a.dmask_slope;
-            }
-          }
-          u32x4 p0, p1;
-#pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            const float x0 = v[2 * e], x1 = v[2 * e + 1], y0 = v[8 + 2 * e], y1 = v[8 + 2 * e + 1];
-            p0[e] = pack2<T>(fmaxf(x0, 0.f) + slope * fminf(x0, 0.f), fmaxf(x1, 0.f) + slope * fminf(x1, 0.f));
-            p1[e] = pack2<T>(fmaxf(y0, 0.f) + slope * fminf(y0, 0.f), fmaxf(y1, 0.f) + slope * fminf(y1, 0.f));
-          }
-          *(u32x4*)(outp + off) = p0;
-          *(u32x4*)(outp + off + 8) = p1;
-        }
+        });
       });
-    });
+    };
+    if (a.act == FSR_ACT_RELU) store_tile(std::integral_constant<int, FSR_ACT_RELU>{});
+    else if (a.act == FSR_ACT_LEAKY) store_tile(std::integral_constant<int, FSR_ACT_LEAKY>{});
+    else store_tile(std::integral_constant<int, FSR_ACT_NONE>{});
+    if (!has_nxt) break;
+    // the next tile becomes the current one; its first fragments are already in registers, its pieces in flight
+    cur = nxt;
+#pragma unroll
+    for (int k = 0; k < HPW; ++k) hv_cur[k] = hv_nxt[k];
+    ws_cur = ws_nxt;
     tile = next;
+    next = tile + nround;
+    has_nxt = next < a.t3_ntiles;
+    tpar ^= 1u;
+    acc_init(tpar);
   }
 }
 
 int t3_mode() {
-  const char* e = getenv("FSR_TALL3");   // 0: off (A/B against conv_igemm.hip); 1 (default): on; 2: prefer the 4-wave 128-channel tile
+  // FSR_TALL3: 0 = off (A/B against conv_igemm.hip); 1 (default) = on, 4-wave workgroups of 256 px x 128 channels, two per
+  // CU; 3 = the 8-wave 256 px x 256 channel workgroup (one per CU, persistent) where Cout allows it.  Measured per layer:
+  // the 4-wave form wins on every benched shape but one (profiles/r03_conv_tall3_ab.txt).
+  const char* e = getenv("FSR_TALL3");
   return e ? atoi(e) : 1;
 }
 
@@ -390,10 +435,10 @@ int t3_cus() {
   return cus;
 }
 
-template <typename T, int BN, int NW, int G, int NSLOT>
+template <typename T, int BN, int NW, int G, int NSLOT, int MB>
 int t3_launch(ConvKArgs& a, int wg_per_cu, hipStream_t stream) {
-  auto kern = conv_tall3_kernel<T, BN, NW, G, NSLOT>;
-  constexpr int lds = t3_lds_bytes<BN, G, NSLOT>();
+  auto kern = conv_tall3_kernel<T, BN, NW, G, NSLOT, MB>;
+  constexpr int lds = t3_lds_bytes<BN, G, NSLOT, MB>();
   static bool attr_set = false;
   if (!attr_set) {
     (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
@@ -404,10 +449,13 @@ int t3_launch(ConvKArgs& a, int wg_per_cu, hipStream_t stream) {
   if (ntiles <= 0 || ntiles > 0x7fffffffLL) return 0;
   a.t3_ntiles = (int)ntiles;
   a.t3_dbg = getenv("FSR_T3_DBG") ? atoi(getenv("FSR_T3_DBG")) : 0;
+  // persistent tile walk, wg_per_cu workgroups per CU; FSR_T3_PERSIST=0 launches one workgroup per tile instead (A/B: the
+  // hardware dispatcher balances better, but every tile then pays a cold prologue)
+  static const bool persist = !(getenv("FSR_T3_PERSIST") && atoi(getenv("FSR_T3_PERSIST")) == 0);
   long long grid = (long long)t3_cus() * wg_per_cu;
-  if (grid > ntiles) grid = ntiles;
+  if (grid > ntiles || !persist) grid = ntiles;
   hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(NW * 64), lds, stream, a);
-  fsr_note_kernel("conv_tall3_kernel<%s,%d,%d,%d,%d>", std::is_same<T, f16_t>::value ? "f16" : "bf16", BN, NW, G, NSLOT);
+  fsr_note_kernel("conv_tall3_kernel<%s,%d,%d,%d,%d,%d>", std::is_same<T, f16_t>::value ? "f16" : "bf16", BN, NW, G, NSLOT, MB);
   const int rc = fsr_check_launch("conv_tall3_kernel");
   return rc ? rc : 1;
 }
@@ -421,9 +469,9 @@ int fsr_conv_tall3_try(int dtype, ConvKArgs& a, int S, hipStream_t stream) {
   if (a.Cin < 128 || a.Cin % 32 != 0 || a.Cout % 128 != 0 || a.CoutPad != a.Cout) return 0;
   if (a.stats || a.preact || a.oscale || a.ps || a.in_ps || a.out_f32) return 0;
   if (a.act != FSR_ACT_NONE && a.act != FSR_ACT_RELU && a.act != FSR_ACT_LEAKY) return 0;
+  if (a.act == FSR_ACT_LEAKY && !(a.slope >= 0.f && a.slope <= 1.f)) return 0;   // the epilogue's max(v, slope * v) form
   if (a.osy != 1 || a.osx != 1 || a.ooy != 0 || a.oox != 0 || a.org_y != -1 || a.org_x != -1) return 0;
   if (a.pool2 && (a.dmask || (a.GH & 1) || (a.GW & 1))) return 0;
-  if ((a.GH & 15) > 0 && (a.GH & 15) <= 8 && !(mode & 4)) return 0;    // 24-row maps: half of every second 16-row tile is padding
   if ((long long)a.N * a.IH * a.IW * a.Cin >= (1LL << 31) || (long long)a.N * a.FOH * a.FOW * a.Cout >= (1LL << 31)) return 0;
   // canonical tap order (ky, kx): which filter slice serves the tap that reads halo offset (ky, kx)
   int slice[9];
@@ -437,12 +485,33 @@ int fsr_conv_tall3_try(int dtype, ConvKArgs& a, int S, hipStream_t stream) {
     a.t3_woff[t] = (unsigned)((size_t)slice[t] * a.CoutPad * a.Cin * 2);
   }
   a.tiles_x = (a.GW + 15) / 16;
-  a.tiles_y = (a.GH + 15) / 16;
-  const bool wide = a.Cout % 256 == 0 && !(mode & 2);
-  if (dtype == FSR_F16) {
-    if (wide) return t3_launch<f16_t, 256, 8, 3, 2>(a, 1, stream);
-    return t3_launch<f16_t, 128, 4, 1, 4>(a, 2, stream);
+  const bool wide = a.Cout % 256 == 0 && (mode & 2);
+  // Tile height (16, 12 or 8 rows): the tallest one that pads the map least -- 16 rows everywhere except the 24-row maps
+  // (two 12-row tiles; 16-row tiles would compute 32 rows: measured 906 against 752 TFLOP/s on 512 -> 512 @ 24^2).  Whole
+  // tile rounds do NOT decide: 12-row tiles give 512 -> 512 @ 48^2 exactly 3 rounds instead of 2.25 and still measured
+  // 0..4 % slower -- a workgroup whose partner has finished runs faster alone, and the shorter tile pays more staging per
+  // MFMA (profiles/r03_conv_tall3_ab.txt).  FSR_T3_ROWS forces a height (A/B, tests).
+  int best_mb = 4, best_rows = 1 << 30;
+  const int forced = getenv("FSR_T3_ROWS") ? atoi(getenv("FSR_T3_ROWS")) : 0;
+  for (int mb = 4; mb >= 2; --mb) {
+    const int th = 4 * mb;
+    if (forced && forced != th) continue;
+    const int rows = (a.GH + th - 1) / th * th;
+    if (rows < best_rows) { best_rows = rows; best_mb = mb; }
   }
-  if (wide) return t3_launch<bf16_t, 256, 8, 3, 2>(a, 1, stream);
-  return t3_launch<bf16_t, 128, 4, 1, 4>(a, 2, stream);
+  a.tiles_y = (a.GH + 4 * best_mb - 1) / (4 * best_mb);
+#define T3_GO(TT, MBV)                                                         \
+  do {                                                                         \
+    if (wide) return t3_launch<TT, 256, 8, 3, 2, MBV>(a, 1, stream);           \
+    return t3_launch<TT, 128, 4, 1, 4, MBV>(a, 2, stream);                     \
+  } while (0)
+  if (dtype == FSR_F16) {
+    if (best_mb == 4) T3_GO(f16_t, 4);
+    if (best_mb == 3) T3_GO(f16_t, 3);
+    T3_GO(f16_t, 2);
+  }
+  if (best_mb == 4) T3_GO(bf16_t, 4);
+  if (best_mb == 3) T3_GO(bf16_t, 3);
+  T3_GO(bf16_t, 2);
+#undef T3_GO
 }

@@ -670,13 +670,16 @@ def test_conv_at_bench_shapes_gpu(shape):
 
 
 @pytest.mark.parametrize("cdn", ["bf16", "f16"])
-@pytest.mark.parametrize("cin,cout,variant", [(128, 256, "plain"), (128, 128, "plain"), (160, 256, "mask"), (128, 128, "pool"), (128, 256, "pool")])
-def test_conv_tall3(dev, cdn, cin, cout, variant, monkeypatch):
+@pytest.mark.parametrize("cin,cout,variant,rows", [(128, 256, "plain", 16), (128, 128, "plain", 16), (160, 256, "mask", 12), (128, 128, "pool", 12),
+                                                   (128, 256, "pool", 8), (128, 128, "mask", 8)])
+def test_conv_tall3(dev, cdn, cin, cout, variant, rows, monkeypatch):
     """conv_tall3.hip (32x32x16 MFMA, both operands by LDS-DMA, persistent tiles): forward with bias + ReLU, the fused
     2x2 max-pool, and the data gradient with the fused activation mask, on maps that are not multiples of the 16 x 16 tile
-    and with more tiles than workgroups (FSR_PERSIST_CUS: every workgroup walks several tiles, borders included)."""
+    and with more tiles than workgroups (FSR_PERSIST_CUS: every workgroup walks several tiles -- the DMA stream runs on across
+    tile boundaries -- borders included), for the three tile heights."""
     monkeypatch.setenv("FSR_PERSIST_CUS", "3" if _big(dev) else "1")
-    monkeypatch.setenv("FSR_TALL3", "5")          # also take maps whose last tile row is mostly padding
+    monkeypatch.setenv("FSR_TALL3", "3" if cout == 256 else "1")   # 256 channels: the 8-wave form; 128: the 4-wave form
+    monkeypatch.setenv("FSR_T3_ROWS", str(rows))                    # tile height (the dispatch picks it by tile rounds otherwise)
     cd = ops.Compute(cdn)
     torch.manual_seed(11)
     n, h, w = (3, 50, 44) if _big(dev) else (1, 18, 20)

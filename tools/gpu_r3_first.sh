@@ -1,0 +1,13 @@
+#!/bin/bash
+# round 3, first full pass: GPU test suite, then the bench with the round-2 tall kernel and with conv_tall3
+set -u
+R=$GRAFT_REPO_ROOT
+mkdir -p $R/gpurun_out/r3
+export TMPDIR=/tmp
+cd $R
+timeout 900 python -m pytest tests -m gpu -q -x --timeout=600 > gpurun_out/r3/pytest_gpu.log 2>&1
+tail -5 gpurun_out/r3/pytest_gpu.log
+for m in 0 1 0 1; do
+  FSR_TALL3=$m timeout 300 python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-inference --no-f32 > gpurun_out/r3/bench_tall3_$m.log 2>&1
+  tail -1 gpurun_out/r3/bench_tall3_$m.log | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('FSR_TALL3=$m', d['value'], d['ms_per_step'], d['roofline']['achieved'], d['roofline']['frac'], d['roofline'].get('kernel'))"
+done
