@@ -1,0 +1,162 @@
+"""Does 16-bit training converge like fp32 training?  (Round-2 verdict: "earn the bf16 default or change it".)
+
+Trains the BASELINE cfg #1-size networks (8 residual blocks / 64 filters, full-width VGG19 stand-in, batch 4, 96 -> 384) for
+N iterations of trainer.py:171-196 from IDENTICAL initial weights on IDENTICAL batches of a small learnable synthetic data
+set (low-pass filtered noise images; LR = antialiased-bicubic 4x reduction, dataloader.py:24-38), in
+
+  * the exact-f32 MFMA mode with label-noise seeds 0, 1, 2  -> the fp32 run-to-run BAND (the kernels are bit-reproducible,
+    so the only run-to-run variation real training has is its label noise, trainer.py:175-176,187);
+  * the 16-bit mode(s) with label-noise seed 0.
+
+Reported: the four loss curves (box-smoothed) at checkpoints, PSNR / SSIM of the generator on a fixed held-out batch at the
+end, and for every 16-bit quantity its distance from the fp32 band in units of the band's half-width.
+tests/test_convergence.py runs the same code and gates on it; `python tools/convergence.py` writes the table that is committed
+under profiles/.
+"""
+import importlib
+import json
+import math
+import os
+import sys
+import types
+import warnings
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+LOSSES = ("loss_real", "loss_fake", "adv_loss", "content_loss")
+
+
+def ns(**k):
+    return types.SimpleNamespace(**k)
+
+
+def synthetic_dataset(n_images, hr_size, seed):
+    """Smooth random images in [-1, 1] (sum of low-pass filtered noise octaves): something a 4x super-resolver can learn."""
+    g = torch.Generator().manual_seed(seed)
+    imgs = []
+    for _ in range(n_images):
+        img = torch.zeros(3, hr_size, hr_size)
+        for octave, amp in ((8, 1.0), (16, 0.6), (32, 0.4), (64, 0.25)):
+            noise = torch.randn(1, 3, octave, octave, generator=g)
+            img += amp * torch.nn.functional.interpolate(noise, size=(hr_size, hr_size), mode="bicubic", align_corners=False)[0]
+        img = img / img.abs().amax().clamp_min(1e-6)
+        imgs.append(img.clamp(-1, 1))
+    return torch.stack(imgs)
+
+
+def run(pkg, mode, iters, noise_seed, hr_all, lr_all, hr_eval, lr_eval, batch=4, device="cuda:0", log=None):
+    """One training run; returns {"curves": {loss: [iters floats]}, "psnr": dB, "ssim": mean, "finite": bool}."""
+    ops = importlib.import_module("fast-srgan_amd.ops")
+    cfg = ns(experiment=ns(name="convergence", seed=1234), generator=ns(n_filters=64, n_layers=8), discriminator=ns(n_filters=64, n_layers=7),
+             training=ns(compiled=False, device=device, log_iter=10 ** 9, checkpoint_iter=10 ** 9, generator_lr=1e-4,
+                         discriminator_lr=1e-4, batch_size=batch, compute_dtype=mode))
+    torch.manual_seed(1234)                      # identical initial G / D in every run (parameters are initialised on the host)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        T = pkg.Trainer(cfg, perceptual_network=pkg.VGG19(compute_dtype=mode, seed=1234))
+    order = torch.Generator().manual_seed(99)    # identical batches in every run
+    ng = torch.Generator().manual_seed(1000 + noise_seed)
+    n_img = hr_all.shape[0]
+    hist = []
+    for it in range(iters):
+        idx = torch.randint(0, n_img, (batch,), generator=order)
+        lr, hr = lr_all[idx].to(device), hr_all[idx].to(device)
+        noise = [torch.rand(batch, 1, hr.shape[2] // 16, hr.shape[3] // 16, generator=ng).to(device) for _ in range(3)]
+        out = T.train_step(lr, hr, noise)
+        hist.append(torch.stack([out[k].detach().float().reshape(()) for k in LOSSES]))
+        if log and (it + 1) % 100 == 0:
+            log("  %s seed %d: iteration %d" % (mode, noise_seed, it + 1))
+    hist = torch.stack(hist).cpu()               # the only device -> host read of the training loop
+    with torch.no_grad():
+        T.generator.eval()
+        sr = T.generator(lr_eval.to(device)).float()
+        r = ops.ssim_sse(sr, hr_eval.to(device)).cpu().double()
+    n, c, h, w = hr_eval.shape
+    ssim = float(r[:, 0].sum() / (c * (h - 10) * (w - 10)) / n)
+    mse = float(r[:, 1].sum()) / (n * c * h * w)
+    psnr = 10.0 * math.log10(1.0 / mse) if mse > 0 else float("inf")
+    del T
+    torch.cuda.empty_cache()
+    return {"curves": {k: hist[:, i].tolist() for i, k in enumerate(LOSSES)}, "psnr": psnr, "ssim": ssim,
+            "finite": bool(torch.isfinite(hist).all())}
+
+
+def smooth_at(curve, t, window):
+    lo = max(0, t - window)
+    seg = curve[lo:t]
+    return sum(seg) / len(seg)
+
+
+def compare(results, iters, window=25, every=50):
+    """results: {"f32": [run, run, run], "<16-bit mode>": run, ...}.  Returns rows + the worst band distance per mode."""
+    cps = list(range(every, iters + 1, every))
+    f32 = results["f32"]
+    rows, worst = [], {}
+    for mode, r in results.items():
+        if mode == "f32":
+            continue
+        w = 0.0
+        for k in LOSSES:
+            for t in cps:
+                ref = [smooth_at(x["curves"][k], t, window) for x in f32]
+                lo, hi = min(ref), max(ref)
+                mid, half = 0.5 * (lo + hi), max(0.5 * (hi - lo), 0.02 * abs(0.5 * (lo + hi)), 1e-6)
+                v = smooth_at(r["curves"][k], t, window)
+                dist = abs(v - mid) / half          # 1.0 = on the edge of the fp32 band (band floored at +-2 % of the value)
+                w = max(w, dist)
+                rows.append((mode, k, t, lo, hi, v, dist))
+        for q in ("psnr", "ssim"):
+            ref = [x[q] for x in f32]
+            lo, hi = min(ref), max(ref)
+            floor = 0.1 if q == "psnr" else 0.002
+            mid, half = 0.5 * (lo + hi), max(0.5 * (hi - lo), floor)
+            dist = abs(r[q] - mid) / half
+            w = max(w, dist)
+            rows.append((mode, q, iters, lo, hi, r[q], dist))
+        worst[mode] = w
+    return rows, worst
+
+
+def main(iters=300, modes=("bf16", "f16"), out_json=None, log=print):
+    pkg = importlib.import_module("fast-srgan_amd")
+    pkg._lib.lib()
+
+    def reduce4(x):   # dataloader.py:34's v2.Resize on a float tensor = torch's antialiased bicubic interpolate
+        return torch.nn.functional.interpolate(x, size=(96, 96), mode="bicubic", antialias=True, align_corners=False)
+
+    hr_all = synthetic_dataset(16, 384, seed=7)
+    lr_all = reduce4(hr_all)
+    hr_eval = synthetic_dataset(8, 384, seed=8)
+    lr_eval = reduce4(hr_eval)
+    results = {"f32": []}
+    for seed in (0, 1, 2):
+        log("f32, label-noise seed %d" % seed)
+        results["f32"].append(run(pkg, "f32", iters, seed, hr_all, lr_all, hr_eval, lr_eval, log=log))
+    for mode in modes:
+        log("%s, label-noise seed 0" % mode)
+        results[mode] = run(pkg, mode, iters, 0, hr_all, lr_all, hr_eval, lr_eval, log=log)
+    rows, worst = compare(results, iters)
+    log("")
+    log("%-5s %-13s %5s   %-25s %10s   %s" % ("mode", "quantity", "iter", "fp32 band (3 noise seeds)", "16-bit", "distance / half-width"))
+    for mode, k, t, lo, hi, v, dist in rows:
+        log("%-5s %-13s %5d   [%10.5f, %10.5f]   %10.5f   %.2f" % (mode, k, t, lo, hi, v, dist))
+    for mode, w in worst.items():
+        log("worst distance from the fp32 band, %s: %.2f half-widths" % (mode, w))
+    log("final PSNR / SSIM on the held-out batch: f32 %s, %s" % (
+        ", ".join("%.3f dB / %.4f" % (x["psnr"], x["ssim"]) for x in results["f32"]),
+        ", ".join("%s %.3f dB / %.4f" % (m, results[m]["psnr"], results[m]["ssim"]) for m in modes)))
+    if out_json:
+        slim = {m: ([{k: v for k, v in x.items() if k != "curves"} for x in r] if isinstance(r, list) else {k: v for k, v in r.items() if k != "curves"})
+                for m, r in results.items()}
+        json.dump({"iters": iters, "summary": slim, "worst_band_distance": worst,
+                   "rows": [dict(mode=a, quantity=b, iteration=c, f32_lo=d, f32_hi=e, value=f, distance=g) for a, b, c, d, e, f, g in rows]},
+                  open(out_json, "w"), indent=1)
+    return results, rows, worst
+
+
+if __name__ == "__main__":
+    n = int(sys.argv[1]) if len(sys.argv) > 1 else 300
+    main(n, out_json=sys.argv[2] if len(sys.argv) > 2 else None)

@@ -11,7 +11,7 @@ cfg = ns(experiment=ns(name="sanity", seed=1), generator=ns(n_filters=64, n_laye
                      discriminator_lr=1e-4, batch_size=B, compute_dtype="bf16"))
 with warnings.catch_warnings():
     warnings.simplefilter("ignore")
-    T = pkg.Trainer(cfg)
+    T = pkg.Trainer(cfg, perceptual_network=pkg.VGG19(compute_dtype="bf16", seed=1234))   # kaiming-normal stand-in (no ImageNet weights offline)
 torch.manual_seed(0)
 hr = torch.rand(B, 3, 384, 384, device="cuda:0") * 2 - 1
 lr = torch.nn.functional.avg_pool2d(hr, 4)
