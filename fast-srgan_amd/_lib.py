@@ -17,7 +17,7 @@ ACT_NONE, ACT_RELU, ACT_LEAKY, ACT_PRELU, ACT_TANH = 0, 1, 2, 3, 4
 CONV_FWD, CONV_DGRAD = 0, 1
 PACK_FWD, PACK_FWD_PS, PACK_DGRAD, PACK_DGRAD_PS = 0, 1, 2, 3
 OUT_DTYPE, OUT_F32, OUT_U8 = 0, 1, 2
-ABI_VERSION = 7
+ABI_VERSION = 8
 
 c_int, c_float, c_void_p, c_size_t, c_ll = ctypes.c_int, ctypes.c_float, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_longlong
 
@@ -88,6 +88,9 @@ SIGNATURES = {
     "fsr_ssim_sse_scratch": (c_size_t, [c_int, c_int, c_int]),
     "fsr_ssim_sse": (c_int, [P, c_ll, c_ll, c_ll, c_ll, P, c_ll, c_ll, c_ll, c_ll, c_int, c_int, c_int, P, P, P]),
     "fsr_adamw_step": (c_int, [P, P, P, P, c_ll, c_float, c_float, c_float, c_float, c_float, P, c_float, P]),
+    "fsr_grad_nonfinite": (c_int, [P, c_ll, P, P]),
+    "fsr_adamw_step_scaled": (c_int, [P, P, P, P, c_ll, c_float, c_float, c_float, c_float, c_float, P, c_float, P, P]),
+    "fsr_loss_scale_update": (c_int, [P, c_float, c_float, c_float, P]),
     "fsr_crop_resize": (c_int, [P, P, P, P, P, c_int, c_int, c_int, P, P, P, c_int, P, P, P, P]),
 }
 

@@ -204,7 +204,85 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const
   }
 }
 
+// ---- dynamic loss scaling (fp16 mode).  state: float[4] on the device = {scale, clean steps, non-finite flag, skipped steps}.
+// Everything is decided on the device, so a captured hipGraph keeps adapting while it replays.
+__global__ __launch_bounds__(256) void grad_nonfinite_kernel(const float* __restrict__ g, long long count, float* __restrict__ state) {
+  bool bad = false;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < count; i += (long long)gridDim.x * 256) {
+    const float x = g[i];
+    bad |= !(fabsf(x) <= 3.0e38f);   // inf or NaN
+  }
+  if (bad) state[2] = 1.f;           // every writer stores the same value: no atomic needed
+}
+
+__global__ __launch_bounds__(256) void adamw_scaled_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                                                           float* __restrict__ v, long long count, float lr, float b1, float b2,
+                                                           float eps, float wd, float* __restrict__ step, float gscale,
+                                                           const float* __restrict__ state) {
+  if (state[2] != 0.f) return;       // a gradient overflowed somewhere: no update at all, moments and step count untouched
+  const float t = step[0] + 1.f;     // (the step counter is advanced by adamw_tick_if_clean_kernel, enqueued behind this kernel)
+  const float gs = gscale / state[0];
+  const float bc1 = 1.f - powf(b1, t);
+  const float rsqrt_bc2 = 1.f / sqrtf(1.f - powf(b2, t));
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < count; i += (long long)gridDim.x * 256) {
+    const float gi = g[i] * gs;
+    float pi = p[i] * (1.f - lr * wd);
+    const float mi = m[i] + (gi - m[i]) * (1.f - b1);
+    const float vi = v[i] * b2 + (1.f - b2) * gi * gi;
+    m[i] = mi;
+    v[i] = vi;
+    const float denom = sqrtf(vi) * rsqrt_bc2 + eps;
+    pi -= (lr / bc1) * (mi / denom);
+    p[i] = pi;
+  }
+}
+__global__ void adamw_tick_if_clean_kernel(float* __restrict__ step, const float* __restrict__ state) {
+  if (threadIdx.x == 0 && state[2] == 0.f) step[0] += 1.f;
+}
+__global__ void loss_scale_update_kernel(float* __restrict__ state, float growth_interval, float growth, float backoff) {
+  if (threadIdx.x != 0) return;
+  if (state[2] != 0.f) {             // overflow in this iteration: back off, start counting again
+    state[0] = fmaxf(state[0] * backoff, 1.f);
+    state[1] = 0.f;
+    state[3] += 1.f;
+    state[2] = 0.f;
+  } else {
+    state[1] += 1.f;
+    if (state[1] >= growth_interval) {
+      state[0] = fminf(state[0] * growth, 16777216.f);
+      state[1] = 0.f;
+    }
+  }
+}
+
 }  // namespace
+
+extern "C" int fsr_grad_nonfinite(const float* g, long long count, float* scale_state, fsr_stream_t stream_) {
+  if (!g || !scale_state || count <= 0) return fsr_fail(-1, "fsr_grad_nonfinite: bad argument");
+  long long blocks = (count + 256 * 8 - 1) / (256 * 8);
+  if (blocks > 1024) blocks = 1024;
+  hipLaunchKernelGGL(grad_nonfinite_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream_, g, count, scale_state);
+  return fsr_check_launch("grad_nonfinite_kernel");
+}
+
+extern "C" int fsr_adamw_step_scaled(float* p, const float* g, float* m, float* v, long long count, float lr, float beta1,
+                                     float beta2, float eps, float weight_decay, float* step_counter, float grad_scale,
+                                     const float* scale_state, fsr_stream_t stream_) {
+  if (!p || !g || !m || !v || !step_counter || !scale_state || count <= 0) return fsr_fail(-1, "fsr_adamw_step_scaled: bad argument");
+  long long blocks = (count + 256 * 4 - 1) / (256 * 4);
+  if (blocks > 2048) blocks = 2048;
+  hipLaunchKernelGGL(adamw_scaled_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream_, p, g, m, v, count, lr, beta1,
+                     beta2, eps, weight_decay, step_counter, grad_scale, scale_state);
+  hipLaunchKernelGGL(adamw_tick_if_clean_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream_, step_counter, scale_state);
+  return fsr_check_launch("adamw_scaled_kernel");
+}
+
+extern "C" int fsr_loss_scale_update(float* scale_state, float growth_interval, float growth, float backoff, fsr_stream_t stream_) {
+  if (!scale_state || !(growth_interval >= 1.f) || !(growth >= 1.f) || !(backoff > 0.f && backoff <= 1.f))
+    return fsr_fail(-1, "fsr_loss_scale_update: bad argument");
+  hipLaunchKernelGGL(loss_scale_update_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream_, scale_state, growth_interval, growth, backoff);
+  return fsr_check_launch("loss_scale_update_kernel");
+}
 
 extern "C" size_t fsr_loss_scratch(void) { return 1024 * sizeof(float); }   // red_blocks() caps the grid at 1024 workgroups
 

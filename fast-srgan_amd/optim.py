@@ -29,6 +29,11 @@ class ArenaAdamW(torch.optim.Optimizer):
         self.step_dev = torch.zeros(1, dtype=torch.float32, device=dev)   # device-side step counter (graph-replay safe)
         self._epoch = 0
         self.grad_scale = 1.0  # set to 1/world_size when gradients are SUM all-reduced
+        # Dynamic loss scaling (fp16 mode, Trainer): device float[4] {scale, clean iterations, non-finite flag, skipped
+        # iterations}.  When set, step() first checks the gradient arena for inf / NaN and the update divides by the scale on
+        # the device -- or does nothing at all while the flag is up (a single overflow would otherwise poison exp_avg,
+        # exp_avg_sq and the parameters for good, silently, under hipGraph replay).
+        self.scale_state = None
         off = 0
         self._slices = []
         for p in params:
@@ -53,10 +58,18 @@ class ArenaAdamW(torch.optim.Optimizer):
             raise L.FsrError("ArenaAdamW does not take a closure")
         g = self.param_groups[0]
         self._epoch += 1
-        L.check(L.lib().fsr_adamw_step(_p(self.flat_param), _p(self.flat_grad), _p(self.exp_avg), _p(self.exp_avg_sq),
-                                       self.flat_param.numel(), float(g["lr"]), float(g["betas"][0]), float(g["betas"][1]),
-                                       float(g["eps"]), float(g["weight_decay"]), _p(self.step_dev), float(self.grad_scale),
-                                       _stream()), "fsr_adamw_step")
+        if self.scale_state is not None:
+            L.check(L.lib().fsr_grad_nonfinite(_p(self.flat_grad), self.flat_grad.numel(), _p(self.scale_state), _stream()),
+                    "fsr_grad_nonfinite")
+            L.check(L.lib().fsr_adamw_step_scaled(_p(self.flat_param), _p(self.flat_grad), _p(self.exp_avg), _p(self.exp_avg_sq),
+                                                  self.flat_param.numel(), float(g["lr"]), float(g["betas"][0]), float(g["betas"][1]),
+                                                  float(g["eps"]), float(g["weight_decay"]), _p(self.step_dev),
+                                                  float(self.grad_scale), _p(self.scale_state), _stream()), "fsr_adamw_step_scaled")
+        else:
+            L.check(L.lib().fsr_adamw_step(_p(self.flat_param), _p(self.flat_grad), _p(self.exp_avg), _p(self.exp_avg_sq),
+                                           self.flat_param.numel(), float(g["lr"]), float(g["betas"][0]), float(g["betas"][1]),
+                                           float(g["eps"]), float(g["weight_decay"]), _p(self.step_dev), float(self.grad_scale),
+                                           _stream()), "fsr_adamw_step")
         # the kernel writes through raw pointers, so torch's version counters do not move: publish an
         # epoch the packed-filter cache (ops.packed_filter) keys on instead
         for p in self._params:

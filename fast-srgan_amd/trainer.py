@@ -74,14 +74,31 @@ class Trainer:
         D.broadcast_parameters(self.optim_discriminator)
         self._sync_g = D.GradSync(self.optim_generator)
         self._sync_d = D.GradSync(self.optim_discriminator)
-        # Static loss scaling (extension key training.loss_scale; default 1, 16384 in the fp16 mode): both backward passes are
-        # seeded with S and AdamW divides the gradients by S again.  fp16 activation gradients need it: the content loss is a
-        # mean over N x 512 x 24 x 24 values, its per-element gradient (~4e-8) lies below the smallest fp16 subnormal.  bf16 and
-        # f32 share float32's exponent range and run unscaled.
-        self.loss_scale = float(getattr(config.training, "loss_scale", 16384.0 if cdt == "f16" else 1.0))
-        self._seed = torch.tensor(self.loss_scale, dtype=torch.float32, device=dev) if self.loss_scale != 1.0 else None
-        for opt in (self.optim_generator, self.optim_discriminator):
-            opt.grad_scale = opt.grad_scale / self.loss_scale
+        # Loss scaling (extension keys training.loss_scale, training.dynamic_loss_scale; defaults 1 / off, and 2^20 / on in
+        # the fp16 mode): both backward passes are seeded with S and AdamW divides the gradients by S again.  fp16 activation
+        # gradients need it: the content loss is a mean over N x 512 x 24 x 24 values, its per-element gradient (~4e-8) lies
+        # below the smallest fp16 subnormal.  bf16 and f32 share float32's exponent range and run unscaled.
+        # Dynamic (the fp16 default): S lives on the device; every optimizer step checks its gradient arena for inf / NaN
+        # and skips the update when it finds one, the iteration then halves S, and 1000 clean iterations double it
+        # (fsr_grad_nonfinite / fsr_adamw_step_scaled / fsr_loss_scale_update: decided on the device, so hipGraph replays adapt).
+        # The initial 2^20 is measured (tools/f16_scale_probe.py, profiles/r03_f16_loss_scale.txt): at 2^14 nothing overflows
+        # but part of the perceptual gradient underflows and 300 iterations end with a content loss 5-10x the fp32 runs';
+        # 2^20 .. 2^22 track fp32; 2^26 overflows, is halved four times in the first iterations and then tracks fp32 too.
+        self.loss_scale = float(getattr(config.training, "loss_scale", 1048576.0 if cdt == "f16" else 1.0))
+        if not (self.loss_scale > 0.0 and self.loss_scale == self.loss_scale and self.loss_scale != float("inf")):
+            raise ValueError("training.loss_scale must be a positive finite number, got %r" % (self.loss_scale,))
+        self.dynamic_loss_scale = bool(getattr(config.training, "dynamic_loss_scale", cdt == "f16"))
+        self.loss_scale_growth_interval = float(getattr(config.training, "loss_scale_growth_interval", 1000))
+        self._scale_state = None
+        if self.dynamic_loss_scale:
+            self._scale_state = torch.tensor([self.loss_scale, 0.0, 0.0, 0.0], dtype=torch.float32, device=dev)
+            self._seed = self._scale_state[0]          # a 0-dim VIEW: the next backward is seeded with whatever S has become
+            for opt in (self.optim_generator, self.optim_discriminator):
+                opt.scale_state = self._scale_state
+        else:
+            self._seed = torch.tensor(self.loss_scale, dtype=torch.float32, device=dev) if self.loss_scale != 1.0 else None
+            for opt in (self.optim_generator, self.optim_discriminator):
+                opt.grad_scale = opt.grad_scale / self.loss_scale
         self._streams = {}
         self.use_side_stream = os.environ.get("FSR_SIDE_STREAM", "1") != "0"
         self.loss_fn = ops.bce_with_logits      # torch.nn.BCEWithLogitsLoss(), trainer.py:41
@@ -190,8 +207,22 @@ class Trainer:
         ops.wgrad_stream_join()
         st["adv"] = adv_loss
 
+    def _update_loss_scale(self):
+        if self._scale_state is not None:
+            from . import _lib as L
+            L.check(L.lib().fsr_loss_scale_update(ops._p(self._scale_state), self.loss_scale_growth_interval, 2.0, 0.5, ops._stream()),
+                    "fsr_loss_scale_update")
+
+    def loss_scale_state(self):
+        """(current loss scale, skipped iterations) -- a host read; None when the scale is static."""
+        if self._scale_state is None:
+            return None
+        v = self._scale_state.detach().cpu()
+        return float(v[0]), int(v[3])
+
     def _phase_end(self, st):
         self.optim_generator.step()                                             # :196
+        self._update_loss_scale()
         # the loss scalars live in the per-iteration scratch arena: copy them out (one launch) so they survive the next reset
         vals = torch.stack([st["loss_real"].detach(), st["loss_fake"].detach(), st["adv"].detach(), st["content"].detach()])
         return dict(zip(("loss_real", "loss_fake", "adv_loss", "content_loss"), vals.unbind(0)))
@@ -275,6 +306,7 @@ class Trainer:
             gen_loss.backward(self._seed)
             self._sync_g.run()
             self.optim_generator.step()
+            self._update_loss_scale()
             return gen_loss.detach().clone()
         finally:
             ops.zero_pool_end(lr_images.device)

@@ -38,7 +38,7 @@
 extern "C" {
 #endif
 
-#define FSR_ABI_VERSION 7
+#define FSR_ABI_VERSION 8
 
 enum { FSR_F32 = 0, FSR_BF16 = 1, FSR_F16 = 2 };
 enum { FSR_ACT_NONE = 0, FSR_ACT_RELU = 1, FSR_ACT_LEAKY = 2, FSR_ACT_PRELU = 3, FSR_ACT_TANH = 4 };
@@ -277,6 +277,22 @@ int fsr_ssim_sse(const float* a, long long asn, long long asc, long long ash, lo
  * bias corrections bc1 = 1 - beta1^t, bc2 = 1 - beta2^t from it (host-free, so a captured hipGraph replays). */
 int fsr_adamw_step(float* p, const float* g, float* m, float* v, long long count, float lr, float beta1, float beta2,
                    float eps, float weight_decay, float* step_counter, float grad_scale, fsr_stream_t stream);
+
+/* Dynamic loss scaling for the fp16 mode (no counterpart in the reference, which trains in fp32, trainer.py:33-43; the shape is
+ * torch.cuda.amp.GradScaler's).  scale_state: DEVICE float[4] = {loss scale S, clean iterations, non-finite flag, skipped
+ * iterations}; the backward passes are seeded with S (the caller reads scale_state[0] on the device).
+ *   fsr_grad_nonfinite     raises the flag if any of the `count` gradients is inf / NaN (after the gradient all-reduce, so
+ *                          every rank decides alike);
+ *   fsr_adamw_step_scaled  fsr_adamw_step with g' = g*grad_scale/S -- and NO update at all (parameters, moments and step
+ *                          counter untouched) while the flag is up;
+ *   fsr_loss_scale_update  once per iteration, after the last optimizer step: flag up -> S *= backoff (>= 1), counters reset,
+ *                          flag cleared; else after `growth_interval` clean iterations S *= growth.
+ * All decisions are taken on the device: a captured hipGraph keeps adapting while it replays. */
+int fsr_grad_nonfinite(const float* g, long long count, float* scale_state, fsr_stream_t stream);
+int fsr_adamw_step_scaled(float* p, const float* g, float* m, float* v, long long count, float lr, float beta1, float beta2,
+                          float eps, float weight_decay, float* step_counter, float grad_scale, const float* scale_state,
+                          fsr_stream_t stream);
+int fsr_loss_scale_update(float* scale_state, float growth_interval, float growth, float backoff, fsr_stream_t stream);
 
 /* ------------------------------------------------------------------ crop + antialiased bicubic down-scale (dataloader.py:24-38)
  * For each of `n` samples: crop hr_size x hr_size at (crop_y[i], crop_x[i]) from the uint8 CHW image

@@ -70,13 +70,15 @@ def report(name, value):
     return value
 
 
-def check_grads(prefix, named, ref, t_tensor, t_slope=0.25, t_cos=None):
+def check_grads(prefix, named, ref, t_tensor, t_slope=0.25, t_cos=None, t_norm=None):
     """Gradient gates of the network-level tests.  `named`: [(name, gradient)], `ref`: {name: reference gradient}.
       * tensors (filters, biases): relative L2 error < t_tensor (relerr2 explains why not max-norm);
       * the single PReLU slopes: each is ONE cancelling sum over a whole layer (the fp32 oracle itself moves some of them by
         more than 100 % between float32 and float64, tests/conditioning_probe.py), so they are held to |error| < t_slope x
         the largest slope gradient of the network instead of their own magnitude;
-      * t_cos: lower bound of the cosine between all tensor gradients concatenated and the reference.
+      * t_cos: lower bound of the cosine between all tensor gradients concatenated and the reference;
+      * t_norm = (lo, hi): bounds of every tensor's norm ratio |g| / |reference| (a scaled or vanishing gradient passes an
+        L2 gate of tens of per cent unnoticed).
     Every value goes to gpurun_out/parity_errors.log.  Returns the list of violations."""
     named = list(named)
     bad = []
@@ -94,7 +96,9 @@ def check_grads(prefix, named, ref, t_tensor, t_slope=0.25, t_cos=None):
         if not e < t_tensor:
             bad.append((n, e))
         a, b = g.detach().double().cpu().reshape(-1), r.detach().double().cpu().reshape(-1)
-        report("%s.normratio.%s" % (prefix, n), float(a.norm() / b.norm().clamp_min(1e-300)))
+        nr = report("%s.normratio.%s" % (prefix, n), float(a.norm() / b.norm().clamp_min(1e-300)))
+        if t_norm is not None and not (t_norm[0] < nr < t_norm[1]):
+            bad.append((n, "normratio", nr))
         dot, na, nb = dot + float(a @ b), na + float(a @ a), nb + float(b @ b)
     cos = report("%s.cosine" % prefix, dot / max((na * nb) ** 0.5, 1e-300))
     if t_cos is not None and not cos > t_cos:

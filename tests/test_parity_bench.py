@@ -34,8 +34,16 @@ VGGQ_OUT, VGGQ_DX, VGG_BF16_OUT, VGG_BF16_DX = 1.2e-2, 0.45, 2e-2, 0.7
 #    the gradients are as far apart as two bf16 evaluations of this network that differ in fp32 summation order are (one bf16
 #    ulp in 0.02 % of the activations after the second discriminator block has become a difference in 67 % of them after the
 #    seventh, with 0.1 % LeakyReLU(0.01) sign flips per layer -- tests/conditioning_probe.py).
-STEPQ_LOSS, STEPQ_D_GRAD, STEPQ_G_GRAD, STEPQ_COS_D, STEPQ_COS_G = 1e-3, 0.7, 0.75, 0.98, 0.85
-STEP_BF16_LOSS, STEP_BF16_GRAD, STEP_BF16_COS = 5e-3, 1.0, 0.8
+#    Round 3 (verdict: "a 100 % L2 gate is not a test"): the gates below are 1.4-1.6x the values measured on the MI355X with the
+#    round-3 kernels (gpurun_out/parity_errors.log, copied to profiles/r03_parity_errors.log) -- per network, with the norm ratio
+#    of every tensor and the PReLU slopes bounded as well:
+#      vs the bf16-storage oracle: D tensors <= 0.479, G tensors <= 0.492, cosines 0.9954 (D) / 0.905 (G), slopes <= 0.076;
+#      vs the plain fp32 oracle:   D tensors <= 0.370, G tensors <= 0.522, cosine 0.992, slopes <= 0.0013, norm ratios 0.97-1.05.
+#    What holds the 16-bit mode to the reference beyond single-iteration gradients is tests/test_convergence.py (300 iterations
+#    of f32 against bf16 / f16 training from one initialisation).
+STEPQ_LOSS, STEPQ_D_GRAD, STEPQ_G_GRAD, STEPQ_COS_D, STEPQ_COS_G, STEPQ_SLOPE = 1e-3, 0.7, 0.7, 0.99, 0.85, 0.15
+STEP_BF16_LOSS, STEP_BF16_D_GRAD, STEP_BF16_G_GRAD, STEP_BF16_COS, STEP_BF16_SLOPE = 4e-3, 0.55, 0.75, 0.984, 0.01
+STEP_NORM = (0.88, 1.14)
 INF_BF16_MEAN, INF_BF16_MAX = 6e-3, 7e-2
 
 
@@ -117,12 +125,14 @@ def test_train_step_at_baseline_cfg1_size(pkg, cdn):
         return
     want, ref = oracle(O.Q_BF16)
     losses("bf16q", want, STEPQ_LOSS)
-    bad = check_grads("cfg1.bf16q.grad", named_d, ref, t_tensor=STEPQ_D_GRAD, t_slope=0.35, t_cos=STEPQ_COS_D)
-    bad += check_grads("cfg1.bf16q.grad", named_g, ref, t_tensor=STEPQ_G_GRAD, t_slope=0.35, t_cos=STEPQ_COS_G)
+    bad = check_grads("cfg1.bf16q.grad", named_d, ref, t_tensor=STEPQ_D_GRAD, t_slope=STEPQ_SLOPE, t_cos=STEPQ_COS_D, t_norm=STEP_NORM)
+    bad += check_grads("cfg1.bf16q.grad", named_g, ref, t_tensor=STEPQ_G_GRAD, t_slope=STEPQ_SLOPE, t_cos=STEPQ_COS_G, t_norm=STEP_NORM)
     assert not bad, bad
     want, ref = oracle(None)
     losses("bf16", want, STEP_BF16_LOSS)
-    bad = check_grads("cfg1.bf16.grad", named_d + named_g, ref, t_tensor=STEP_BF16_GRAD, t_slope=1.0, t_cos=STEP_BF16_COS)
+    bad = check_grads("cfg1.bf16.grad", named_d, ref, t_tensor=STEP_BF16_D_GRAD, t_slope=STEP_BF16_SLOPE, t_norm=STEP_NORM)
+    bad += check_grads("cfg1.bf16.grad", named_g, ref, t_tensor=STEP_BF16_G_GRAD, t_slope=STEP_BF16_SLOPE, t_norm=STEP_NORM)
+    bad += check_grads("cfg1.bf16.grad.all", named_d + named_g, ref, t_tensor=STEP_BF16_G_GRAD, t_slope=STEP_BF16_SLOPE, t_cos=STEP_BF16_COS)
     assert not bad, bad
 
 

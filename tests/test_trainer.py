@@ -163,6 +163,65 @@ def test_arena_adamw_matches_torch(pkg):
     assert set(sd["state"][0]) == {"step", "exp_avg", "exp_avg_sq"} and sd["state"][0]["exp_avg"].shape == (5, 4, 3, 3)
 
 
+def test_dynamic_loss_scale_skips_overflowed_steps(pkg):
+    """fp16-mode loss scaling (one overflow must not poison the moments for good): with a device-side scale
+    state, a step whose gradient arena holds an inf / NaN changes NOTHING and halves the scale; clean steps divide by the
+    scale on the device and match torch.optim.AdamW on the unscaled gradients; enough clean iterations double the scale."""
+    import ctypes
+    dev = select("emu")
+    L = __import__("importlib").import_module("fast-srgan_amd._lib")
+    ops = __import__("importlib").import_module("fast-srgan_amd.ops")
+    torch.manual_seed(3)
+    ps = [torch.nn.Parameter(torch.randn(6, 4, 3, 3)), torch.nn.Parameter(torch.randn(9))]
+    ref = [torch.nn.Parameter(p.detach().clone()) for p in ps]
+    opt, ropt = pkg.ArenaAdamW(ps, lr=1e-3), torch.optim.AdamW(ref, lr=1e-3)
+    state = torch.tensor([1024.0, 0.0, 0.0, 0.0])
+    opt.scale_state = state
+
+    def iteration(poison):
+        opt.zero_grad()
+        ropt.zero_grad()
+        for p, r in zip(ps, ref):
+            g = torch.randn_like(p)
+            p.grad.add_(g * float(state[0]))        # what a backward pass seeded with the scale leaves in the arena
+            r.grad = g.clone()
+        if poison:
+            ps[0].grad.view(-1)[5] = poison
+        before = [t.clone() for t in (opt.flat_param, opt.exp_avg, opt.exp_avg_sq, opt.step_dev)]
+        opt.step()
+        L.check(L.lib().fsr_loss_scale_update(ops._p(state), 3.0, 2.0, 0.5, None), "fsr_loss_scale_update")
+        return before
+
+    iteration(None)
+    ropt.step()
+    for p, r in zip(ps, ref):
+        assert (p.detach() - r.detach()).abs().max() < 1e-6
+    assert state.tolist() == [1024.0, 1.0, 0.0, 0.0]
+    for poison in (float("inf"), float("nan")):
+        before = iteration(poison)
+        for a, b in zip(before, (opt.flat_param, opt.exp_avg, opt.exp_avg_sq, opt.step_dev)):
+            assert torch.equal(a, b)                # nothing moved, the step counter included
+    assert state.tolist() == [256.0, 0.0, 0.0, 2.0]
+    for _ in range(3):                              # growth_interval = 3 clean iterations -> the scale doubles
+        iteration(None)
+        ropt.step()
+    assert state.tolist() == [512.0, 0.0, 0.0, 2.0]
+    for p, r in zip(ps, ref):
+        assert (p.detach() - r.detach()).abs().max() < 1e-6
+
+
+def test_trainer_rejects_bad_loss_scale(pkg):
+    select("emu")
+    import types
+    ns = types.SimpleNamespace
+    for bad in (0.0, -4.0, float("nan")):
+        cfg = ns(experiment=ns(name="t", seed=1), generator=ns(n_filters=16, n_layers=1), discriminator=ns(n_filters=16, n_layers=7),
+                 training=ns(compiled=False, device="cpu", log_iter=1, checkpoint_iter=10 ** 9, generator_lr=1e-4, discriminator_lr=1e-4,
+                             batch_size=1, compute_dtype="f16", loss_scale=bad))
+        with pytest.raises(ValueError):
+            pkg.Trainer(cfg, perceptual_network=pkg.VGG19(compute_dtype="f16", width_div=8, seed=1))
+
+
 @pytest.mark.gpu
 def test_device_crop_pipeline_full_size_gpu(pkg, tmp_path):
     """NumpyImagesDataset at the bench geometry (96 -> 384 crops of 2K-wide images) on the HIP kernels vs the oracle's

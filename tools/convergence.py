@@ -1,7 +1,8 @@
 """Does 16-bit training converge like fp32 training?  (Round-2 verdict: "earn the bf16 default or change it".)
 
 Trains the BASELINE cfg #1-size networks (8 residual blocks / 64 filters, full-width VGG19 stand-in, batch 4, 96 -> 384) for
-N iterations of trainer.py:171-196 from IDENTICAL initial weights on IDENTICAL batches of a small learnable synthetic data
+P iterations of generator pre-training (trainer.py:107-111, the phase train.py:115 runs first) and then N iterations of the GAN
+step trainer.py:171-196, from IDENTICAL initial weights on IDENTICAL batches of a small learnable synthetic data
 set (low-pass filtered noise images; LR = antialiased-bicubic 4x reduction, dataloader.py:24-38), in
 
   * the exact-f32 MFMA mode with label-noise seeds 0, 1, 2  -> the fp32 run-to-run BAND (the kernels are bit-reproducible,
@@ -47,12 +48,14 @@ def synthetic_dataset(n_images, hr_size, seed):
     return torch.stack(imgs)
 
 
-def run(pkg, mode, iters, noise_seed, hr_all, lr_all, hr_eval, lr_eval, batch=4, device="cuda:0", log=None):
+def run(pkg, mode, iters, noise_seed, hr_all, lr_all, hr_eval, lr_eval, batch=4, device="cuda:0", log=None, pre_iters=100):
     """One training run; returns {"curves": {loss: [iters floats]}, "psnr": dB, "ssim": mean, "finite": bool}."""
     ops = importlib.import_module("fast-srgan_amd.ops")
     cfg = ns(experiment=ns(name="convergence", seed=1234), generator=ns(n_filters=64, n_layers=8), discriminator=ns(n_filters=64, n_layers=7),
              training=ns(compiled=False, device=device, log_iter=10 ** 9, checkpoint_iter=10 ** 9, generator_lr=1e-4,
                          discriminator_lr=1e-4, batch_size=batch, compute_dtype=mode))
+    if os.environ.get("CONV_LOSS_SCALE"):        # diagnostic: static loss scale of the 16-bit modes (training.loss_scale)
+        cfg.training.loss_scale = float(os.environ["CONV_LOSS_SCALE"])
     torch.manual_seed(1234)                      # identical initial G / D in every run (parameters are initialised on the host)
     with warnings.catch_warnings():
         warnings.simplefilter("ignore")
@@ -60,6 +63,10 @@ def run(pkg, mode, iters, noise_seed, hr_all, lr_all, hr_eval, lr_eval, batch=4,
     order = torch.Generator().manual_seed(99)    # identical batches in every run
     ng = torch.Generator().manual_seed(1000 + noise_seed)
     n_img = hr_all.shape[0]
+    pre = []
+    for it in range(pre_iters):                  # trainer.py:107-111: pixel SmoothL1 only (no label noise: identical in every f32 run)
+        idx = torch.randint(0, n_img, (batch,), generator=order)
+        pre.append(T.pretrain_step(lr_all[idx].to(device), hr_all[idx].to(device)).detach().float().reshape(()))
     hist = []
     for it in range(iters):
         idx = torch.randint(0, n_img, (batch,), generator=order)
@@ -78,10 +85,13 @@ def run(pkg, mode, iters, noise_seed, hr_all, lr_all, hr_eval, lr_eval, batch=4,
     ssim = float(r[:, 0].sum() / (c * (h - 10) * (w - 10)) / n)
     mse = float(r[:, 1].sum()) / (n * c * h * w)
     psnr = 10.0 * math.log10(1.0 / mse) if mse > 0 else float("inf")
+    scale_state = T.loss_scale_state()           # (final loss scale, skipped iterations) of the dynamic fp16 scaler, else None
     del T
     torch.cuda.empty_cache()
-    return {"curves": {k: hist[:, i].tolist() for i, k in enumerate(LOSSES)}, "psnr": psnr, "ssim": ssim,
-            "finite": bool(torch.isfinite(hist).all())}
+    curves = {k: hist[:, i].tolist() for i, k in enumerate(LOSSES)}
+    if pre:
+        curves["pretrain_loss"] = torch.stack(pre).cpu().tolist()
+    return {"curves": curves, "psnr": psnr, "ssim": ssim, "finite": bool(torch.isfinite(hist).all()), "loss_scale": scale_state}
 
 
 def smooth_at(curve, t, window):
@@ -99,8 +109,9 @@ def compare(results, iters, window=25, every=50):
         if mode == "f32":
             continue
         w = 0.0
-        for k in LOSSES:
-            for t in cps:
+        keys = list(LOSSES) + (["pretrain_loss"] if "pretrain_loss" in r["curves"] else [])
+        for k in keys:
+            for t in (cps if k != "pretrain_loss" else [c for c in cps if c <= len(r["curves"][k])]):
                 ref = [smooth_at(x["curves"][k], t, window) for x in f32]
                 lo, hi = min(ref), max(ref)
                 mid, half = 0.5 * (lo + hi), max(0.5 * (hi - lo), 0.02 * abs(0.5 * (lo + hi)), 1e-6)
@@ -145,6 +156,9 @@ def main(iters=300, modes=("bf16", "f16"), out_json=None, log=print):
         log("%-5s %-13s %5d   [%10.5f, %10.5f]   %10.5f   %.2f" % (mode, k, t, lo, hi, v, dist))
     for mode, w in worst.items():
         log("worst distance from the fp32 band, %s: %.2f half-widths" % (mode, w))
+    for m in modes:
+        if results[m].get("loss_scale"):
+            log("%s dynamic loss scale: final %.0f, %d skipped iterations" % ((m,) + tuple(results[m]["loss_scale"])))
     log("final PSNR / SSIM on the held-out batch: f32 %s, %s" % (
         ", ".join("%.3f dB / %.4f" % (x["psnr"], x["ssim"]) for x in results["f32"]),
         ", ".join("%s %.3f dB / %.4f" % (m, results[m]["psnr"], results[m]["ssim"]) for m in modes)))

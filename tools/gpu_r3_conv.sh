@@ -5,5 +5,5 @@ mkdir -p $R/gpurun_out/r3
 cd $R
 timeout 1200 python tools/convergence.py 300 gpurun_out/r3/convergence.json > gpurun_out/r3/convergence.txt 2>&1
 tail -70 gpurun_out/r3/convergence.txt
-timeout 600 python bench.py --steps 20 --warmup 5 > gpurun_out/r3/bench_new.log 2>&1
-tail -3 gpurun_out/r3/bench_new.log | cut -c1-3000
+true
+true
