@@ -69,6 +69,15 @@ class GradSync:
             self.work = None
 
 
+def all_ranks_ok(ok, device=None):
+    """True iff `ok` holds on EVERY rank (one MIN all-reduce of a flag; trivially `ok` in a single process)."""
+    if not is_distributed():
+        return bool(ok)
+    t = torch.tensor([1 if ok else 0], dtype=torch.int32, device=device if device is not None and str(device) != "cpu" else None)
+    dist.all_reduce(t, op=dist.ReduceOp.MIN)
+    return bool(int(t.item()))
+
+
 def broadcast_parameters(optimizer, src=0):
     """All ranks start from rank `src`'s parameters (one broadcast of the parameter arena)."""
     if is_distributed():

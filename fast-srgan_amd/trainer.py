@@ -123,10 +123,10 @@ class Trainer:
         """noise: optional (n0, n1, n2) replacing the torch.rand_like draws of trainer.py:175,176,187."""
         try:
             st = self._phase_d(lr_images, hr_images, noise)
-            self._sync_d.run()
-            self._phase_g(st, noise)
-            self._sync_g.run()
-            return self._phase_end(st)
+            self._sync_d.start()        # RCCL all-reduce of D's gradient arena on the collective's stream; nothing waits yet
+            self._phase_g(st, noise)    # ... waits for it right before optim_discriminator.step(); the side stream's VGG branch
+            self._sync_g.start()        #     and the generator's zero_grad run beside the exchange
+            return self._phase_end(st)  # waits for the generator exchange right before optim_generator.step()
         finally:
             self._end_iteration(lr_images.device)
 
@@ -188,8 +188,9 @@ class Trainer:
 
     def _phase_g(self, st, noise):
         Dm = self.discriminator
+        self.optim_generator.zero_grad()                                        # :184 (independent of the exchange in flight)
+        self._sync_d.wait()             # no-op without a pending exchange (single process, graph capture)
         self.optim_discriminator.step()                                         # :181
-        self.optim_generator.zero_grad()                                        # :184
         for p in Dm.parameters():
             p.requires_grad_(False)      # D's weight gradients of this pass are discarded by the reference (:171)
         try:
@@ -221,6 +222,7 @@ class Trainer:
         return float(v[0]), int(v[3])
 
     def _phase_end(self, st):
+        self._sync_g.wait()
         self.optim_generator.step()                                             # :196
         self._update_loss_scale()
         # the loss scalars live in the per-iteration scratch arena: copy them out (one launch) so they survive the next reset
@@ -260,14 +262,34 @@ class Trainer:
                 self._graphs = [g]
             else:
                 ga, gb, gc = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
-                with torch.cuda.graph(ga, **kw):
-                    st = self._phase_d(self._g_lr, self._g_hr, self._g_noise, join_side=True)
+                # the exchanges between the captures are REAL collectives: every rank issues exactly these two, whether or not its
+                # own capture succeeds (a rank that raised inside a capture would otherwise leave its peers in an all-reduce)
+                err = None
+                try:
+                    with torch.cuda.graph(ga, **kw):
+                        st = self._phase_d(self._g_lr, self._g_hr, self._g_noise, join_side=True)
+                except Exception as exc:  # noqa: BLE001
+                    err = exc
                 self._sync_d.run()
-                with torch.cuda.graph(gb, pool=ga.pool(), **kw):
-                    self._phase_g(st, self._g_noise)
+                if err is None:
+                    try:
+                        with torch.cuda.graph(gb, pool=ga.pool(), **kw):
+                            self._phase_g(st, self._g_noise)
+                    except Exception as exc:  # noqa: BLE001
+                        err = exc
                 self._sync_g.run()
-                with torch.cuda.graph(gc, pool=ga.pool(), **kw):
-                    self._graph_out = self._phase_end(st)
+                if err is None:
+                    try:
+                        with torch.cuda.graph(gc, pool=ga.pool(), **kw):
+                            self._graph_out = self._phase_end(st)
+                    except Exception as exc:  # noqa: BLE001
+                        err = exc
+                # all ranks replay graphs or none does: a rank replaying while another runs eager would pair different
+                # numbers of collectives per step
+                ok = D.all_ranks_ok(err is None, dev)
+                if not ok:
+                    self._graphs = []
+                    raise RuntimeError("hipGraph capture failed on %s: %s" % ("this rank" if err is not None else "another rank", err))
                 self._graphs = [ga, gb, gc]
         finally:
             self._end_iteration(dev)
@@ -286,9 +308,11 @@ class Trainer:
             self._graphs[0].replay()
         else:
             self._graphs[0].replay()
-            self._sync_d.run()
+            self._sync_d.start()        # the exchange is enqueued behind phase D on RCCL's stream ...
+            self._sync_d.wait()         # ... and phase G's graph launch is ordered behind it (stream wait, no host block)
             self._graphs[1].replay()
-            self._sync_g.run()
+            self._sync_g.start()
+            self._sync_g.wait()
             self._graphs[2].replay()
         # the replay stepped both optimizers on the device without running any Python: advance the host-side epochs so
         # that eager code running afterwards (evaluation, checkpoint-time inference) re-packs the filters it caches

@@ -135,3 +135,44 @@ def test_two_rank_iteration_equals_single_process_at_global_batch(tmp_path):
     T.train_step(lr, hr, noise)
     assert relerr2(res[0]["g_grad"], T.optim_generator.flat_grad) < 1e-3
     assert relerr2(res[0]["d_grad"], T.optim_discriminator.flat_grad) < 1e-3
+
+
+# ------------------------------------------------------------------ four ranks, different data everywhere, several iterations
+def _four_rank_worker(rank, world, port, out_dir):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port))
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import importlib
+    from backend import select
+    dev = select("emu")
+    pkg = importlib.import_module("fast-srgan_amd")
+    D = importlib.import_module("fast-srgan_amd.distributed")
+    D.init_from_env(backend="gloo")
+    assert D.all_ranks_ok(True) and not D.all_ranks_ok(rank != 2)      # one dissenting rank turns every rank's answer
+    torch.manual_seed(50 + rank)
+    T = _tiny_trainer(pkg, dev)
+    g = torch.Generator().manual_seed(900 + 17 * rank)                 # every rank draws its OWN crops and label noise
+    for _ in range(3):
+        lr = torch.rand(1, 3, 8, 8, generator=g) * 2 - 1
+        hr = torch.rand(1, 3, 32, 32, generator=g) * 2 - 1
+        noise = [torch.rand(1, 1, 2, 2, generator=g) for _ in range(3)]
+        T.train_step(lr, hr, noise)
+    torch.save({"g": T.optim_generator.flat_param.clone(), "d": T.optim_discriminator.flat_param.clone(),
+                "gm": T.optim_generator.exp_avg.clone(), "dm": T.optim_discriminator.exp_avg.clone(),
+                "gstep": T.optim_generator.step_dev.clone()}, os.path.join(out_dir, f"four_rank{rank}.pt"))
+    torch.distributed.barrier()
+    torch.distributed.destroy_process_group()
+
+
+def test_four_ranks_with_unequal_data_stay_bit_identical(tmp_path):
+    """World size 4 (gloo, host emulator), per-rank data and label-noise seeds, three graph-less iterations of
+    trainer.py:171-196 with the exchange started after each phase and awaited before its optimizer step: the replicas'
+    parameters AND Adam moments are bit-identical afterwards, and they moved."""
+    world, port = 4, _free_port()
+    mp.spawn(_four_rank_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    res = [torch.load(os.path.join(str(tmp_path), f"four_rank{r}.pt")) for r in range(world)]
+    for r in range(1, world):
+        for k in res[0]:
+            assert torch.equal(res[0][k], res[r][k]), (r, k)
+    assert float(res[0]["gstep"]) == 3.0 and float(res[0]["gm"].abs().max()) > 0 and float(res[0]["dm"].abs().max()) > 0
