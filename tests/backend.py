@@ -52,7 +52,7 @@ def relerr(a, b):
 def relerr2(a, b):
     """Relative L2 error.  Gradients of (Leaky/P)ReLU networks are discontinuous in the activations' signs: a 1e-6
     perturbation of the weights already moves single elements of the fp32 ORACLE's own gradients by ~1% of the
-    tensor maximum (measured: tests/grad_sensitivity.py), so element-wise max-norm bounds are not meaningful for
+    tensor maximum (measured: tests/probes/grad_sensitivity.py), so element-wise max-norm bounds are not meaningful for
     them; the L2 norm is."""
     a, b = a.detach().double().cpu(), b.detach().double().cpu()
     return float((a - b).norm() / b.norm().clamp_min(1e-30))
@@ -74,7 +74,7 @@ def check_grads(prefix, named, ref, t_tensor, t_slope=0.25, t_cos=None, t_norm=N
     """Gradient gates of the network-level tests.  `named`: [(name, gradient)], `ref`: {name: reference gradient}.
       * tensors (filters, biases): relative L2 error < t_tensor (relerr2 explains why not max-norm);
       * the single PReLU slopes: each is ONE cancelling sum over a whole layer (the fp32 oracle itself moves some of them by
-        more than 100 % between float32 and float64, tests/conditioning_probe.py), so they are held to |error| < t_slope x
+        more than 100 % between float32 and float64, tests/probes/conditioning_probe.py), so they are held to |error| < t_slope x
         the largest slope gradient of the network instead of their own magnitude;
       * t_cos: lower bound of the cosine between all tensor gradients concatenated and the reference;
       * t_norm = (lo, hi): bounds of every tensor's norm ratio |g| / |reference| (a scaled or vanishing gradient passes an

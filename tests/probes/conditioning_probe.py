@@ -7,10 +7,10 @@ discriminator gradients 0.4-0.5 %, generator gradients 8-10 % (single PReLU slop
 perturbations and every flip re-routes a gradient path; the generator's gradient crosses 8 discriminator layers or 15 VGG
 layers plus its own 18.  The gates of tests/test_parity_bench.py are set from these numbers (2x), see DESIGN.md section 5.
 
-    python tests/conditioning_probe.py
+    python tests/probes/conditioning_probe.py
 """
 import sys, types, importlib, time, torch
-sys.path.insert(0, __import__('os').path.dirname(__import__('os').path.dirname(__import__('os').path.abspath(__file__))))
+sys.path.insert(0, __import__('os').path.dirname(__import__('os').path.dirname(__import__('os').path.dirname(__import__('os').path.abspath(__file__)))))
 from oracle import srgan_cpu as O
 pkg = importlib.import_module("fast-srgan_amd")
 ns = types.SimpleNamespace

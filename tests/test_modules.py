@@ -263,3 +263,88 @@ def test_vgg_no_grad_pass_with_fused_pools_equals_the_training_pass(dev, pkg):
         with torch.no_grad():
             fused = V.features_nhwc(x)
         assert torch.equal(fused, V.features_nhwc(x.clone().requires_grad_(True)).detach())
+
+
+# ------------------------------------------------------------------ VGG19 weights: the real-checkpoint path (model.py:8)
+def _tv_checkpoint(path, width_div, seed):
+    """A file shaped like torchvision's vgg19 checkpoint: features.N.{weight,bias} for all 16 convolutions (the last two
+    lie beyond features[:34] and must be ignored) plus classifier tensors."""
+    import importlib
+    M = importlib.import_module("fast-srgan_amd.model")
+    g = torch.Generator().manual_seed(seed)
+    sd, cin, idx = {}, 3, 0
+    for v in M._VGG_CFG:
+        if v == "M":
+            idx += 1
+            continue
+        c = v // width_div
+        sd["features.%d.weight" % idx] = torch.randn(c, cin, 3, 3, generator=g) * (2.0 / (9 * cin)) ** 0.5
+        sd["features.%d.bias" % idx] = torch.randn(c, generator=g) * 0.05
+        cin = c
+        idx += 2
+    sd["classifier.0.weight"] = torch.zeros(4, 4)
+    torch.save(sd, path)
+    return sd
+
+
+def test_vgg19_loads_a_torchvision_format_checkpoint(pkg, tmp_path, monkeypatch):
+    """VGG19(weights=<path>) / FSR_VGG19_WEIGHTS / training.vgg19_weights: features.0 .. features.32 land in vgg.0 .. vgg.32
+    bit for bit (features.34 and the classifier are dropped), the stack is frozen, and the features match the oracle's VGG
+    on those weights."""
+    dev = select("emu")
+    path = str(tmp_path / "vgg19-dcbb9e9d.pth")
+    sd = _tv_checkpoint(path, width_div=4, seed=3)
+    assert "features.34.weight" in sd
+    V = pkg.VGG19(weights=path, compute_dtype="f32", width_div=4)
+    got = V.state_dict()
+    assert len(got) == 32 and "vgg.34.weight" not in got
+    for k, v in got.items():
+        if k.startswith("vgg."):
+            assert torch.equal(v, sd["features." + k[len("vgg."):]]), k
+    assert all(not p.requires_grad for p in V.parameters())
+    torch.manual_seed(0)
+    x = torch.rand(1, 3, 16, 32) * 2 - 1
+    want = O.vgg_forward({k: v.clone() for k, v in got.items()}, x)
+    assert relerr(V.to(dev)(x.to(dev)), want) < 1e-4
+    # the two other ways to name the file
+    monkeypatch.setenv("FSR_VGG19_WEIGHTS", path)
+    V2 = pkg.VGG19(compute_dtype="f32", width_div=4)
+    assert torch.equal(V2.vgg[0].weight, sd["features.0.weight"])
+    monkeypatch.delenv("FSR_VGG19_WEIGHTS")
+    import types
+    ns = types.SimpleNamespace
+    monkeypatch.setattr(pkg.trainer, "VGG19", lambda **kw: pkg.VGG19(width_div=4, **kw))
+    cfg = ns(experiment=ns(name="w", seed=1), generator=ns(n_filters=16, n_layers=1), discriminator=ns(n_filters=16, n_layers=7),
+             training=ns(compiled=False, device="cpu", log_iter=1, checkpoint_iter=10 ** 9, generator_lr=1e-4, discriminator_lr=1e-4,
+                         batch_size=1, compute_dtype="f32", vgg19_weights=path))
+    T = pkg.Trainer(cfg)
+    assert torch.equal(T.perceptual_network.vgg[2].weight, sd["features.2.weight"])
+
+
+def test_vgg19_without_weights_raises_unless_opted_in(pkg, monkeypatch):
+    """model.py:8 needs ImageNet weights; offline there are none: VGG19() must refuse (a perceptual loss against random
+    features trains a silently different model) unless the caller opts in -- VGG19(seed=), allow_random=True, or the config
+    key training.allow_random_vgg."""
+    select("emu")
+    L = __import__("importlib").import_module("fast-srgan_amd._lib")
+    monkeypatch.delenv("FSR_VGG19_WEIGHTS", raising=False)
+    import sys
+    monkeypatch.setitem(sys.modules, "torchvision", None)           # whatever is installed, the download path is closed
+    with pytest.raises(L.FsrError, match="no ImageNet weights"):
+        pkg.VGG19(compute_dtype="f32", width_div=4)
+    with pytest.warns(UserWarning, match="stand-in"):
+        V = pkg.VGG19(compute_dtype="f32", width_div=4, allow_random=True)
+    assert torch.equal(V.vgg[0].weight, pkg.VGG19(compute_dtype="f32", width_div=4, seed=1234).vgg[0].weight)
+    import types
+    ns = types.SimpleNamespace
+
+    def cfg(**extra):
+        return ns(experiment=ns(name="w", seed=1), generator=ns(n_filters=16, n_layers=1), discriminator=ns(n_filters=16, n_layers=7),
+                  training=ns(compiled=False, device="cpu", log_iter=1, checkpoint_iter=10 ** 9, generator_lr=1e-4,
+                              discriminator_lr=1e-4, batch_size=1, compute_dtype="f32", **extra))
+    monkeypatch.setattr(pkg.trainer, "VGG19", lambda **kw: pkg.VGG19(width_div=4, **kw))
+    with pytest.raises(L.FsrError, match="no ImageNet weights"):
+        pkg.Trainer(cfg())
+    with pytest.warns(UserWarning, match="stand-in"):
+        T = pkg.Trainer(cfg(allow_random_vgg=True))
+    assert T.perceptual_network.vgg[0].weight.abs().sum() > 0

@@ -20,7 +20,7 @@ def ns(**k):
 
 
 # Gates (~2x the errors measured on the MI355X, gpurun_out/parity_errors.log).  Two facts shape them (DESIGN.md section 5,
-# tests/conditioning_probe.py):
+# tests/probes/conditioning_probe.py):
 #  * whole-network GRADIENTS of this model are ill-conditioned: the fp32 oracle itself, run in float64, moves the generator's
 #    gradients of this very iteration by 9.4 % (relative L2), the discriminator's by 0.5 %, the VGG image gradient by 0.6 % --
 #    ReLU / LeakyReLU(0.01) / max-pool decisions flip under 1e-7 perturbations.  The f32-mode gates are 2x THAT, losses and
@@ -33,7 +33,7 @@ VGGQ_OUT, VGGQ_DX, VGG_BF16_OUT, VGG_BF16_DX = 1.2e-2, 0.45, 2e-2, 0.7
 #    0.15-0.5 relative L2 with norm ratios 0.94-1.01 and cosines 0.995 (D) / 0.90 (G): the forward pass is reproduced to 1e-3,
 #    the gradients are as far apart as two bf16 evaluations of this network that differ in fp32 summation order are (one bf16
 #    ulp in 0.02 % of the activations after the second discriminator block has become a difference in 67 % of them after the
-#    seventh, with 0.1 % LeakyReLU(0.01) sign flips per layer -- tests/conditioning_probe.py).
+#    seventh, with 0.1 % LeakyReLU(0.01) sign flips per layer -- tests/probes/conditioning_probe.py).
 #    Round 3 (verdict: "a 100 % L2 gate is not a test"): the gates below are 1.4-1.6x the values measured on the MI355X with the
 #    round-3 kernels (gpurun_out/parity_errors.log, copied to profiles/r03_parity_errors.log) -- per network, with the norm ratio
 #    of every tensor and the PReLU slopes bounded as well:
