@@ -122,6 +122,12 @@ class DeviceBatchLoader:
         self.iterations = len(dataset) // batch_size if sequential else iterations
         if self.iterations is None:
             raise ValueError("DeviceBatchLoader needs `iterations` unless sequential=True")
+        if sequential and self.iterations == 0:
+            # the reference's DataLoader(drop_last=True) behaves the same way (train.py:81-91), but silently: SSIM / PSNR are
+            # then never logged and no fixed validation images exist
+            import warnings
+            warnings.warn("DeviceBatchLoader(sequential=True): %d images give no full batch of %d -- validation metrics and the "
+                          "fixed validation images will be skipped (drop_last semantics of train.py:81-91)" % (len(dataset), batch_size))
         self.gen = torch.Generator().manual_seed(seed)
         self.rng = random.Random(seed)
 

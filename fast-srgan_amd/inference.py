@@ -46,59 +46,87 @@ class InferencePipeline:
                       generator, head epilogue storing the uint8 frame)
       copy stream   : D2H of the finished uint8 frames (2.8 MB per 720p frame, 4x less than floats) into pinned memory,
                       overlapped with the next batch's compute (`depth` staging slots, each with its own graph)
-    Frames are bucketed by shape; one set of graphs per (H, W).  `run` yields results in input order."""
+    Frames are bucketed by shape; one set of graphs per (H, W), built lazily and kept for the most recently used shapes
+    only.  `run` yields results in input order."""
 
-    def __init__(self, model, device="cuda", batch=8, depth=2, use_graph=True, copy=True):
+    def __init__(self, model, device="cuda", batch=8, depth=2, use_graph=True, copy=True, max_shapes=4):
         """copy=False: `run` yields VIEWS of the pinned result buffers (valid until `depth` more batches have been
-        submitted) instead of private arrays -- for consumers that encode / display a frame right away."""
+        submitted) instead of private arrays -- for consumers that encode / display a frame right away.
+        max_shapes: plans (pinned staging, device buffers, captured graphs with their private pools) are kept for the
+        `max_shapes` most recently used frame shapes only; a directory of differently sized images (which the reference's
+        per-image loop handles, inference.py:47-57) would otherwise pin a few GB per distinct shape for good."""
         self.model, self.device, self.batch, self.depth, self.use_graph = model.eval(), torch.device(device), batch, depth, use_graph
         self.copy = copy
-        self._plans = {}
+        self.max_shapes = max(1, int(max_shapes))
+        self._plans = {}            # (h, w) -> list of `depth` slots, built lazily (a one-batch bucket only ever builds slot 0)
+        self._lru = []              # shapes, least recently used first
         self._copy_stream = torch.cuda.Stream(device=self.device)
 
     class _Slot:
         pass
 
-    def _plan(self, h, w):
+    def _touch(self, key):
+        if key in self._lru:
+            self._lru.remove(key)
+        self._lru.append(key)
+        while len(self._lru) > self.max_shapes:
+            old = self._lru.pop(0)
+            plan = self._plans.pop(old, None)
+            if plan is not None:
+                for sl in plan:
+                    if sl is not None and sl.pending is not None:
+                        sl.copied.synchronize()
+                del plan            # graphs (and their private memory pools), device and pinned buffers go with the slots
+                torch.cuda.synchronize(self.device)
+                torch.cuda.empty_cache()
+
+    def _slot(self, h, w, j):
+        """Slot j of the plan for (h, w), created on first use."""
         key = (h, w)
         plan = self._plans.get(key)
-        if plan is not None:
-            return plan
-        plan = []
-        scale = None
-        for _ in range(self.depth):
-            sl = self._Slot()
-            sl.host_in = torch.empty((self.batch, h, w, 3), dtype=torch.uint8).pin_memory()
-            sl.x = torch.zeros((self.batch, h, w, 3), dtype=torch.uint8, device=self.device)
-            with torch.no_grad():
-                side = torch.cuda.Stream(device=self.device)
-                side.wait_stream(torch.cuda.current_stream())
-                with torch.cuda.stream(side):
-                    y = self.model.forward_u8(sl.x)            # warm-up: creates every lazily allocated buffer
-                torch.cuda.current_stream().wait_stream(side)
-                torch.cuda.synchronize()
-                sl.graph = None
-                if self.use_graph:
-                    try:
-                        g = torch.cuda.CUDAGraph()
-                        with torch.cuda.graph(g):
-                            y = self.model.forward_u8(sl.x)
-                        sl.graph = g
-                    except Exception as exc:  # noqa: BLE001 -- eager launches are always available
-                        print("InferencePipeline: hipGraph capture failed (%s: %s); eager launches" % (type(exc).__name__, exc))
-                        torch.cuda.synchronize()
-            sl.y = y
-            scale = y.shape[1] // h
-            sl.host_out = torch.empty(tuple(y.shape), dtype=torch.uint8).pin_memory()
-            # plain numpy views for the host-side packing / unpacking: one memcpy per frame on this thread (torch's
-            # multi-threaded copy_ pays a thread-pool wake-up per call, milliseconds when the pool has gone to sleep)
-            sl.host_in_np, sl.host_out_np = sl.host_in.numpy(), sl.host_out.numpy()
-            sl.done = torch.cuda.Event()
-            sl.copied = torch.cuda.Event()
-            sl.pending = None
-            plan.append(sl)
-        self._plans[key] = plan
-        return plan
+        if plan is None:
+            plan = self._plans[key] = [None] * self.depth
+        self._touch(key)
+        if plan[j] is not None:
+            return plan[j]
+        sl = self._Slot()
+        sl.host_in = torch.empty((self.batch, h, w, 3), dtype=torch.uint8).pin_memory()
+        sl.x = torch.zeros((self.batch, h, w, 3), dtype=torch.uint8, device=self.device)
+        with torch.no_grad():
+            side = torch.cuda.Stream(device=self.device)
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                y = self.model.forward_u8(sl.x)            # warm-up: creates every lazily allocated buffer
+            torch.cuda.current_stream().wait_stream(side)
+            torch.cuda.synchronize()
+            sl.graph = None
+            if self.use_graph:
+                try:
+                    g = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(g):
+                        y = self.model.forward_u8(sl.x)
+                    sl.graph = g
+                except Exception as exc:  # noqa: BLE001 -- eager launches are always available
+                    print("InferencePipeline: hipGraph capture failed (%s: %s); eager launches" % (type(exc).__name__, exc))
+                    torch.cuda.synchronize()
+        sl.y = y
+        sl.host_out = torch.empty(tuple(y.shape), dtype=torch.uint8).pin_memory()
+        # plain numpy views for the host-side packing / unpacking: one memcpy per frame on this thread (torch's
+        # multi-threaded copy_ pays a thread-pool wake-up per call, milliseconds when the pool has gone to sleep)
+        sl.host_in_np, sl.host_out_np = sl.host_in.numpy(), sl.host_out.numpy()
+        sl.done = torch.cuda.Event()
+        sl.copied = torch.cuda.Event()
+        sl.pending = None
+        plan[j] = sl
+        return sl
+
+    @torch.no_grad()
+    def _eager(self, frames):
+        """A handful of frames of one shape (fewer than a batch): one eager launch at their TRUE count -- no staging plan, no
+        graph capture, no padding of the batch with repeated frames."""
+        x = torch.from_numpy(np.stack([np.ascontiguousarray(f) for f in frames])).to(self.device)
+        y = self.model.forward_u8(x).cpu().numpy()
+        return [y[i] for i in range(len(frames))]
 
     @torch.no_grad()
     def _submit(self, sl, frames):
@@ -106,8 +134,7 @@ class InferencePipeline:
         n = len(frames)
         for i, f in enumerate(frames):
             np.copyto(sl.host_in_np[i], f)
-        for i in range(n, self.batch):      # ragged tail: repeat the last frame, results dropped
-            np.copyto(sl.host_in_np[i], sl.host_in_np[n - 1])
+        assert n == self.batch       # (ragged tails run eagerly: InferencePipeline.run)
         main = torch.cuda.current_stream()
         sl.x.copy_(sl.host_in, non_blocking=True)
         if sl.graph is not None:
@@ -130,9 +157,9 @@ class InferencePipeline:
 
     def run(self, frames):
         """frames: iterable of uint8 (H,W,3) arrays, all of ONE shape per call (use `run_mixed` otherwise).  Yields uint8
-        (4H,4W,3) arrays in order."""
+        (4H,4W,3) arrays in order.  Full batches go through the pipelined slots; a ragged tail runs eagerly at its true size."""
         it = iter(frames)
-        plan, k, inflight = None, 0, []
+        hw, k, inflight = None, 0, []
         while True:
             chunk = []
             for f in it:
@@ -141,9 +168,15 @@ class InferencePipeline:
                     break
             if not chunk:
                 break
-            if plan is None:
-                plan = self._plan(chunk[0].shape[0], chunk[0].shape[1])
-            sl = plan[k % self.depth]
+            if hw is None:
+                hw = (chunk[0].shape[0], chunk[0].shape[1])
+            if len(chunk) < self.batch:           # the tail (or a bucket smaller than one batch)
+                for sl in inflight:
+                    yield from self._collect(sl)
+                inflight = []
+                yield from self._eager(chunk)
+                break
+            sl = self._slot(hw[0], hw[1], k % self.depth)
             if sl.pending is not None:
                 inflight.remove(sl)
                 yield from self._collect(sl)

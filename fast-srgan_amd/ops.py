@@ -180,7 +180,8 @@ def _last_kernel():
     return name.decode() if name else "?"
 
 
-_ws_retired = []    # outgrown scratch buffers: captured hipGraphs may still hold their addresses, so they are never freed
+_ws_retired = []    # outgrown scratch buffers that a captured hipGraph may still address: never freed
+_capture_seen = {}  # (device, stream) -> the current buffer was handed out during a stream capture
 
 
 def _workspace(nbytes, device):
@@ -191,9 +192,16 @@ def _workspace(nbytes, device):
     buf = _ws.get(key)
     if buf is None or buf.numel() * 4 < nbytes:
         if buf is not None:
-            _ws_retired.append(buf)
+            # a captured hipGraph may have baked this address in: keep the buffer alive only in that case (a buffer that no
+            # capture can have seen is simply dropped, so a run of growing requests does not pile up)
+            if _capture_seen.get(key):
+                _ws_retired.append(buf)
+            nbytes = max(nbytes, 2 * buf.numel() * 4)      # geometric growth: O(log) reallocations, not one per larger request
         buf = torch.empty((max(nbytes, 1 << 20) + 3) // 4, dtype=torch.float32, device=device)
         _ws[key] = buf
+        _capture_seen[key] = False
+    if device.type == "cuda" and torch.cuda.is_current_stream_capturing():
+        _capture_seen[key] = True
     return buf
 
 

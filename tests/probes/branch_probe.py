@@ -2,7 +2,7 @@
 content branch (VGG + SmoothL1) and of the adversarial branch (D + BCE) separately, cfg1 size."""
 import importlib, os, sys, types
 import torch
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from oracle import srgan_cpu as O
 pkg = importlib.import_module("fast-srgan_amd")
 ops = importlib.import_module("fast-srgan_amd.ops")

@@ -84,9 +84,17 @@ def test_inference_pipeline_batched_frames(tmp_path):
     rng = np.random.default_rng(5)
     shapes = [(24, 40)] * 7 + [(30, 30)] * 3 + [(24, 40)] * 2
     frames = [rng.integers(0, 256, size=(h, w, 3), dtype=np.uint8) for h, w in shapes]
-    pipe = pkg.InferencePipeline(G, dev, batch=4, depth=2)
+    pipe = pkg.InferencePipeline(G, dev, batch=4, depth=2, max_shapes=1)
     outs = pipe.run_mixed(frames)
     assert len(outs) == len(frames)
+    # plans are built lazily and only for full batches: the 3-frame bucket and the 1-frame tail ran eagerly at their true size
+    assert list(pipe._plans) == [(24, 40)] and all(sl is not None for sl in pipe._plans[(24, 40)])
+    # ... and are evicted least-recently-used first (a folder of differently sized images must not pin
+    # graph pools per shape for good)
+    more = [rng.integers(0, 256, size=(40, 24, 3), dtype=np.uint8) for _ in range(4)]
+    outs2 = pipe.run_mixed(more)
+    assert list(pipe._plans) == [(40, 24)] and pipe._plans[(40, 24)][1] is None      # one batch: only slot 0 was ever built
+    frames, outs = frames + more, outs + outs2
     inference = importlib.import_module("fast-srgan_amd.inference")
     for f, y in zip(frames, outs):
         assert y.dtype == np.uint8 and y.shape == (4 * f.shape[0], 4 * f.shape[1], 3)
@@ -111,7 +119,7 @@ def test_bench_self_spawns_ranks_and_runs_the_rccl_path():
     for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
         env.pop(k, None)
     r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1", "--batch", "2",
-                        "--no-cpu-baseline", "--no-inference", "--no-f32"], env=env, capture_output=True, text=True, timeout=900)
+                        "--no-cpu-baseline", "--no-inference", "--no-f32", "--no-sustained"], env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-1500:]
     line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1]
     d = json.loads(line)

@@ -210,6 +210,17 @@ def test_dynamic_loss_scale_skips_overflowed_steps(pkg):
         assert (p.detach() - r.detach()).abs().max() < 1e-6
 
 
+def test_sequential_loader_without_a_full_batch_warns(pkg):
+    """train.py:81-91's validation loader drops the last partial batch; a data set smaller than one batch then yields nothing.
+    The reference skips its metrics silently; here the loader says so."""
+    class Tiny:
+        def __len__(self):
+            return 3
+    with pytest.warns(UserWarning, match="no full batch"):
+        loader = pkg.DeviceBatchLoader(Tiny(), 4, sequential=True)
+    assert len(loader) == 0 and list(loader) == []
+
+
 def test_trainer_rejects_bad_loss_scale(pkg):
     select("emu")
     import types
