@@ -29,7 +29,7 @@ class ConvDesc(ctypes.Structure):
         ("n", c_int), ("ih", c_int), ("iw", c_int), ("cin", c_int),
         ("oh", c_int), ("ow", c_int), ("cout", c_int),
         ("stride", c_int), ("act", c_int), ("slope", c_float),
-        ("pixel_shuffle", c_int), ("in_pixel_shuffled", c_int), ("out_f32", c_int), ("pool2", c_int),
+        ("pixel_shuffle", c_int), ("in_pixel_shuffled", c_int), ("out_f32", c_int), ("pool2", c_int), ("mask_is_addend", c_int),
     ]
 
 

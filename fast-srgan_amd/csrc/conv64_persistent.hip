@@ -265,7 +265,7 @@ __global__ __launch_bounds__(NTHR64, 2) void conv64_persistent_kernel(const Conv
             const float mk[4] = {cvt_lo<T>(t.x), cvt_hi<T>(t.x),
                                  cvt_lo<T>(t.y), cvt_hi<T>(t.y)};
 #pragma unroll
-            for (int r = 0; r < 4; ++r) v[r] = mk[r] > 0.f ? v[r] : v[r] * a.dmask_slope;
+            for (int r = 0; r < 4; ++r) v[r] = a.dmask_add ? v[r] + mk[r] : (mk[r] > 0.f ? v[r] : v[r] * a.dmask_slope);
           }
           if (want_stats) {
             s1acc[n] += v;
@@ -544,7 +544,7 @@ __global__ __launch_bounds__(NTHR64) void conv64_v2_kernel(const ConvKArgs a) {
             const unsigned t0 = mkv[m][n >> 1][(n & 1) * 2], t1 = mkv[m][n >> 1][(n & 1) * 2 + 1];
             const float mk[4] = {cvt_lo<T>(t0), cvt_hi<T>(t0), cvt_lo<T>(t1), cvt_hi<T>(t1)};
 #pragma unroll
-            for (int r = 0; r < 4; ++r) v[r] = mk[r] > 0.f ? v[r] : v[r] * a.dmask_slope;
+            for (int r = 0; r < 4; ++r) v[r] = a.dmask_add ? v[r] + mk[r] : (mk[r] > 0.f ? v[r] : v[r] * a.dmask_slope);
           }
           if constexpr (STATS) {
             s1acc[n] += v;
@@ -986,7 +986,7 @@ __global__ __launch_bounds__(NTHR64, 2) void conv64_s2dgrad_kernel(const ConvKAr
               const float mk[4] = {cvt_lo<T>(tm.x), cvt_hi<T>(tm.x),
                                    cvt_lo<T>(tm.y), cvt_hi<T>(tm.y)};
 #pragma unroll
-              for (int r = 0; r < 4; ++r) v[r] = mk[r] > 0.f ? v[r] : v[r] * a.dmask_slope;
+              for (int r = 0; r < 4; ++r) v[r] = a.dmask_add ? v[r] + mk[r] : (mk[r] > 0.f ? v[r] : v[r] * a.dmask_slope);
             }
             u32x2 pk;
             pk.x = pack2<T>(v[0], v[1]);

@@ -586,7 +586,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv_igemm_kernel(const ConvK
             mk[2] = cvt_lo<T>(t.y); mk[3] = cvt_hi<T>(t.y);
           }
 #pragma unroll
-          for (int r = 0; r < 4; ++r) v[r] = mk[r] > 0.f ? v[r] : v[r] * a.dmask_slope;
+          for (int r = 0; r < 4; ++r) v[r] = a.dmask_add ? v[r] + mk[r] : (mk[r] > 0.f ? v[r] : v[r] * a.dmask_slope);
         }
         if (want_stats) {
           s1 += v;

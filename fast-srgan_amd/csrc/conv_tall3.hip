@@ -374,6 +374,15 @@ __global__ __launch_bounds__(NW * 64, 2) void conv_tall3_kernel(const ConvKArgs 
             if (maskp) {   // fused activation backward of the producing layer: dz = dx * act'(y), y = the saved forward input
               const u32x4 k0 = *(const u32x4*)(maskp + off), k1 = *(const u32x4*)(maskp + off + 8);
               const float ms = a.dmask_slope;
+              if (a.dmask_add) {   // the tensor is an addend (gradient of a skip connection), not a gate
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                  v[2 * e] += cvt_lo<T>(k0[e]);
+                  v[2 * e + 1] += cvt_hi<T>(k0[e]);
+                  v[8 + 2 * e] += cvt_lo<T>(k1[e]);
+                  v[8 + 2 * e + 1] += cvt_hi<T>(k1[e]);
+                }
+              } else {
               // y > 0 on the raw 16-bit pattern: the element moved to the top of a signed word is positive (bf16 and f16 alike)
 #pragma unroll
               for (int e = 0; e < 4; ++e) {
@@ -381,6 +390,7 @@ __global__ __launch_bounds__(NW * 64, 2) void conv_tall3_kernel(const ConvKArgs 
                 v[2 * e + 1] = (int)(k0[e] & 0xffff0000u) > 0 ? v[2 * e + 1] : v[2 * e + 1] * ms;
                 v[8 + 2 * e] = (int)(k1[e] << 16) > 0 ? v[8 + 2 * e] : v[8 + 2 * e] * ms;
                 v[8 + 2 * e + 1] = (int)(k1[e] & 0xffff0000u) > 0 ? v[8 + 2 * e + 1] : v[8 + 2 * e + 1] * ms;
+              }
               }
             }
             u32x4 p0, p1;

@@ -81,6 +81,8 @@ extern "C" int fsr_conv3x3(const fsr_conv_desc* d, const void* in, const void* p
   a.oscale = oscale;
   a.dmask = dact_mask;
   a.dmask_slope = dact_slope;
+  a.dmask_add = (dact_mask && d->mask_is_addend) ? 1 : 0;
+  if (d->mask_is_addend && !dact_mask) return fsr_fail(-1, "fsr_conv3x3: mask_is_addend needs the dact_mask tensor");
   a.stats = stats ? (float*)scratch : nullptr;   // the kernels write per-workgroup partials; finished below
   a.N = d->n;
   a.IH = d->ih;

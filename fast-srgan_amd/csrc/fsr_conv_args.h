@@ -19,6 +19,7 @@ struct ConvKArgs {
   const float* oscale;  // optional [Cout] scale applied to the accumulator before the bias
   const void* dmask;    // optional tensor like `out`: result *= (dmask > 0 ? 1 : dmask_slope) (fused activation backward)
   float dmask_slope;
+  int dmask_add;        // the dmask tensor is an addend (result += dmask) instead of a gate
   float* stats;         // optional per-workgroup partials [N][stats_P][Cout][2] (sum, sum of squares of the pre-activation)
   int stats_P;          // partial slots per image (set by the launcher: tiles per image, or tile ranges per image)
   int stats_tpi, stats_per;   // persistent kernels: tiles per image / tiles per workgroup (0 for one-tile workgroups)

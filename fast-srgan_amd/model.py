@@ -61,6 +61,10 @@ class Generator(torch.nn.Module):
         cd = self.compute
         self._cfg_neck = ops.ConvCfg(cd, act=L.ACT_PRELU, image_in=True)
         self._cfg_in = ops.ConvCfg(cd, stats=True)
+        # first convolution of a residual block: also hands out aliases of its input for the skip connection(s), whose
+        # gradients its data-gradient launch adds in the epilogue (no autograd accumulation kernels on the block inputs)
+        self._cfg_in_skip = ops.ConvCfg(cd, stats=True, n_alias=1)
+        self._cfg_in_skip2 = ops.ConvCfg(cd, stats=True, n_alias=2)
         self._cfg_up = ops.ConvCfg(cd, act=L.ACT_PRELU, pixel_shuffle=True)
         self._cfg_head = ops.ConvCfg(cd, tanh_head=True)
         self._cfg_head_u8 = ops.ConvCfg(cd, tanh_head=True, u8_head=True)
@@ -80,11 +84,19 @@ class Generator(torch.nn.Module):
         cd = self.compute
         r, _ = ops.conv3x3(x, self.neck[0].weight, self.neck[0].bias, self.neck[1].weight, self._cfg_neck)  # :113
         y = r
-        for blk in self.stem:                                                                           # :114
-            t, st = ops.conv3x3(y, blk.conv1.weight, None, None, self._cfg_in)
+        training = torch.is_grad_enabled()
+        for k, blk in enumerate(self.stem):                                                             # :114
+            if training:
+                # block 0's input r also feeds the long skip of :115: two aliases
+                t, st, *skip = ops.conv3x3(y, blk.conv1.weight, None, None, self._cfg_in_skip2 if k == 0 else self._cfg_in_skip)
+            else:
+                t, st = ops.conv3x3(y, blk.conv1.weight, None, None, self._cfg_in)
+                skip = [y, y]
+            if k == 0:
+                r = skip[1]
             t = ops.instnorm_act(t, st, None, blk.relu1.weight, cd, L.ACT_PRELU)
             u, st = ops.conv3x3(t, blk.conv2.weight, None, None, self._cfg_in)
-            y = ops.instnorm_act(u, st, y, None, cd)
+            y = ops.instnorm_act(u, st, skip[0], None, cd)
         u, st = ops.conv3x3(y, self.bottleneck[0].weight, None, None, self._cfg_in)                      # :115
         y = ops.instnorm_act(u, st, r, None, cd)
         for up in self.upsampling:                                                                      # :116

@@ -319,10 +319,11 @@ class _on_wgrad_stream:
 # ---------------------------------------------------------------------------------- raw launches
 def conv3x3_raw(cd, x, wpk, cout, *, mode=L.CONV_FWD, out_hw=None, stride=1, bias=None, act=L.ACT_NONE, slope=0.0,
                 prelu=None, oscale=None, pixel_shuffle=False, in_pixel_shuffled=False, out_f32=False, want_stats=False,
-                want_preact=False, alg_k=None, dact_mask=None, dact_slope=0.0, out_u8=False, pool2=False):
+                want_preact=False, alg_k=None, dact_mask=None, dact_slope=0.0, out_u8=False, pool2=False, dact_add=False):
     """One fsr_conv3x3 launch.  x: (N,IH,IW,Cin) [or its depth-to-space form when in_pixel_shuffled].
     out_u8 (tanh heads): the output is the finished uint8 HWC image of inference.py:53-56.
-    pool2 (no-grad passes): the output is MaxPool2d(2,2) of the activated result; the full-resolution tensor is never written."""
+    pool2 (no-grad passes): the output is MaxPool2d(2,2) of the activated result; the full-resolution tensor is never written.
+    dact_add: `dact_mask` is ADDED to the result (the gradient of a skip connection) instead of gating it."""
     _check_dev(x)
     n = x.shape[0]
     if in_pixel_shuffled:
@@ -339,7 +340,7 @@ def conv3x3_raw(cd, x, wpk, cout, *, mode=L.CONV_FWD, out_hw=None, stride=1, bia
     pre = torch.empty(oshape, dtype=odt, device=x.device) if want_preact else None
     stats = _zeros((n, cout, 2), x.device) if want_stats else None
     d = L.ConvDesc(cd.code, mode, n, ih, iw, cin, oh, ow, cout, stride, act, float(slope), int(pixel_shuffle),
-                   int(in_pixel_shuffled), L.OUT_U8 if out_u8 else int(out_f32), int(pool2))
+                   int(in_pixel_shuffled), L.OUT_U8 if out_u8 else int(out_f32), int(pool2), int(bool(dact_add)))
     scratch = _workspace(L.lib().fsr_conv3x3_scratch(ctypes.byref(d)), x.device) if want_stats else None
     prof = PROFILE_CONV
     if prof is not None:
@@ -408,7 +409,7 @@ class ConvCfg:
 
     def __init__(self, cd, *, stride=1, act=L.ACT_NONE, slope=0.0, pixel_shuffle=False, stats=False, image_in=False,
                  in_scale=(1.0, 1.0, 1.0), in_shift=(0.0, 0.0, 0.0), tanh_head=False, input_act_bwd=None,
-                 act_bwd_by_consumer=False, u8_head=False, pool_after=False):
+                 act_bwd_by_consumer=False, u8_head=False, pool_after=False, n_alias=0):
         # u8_head (inference only, with tanh_head): the head stores the finished uint8 HWC frame instead of float
         # input_act_bwd = slope: the data-gradient launch also applies the backward of the ReLU (0.0) / LeakyReLU
         #   that produced this conv's input (the mask is the saved input itself), so the tensor it returns is
@@ -424,6 +425,10 @@ class ConvCfg:
         # pool_after (no-grad passes only): the MaxPool2d(2,2) that follows this conv + ReLU is taken in the epilogue and
         # only the pooled tensor is stored (the full-resolution tensor is what a backward pass would need)
         self.pool_after = pool_after
+        # n_alias (1 or 2): forward also returns that many ALIASES of its input for the caller's skip connections
+        # (model.py:69, :115).  Their gradients come back to THIS function's backward, whose data-gradient launch adds the
+        # first one in its epilogue (fsr_conv_desc.mask_is_addend): autograd has nothing left to accumulate on the block input.
+        self.n_alias = n_alias
 
 
 class Conv3x3Fn(torch.autograd.Function):
@@ -479,6 +484,10 @@ class Conv3x3Fn(torch.autograd.Function):
             return out, stats               # (N,H,W,3) uint8: already the frame layout inference.py:55 permutes to
         if cfg.tanh_head:
             return out.permute(0, 3, 1, 2), stats
+        if cfg.n_alias:
+            if cfg.image_in or cfg.input_act_bwd is not None or cfg.pixel_shuffle or cfg.stride != 1:
+                raise L.FsrError("skip aliases are for plain stride-1 convolutions on NHWC activations")
+            return (out, stats) + tuple(xin.view_as(xin) for _ in range(cfg.n_alias))
         return out, stats
 
     @staticmethod
@@ -524,9 +533,13 @@ class Conv3x3Fn(torch.autograd.Function):
         return out, stats
 
     @staticmethod
-    def backward(ctx, g, _gstats):
-        if g is None:       # (gradients are not materialised: only the statistics output was used downstream)
-            return None, None, None, None, None, None
+    def backward(ctx, g, _gstats, *g_alias):
+        skips = [t for t in g_alias if t is not None]
+        if g is None:       # (gradients are not materialised: only the statistics output -- or only a skip alias -- was used)
+            dx = None
+            for t in skips:
+                dx = t if dx is None else dx + t
+            return dx, None, None, None, None, None
         cfg, cd = ctx.cfg, ctx.cfg.cd
         xin, weight, prelu, saved = ctx.saved_tensors
         cout, cin, xshape = ctx.dims
@@ -582,9 +595,14 @@ class Conv3x3Fn(torch.autograd.Function):
                 kpad = dz.shape[3] * (4 if cfg.pixel_shuffle else 1)
                 wpk = packed_filter(cd, weight, L.PACK_DGRAD_PS if cfg.pixel_shuffle else L.PACK_DGRAD, kpad)
                 mask = xin if cfg.input_act_bwd is not None else None
+                addend = None
+                if skips:       # dL/dx = conv_dgrad(dz) + dL/d(skip): the first skip gradient rides in the launch's epilogue
+                    addend = skips[0] if skips[0].is_contiguous() else skips[0].contiguous()
                 dx, _, _ = conv3x3_raw(cd, dz, wpk, cin_pad, mode=L.CONV_DGRAD, out_hw=(ih, iw), stride=cfg.stride,
-                                       in_pixel_shuffled=cfg.pixel_shuffle, alg_k=cout, dact_mask=mask,
-                                       dact_slope=cfg.input_act_bwd or 0.0)
+                                       in_pixel_shuffled=cfg.pixel_shuffle, alg_k=cout, dact_mask=addend if addend is not None else mask,
+                                       dact_slope=cfg.input_act_bwd or 0.0, dact_add=addend is not None)
+                for t in skips[1:]:
+                    dx += t
         dw = None
         if ctx.needs_input_grad[1]:
             arena = getattr(weight, "_fsr_grad", None)  # optim.ArenaAdamW: accumulate in place, hand autograd nothing

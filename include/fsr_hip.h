@@ -98,7 +98,11 @@ int fsr_pack_conv3x3(int dtype, int mode, const float* w_oihw, int cout, int cin
  *   1/(2 std) of VGG19.forward's normalisation, model.py:21-22, applied to input gradients).
  * dact_mask (optional): tensor like out; the result is multiplied by (mask > 0 ? 1 : dact_slope).  A
  *   data-gradient launch uses it to apply the ReLU / LeakyReLU backward of the layer that PRODUCED the
- *   forward input (mask = that layer's output), saving a separate elementwise pass. */
+ *   forward input (mask = that layer's output), saving a separate elementwise pass.
+ *   With desc.mask_is_addend the same tensor is ADDED to the result instead (before the activation): the data gradient of
+ *   the first convolution of a ResidualBlock (model.py:67-69) takes the gradient of the block's skip connection there, so
+ *   dL/dx = conv_dgrad(dz) + dL/d(skip) leaves the kernel in one piece and autograd has nothing to accumulate (round 2 ran
+ *   nine at::add<bf16> kernels per iteration for this). */
 typedef struct fsr_conv_desc {
   int dtype;
   int mode;
@@ -111,6 +115,7 @@ typedef struct fsr_conv_desc {
   int in_pixel_shuffled;
   int out_f32;
   int pool2; /* FWD, 16-bit dtypes, no pixel shuffle: out is the MaxPool2d(2,2) of the activated result, [n,oh/2,ow/2,cout] */
+  int mask_is_addend; /* dact_mask is ADDED to the result instead of gating it (see below) */
 } fsr_conv_desc;
 
 size_t fsr_conv3x3_scratch(const fsr_conv_desc* desc);
