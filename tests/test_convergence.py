@@ -1,10 +1,13 @@
 """Does training in the 16-bit modes converge like training at the reference's precision?  (trainer.py:89-141 + :158-196.)
 
 tools/convergence.py trains the BASELINE cfg #1-size networks from one initialisation on identical batches: three exact-f32
-runs that differ only in their label noise (the fp32 run-to-run band) and one bf16 / f16 run.  Gates (about 2x what the MI355X
-measured, profiles/r03_convergence.txt): every smoothed loss from iteration 100 on, the final PSNR and SSIM of the generator on
-a held-out batch within a few half-widths of the fp32 band; the first 50 iterations -- where the three f32 runs have not
-spread yet and the band is a hair -- within a wider bound; everything finite."""
+runs that differ only in their label noise (the fp32 run-to-run band) and one bf16 / f16 run.  Gates, in half-widths of that
+band (floored at +-2 % of the value): every smoothed loss from iteration 100 on within 6 (measured on the MI355X: <= 2.4 with
+the shipped kernels, profiles/r03_convergence.txt; <= 5.4 across the kernel versions of round 3 -- GAN training is chaotic, any
+change of summation order moves the trajectory by a band or two), the first 50 iterations -- where the three f32 runs have not
+spread yet and the band is a hair -- within 12 (measured 4.9), final PSNR / SSIM of the generator on a held-out batch within
+4.5 (measured 0.6); everything finite.  What the gate excludes is the failure round 3 found and fixed: fp16 with the former
+static loss scale of 2^14 ended 300 iterations with a content loss 5-10x the fp32 band's (12.7 half-widths) and 6 dB PSNR."""
 import importlib.util
 import os
 
@@ -14,7 +17,7 @@ import torch
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
-LATE, EARLY, QUALITY = 3.5, 12.0, 4.5      # half-widths of the fp32 band: iterations >= 100 / the first checkpoints / PSNR, SSIM
+LATE, EARLY, QUALITY = 6.0, 12.0, 4.5      # half-widths of the fp32 band: iterations >= 100 / the first checkpoints / PSNR, SSIM
 
 
 def _tool():

@@ -38,11 +38,12 @@ VGGQ_OUT, VGGQ_DX, VGG_BF16_OUT, VGG_BF16_DX = 1.2e-2, 0.45, 2e-2, 0.7
 #    round-3 kernels (gpurun_out/parity_errors.log, copied to profiles/r03_parity_errors.log) -- per network, with the norm ratio
 #    of every tensor and the PReLU slopes bounded as well:
 #      vs the bf16-storage oracle: D tensors <= 0.479, G tensors <= 0.492, cosines 0.9954 (D) / 0.905 (G), slopes <= 0.076;
-#      vs the plain fp32 oracle:   D tensors <= 0.370, G tensors <= 0.522, cosine 0.992, slopes <= 0.0013, norm ratios 0.97-1.05.
+#      vs the plain fp32 oracle:   D tensors <= 0.370, G tensors <= 0.522, cosine 0.992, norm ratios 0.97-1.05; PReLU slopes <= 0.07 of
+#                                  the generator's largest slope gradient (<= 0.0013 of the largest 1-element gradient of both networks).
 #    What holds the 16-bit mode to the reference beyond single-iteration gradients is tests/test_convergence.py (300 iterations
 #    of f32 against bf16 / f16 training from one initialisation).
 STEPQ_LOSS, STEPQ_D_GRAD, STEPQ_G_GRAD, STEPQ_COS_D, STEPQ_COS_G, STEPQ_SLOPE = 1e-3, 0.7, 0.7, 0.99, 0.85, 0.15
-STEP_BF16_LOSS, STEP_BF16_D_GRAD, STEP_BF16_G_GRAD, STEP_BF16_COS, STEP_BF16_SLOPE = 4e-3, 0.55, 0.75, 0.984, 0.01
+STEP_BF16_LOSS, STEP_BF16_D_GRAD, STEP_BF16_G_GRAD, STEP_BF16_COS, STEP_BF16_SLOPE, STEP_BF16_SLOPE_ALL = 4e-3, 0.55, 0.75, 0.984, 0.15, 0.01
 STEP_NORM = (0.88, 1.14)
 INF_BF16_MEAN, INF_BF16_MAX = 6e-3, 7e-2
 
@@ -132,7 +133,7 @@ def test_train_step_at_baseline_cfg1_size(pkg, cdn):
     losses("bf16", want, STEP_BF16_LOSS)
     bad = check_grads("cfg1.bf16.grad", named_d, ref, t_tensor=STEP_BF16_D_GRAD, t_slope=STEP_BF16_SLOPE, t_norm=STEP_NORM)
     bad += check_grads("cfg1.bf16.grad", named_g, ref, t_tensor=STEP_BF16_G_GRAD, t_slope=STEP_BF16_SLOPE, t_norm=STEP_NORM)
-    bad += check_grads("cfg1.bf16.grad.all", named_d + named_g, ref, t_tensor=STEP_BF16_G_GRAD, t_slope=STEP_BF16_SLOPE, t_cos=STEP_BF16_COS)
+    bad += check_grads("cfg1.bf16.grad.all", named_d + named_g, ref, t_tensor=STEP_BF16_G_GRAD, t_slope=STEP_BF16_SLOPE_ALL, t_cos=STEP_BF16_COS)
     assert not bad, bad
 
 
