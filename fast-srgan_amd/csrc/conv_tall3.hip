@@ -67,24 +67,29 @@ __device__ __forceinline__ V t3_lds_read(const char* smem, unsigned off) {
   return *FSR_LDS_PTR(const V, smem + off);
 }
 
-template <typename T, int BN, int NW, int G, int NSLOT, int MB>
-__global__ __launch_bounds__(NW * 64, 2) void conv_tall3_kernel(const ConvKArgs a) {
-  static_assert(BN == NW * 32, "a wave owns 32 * MB pixels x 64 channels");
+template <typename T, int BN, int NW, int G, int NSLOT, int MB, int NA = 2>
+__global__ __launch_bounds__(NW * 64, NA == 4 ? 1 : 2) void conv_tall3_kernel(const ConvKArgs a) {
+  // a wave owns 32 * MB pixels x 32 * NA channels.  NA = 2: two waves per SIMD (256 registers each); NA = 4 (with MB = 4: the
+  // 128 x 128 wave tile, 256 accumulator registers in the AGPR half of the file): ONE 512-register wave per SIMD, 8 fragment
+  // reads per 16 MFMAs instead of 6 per 8, the 256 x 256 workgroup tile from four waves
+  static_assert(BN % (NA * 32) == 0 && NW == 2 * (BN / (NA * 32)), "two pixel-row groups x BN / (32 NA) channel groups of waves");
+  static_assert(NA == 2 || NA == 4, "2 or 4 filter fragments per wave");
   static_assert(MB >= 2 && MB <= 4, "8, 12 or 16 tile rows");
   constexpr int TH = 4 * MB;                       // tile rows
   constexpr int T3_HUNITS = t3_hunits<MB>(), T3_NHP = t3_nhp<MB>(), T3_HALO_BYTES = t3_halo_bytes<MB>();
-  constexpr int NM = 2 * MB;                       // MFMAs per substep (2 filter x MB pixel fragments)
-  constexpr int NR = 2 + MB;                       // fragment reads per substep
+  constexpr int NM = NA * MB;                      // MFMAs per substep (NA filter x MB pixel fragments)
+  constexpr int NR = NA + MB;                      // fragment reads per substep
   static_assert(9 % G == 0 && (9 / G) % NSLOT == 1, "stage s lives in slot s % NSLOT == (chunk + stage in chunk) % NSLOT");
-  constexpr int WCO = NW / 2;
+  constexpr int WCO = BN / (NA * 32);
   constexpr int SPC = 9 / G;                       // stages per chunk
   constexpr int NQ = 2 * G;                        // substeps per stage
   constexpr int D = NSLOT - 1;                     // the DMA runs D stages ahead
   constexpr int FP = BN / 16 / NW;                 // filter pieces per tap and wave (2)
   constexpr int HPW = (T3_NHP + NW - 1) / NW;      // halo pieces per chunk and wave
   constexpr int SLOT_BYTES = G * BN * 64;
-  static_assert(HPW + D <= SPC + 1, "halo pieces must land before their chunk starts");
-  static_assert(FP == 2, "piece placement below assumes two filter pieces per tap and wave");
+  constexpr int HPS = (HPW + SPC - 1) / SPC > 1 ? (HPW + SPC - 1) / SPC : 1;   // halo pieces a wave issues per stage
+  static_assert((HPW + HPS - 1) / HPS + D <= SPC + 1, "halo pieces must land before their chunk starts");
+  static_assert(FP >= 1 && FP <= NM && HPS + 1 <= NM, "one DMA piece per MFMA slot at most");
 
   HIP_DYNAMIC_SHARED(char, smem)
   const int tid = threadIdx.x, lane = tid & 63;
@@ -102,7 +107,7 @@ __global__ __launch_bounds__(NW * 64, 2) void conv_tall3_kernel(const ConvKArgs 
   // filter fragment (n, k half j) of tap g of the stage in ring slot `sl`: ring + sl + g*BN*64 + n*2048 + aoff[j]
   unsigned aoff[2];
   {
-    const int R = wco * 64 + l31;
+    const int R = wco * (NA * 32) + l31;
 #pragma unroll
     for (int j = 0; j < 2; ++j) aoff[j] = (unsigned)(2 * T3_HALO_BYTES + R * 64 + (((2 * j + hi) ^ t3_swz_row(R)) << 4));
   }
@@ -122,8 +127,8 @@ __global__ __launch_bounds__(NW * 64, 2) void conv_tall3_kernel(const ConvKArgs 
     wvoff[k] = (unsigned)((co * a.Cin + ((ul ^ t3_swz_row(R)) << 3)) * (int)sizeof(T));
   }
 
-  f32x16 acc[2][MB];
-  s16x8 fa[2][2], fb[2][MB];
+  f32x16 acc[NA][MB];
+  s16x8 fa[2][NA], fb[2][MB];
 
   // ---- per-tile state: the tile being accumulated (`cur`) and the tile the DMA stream moves on to once the current
   // tile's last stages have their pieces (`nxt`).  The pipeline NEVER drains between tiles: halo chunks keep alternating
@@ -177,12 +182,12 @@ __global__ __launch_bounds__(NW * 64, 2) void conv_tall3_kernel(const ConvKArgs 
     // the accumulators start at the bias (a lane's 16 registers of fragment row n are 16 consecutive channels): the epilogue
     // has no bias pass
 #pragma unroll
-    for (int n = 0; n < 2; ++n) {
+    for (int n = 0; n < NA; ++n) {
       f32x16 b0;
 #pragma unroll
       for (int e = 0; e < 16; ++e) b0[e] = 0.f;
       if (a.bias) {
-        const unsigned bo = (unsigned)(2 * T3_HALO_BYTES + NSLOT * SLOT_BYTES) + par * 1024 + (unsigned)((wco * 64 + n * 32 + hi * 16) * 4);
+        const unsigned bo = (unsigned)(2 * T3_HALO_BYTES + NSLOT * SLOT_BYTES) + par * 1024 + (unsigned)((wco * (NA * 32) + n * 32 + hi * 16) * 4);
 #pragma unroll
         for (int e4 = 0; e4 < 4; ++e4) {
           const f32x4 b = t3_lds_read<f32x4>(smem, bo + 16 * e4);
@@ -197,13 +202,13 @@ __global__ __launch_bounds__(NW * 64, 2) void conv_tall3_kernel(const ConvKArgs 
   auto slot_of = [&](int gchunk, int si) { return (unsigned)(((gchunk + si) & (NSLOT - 1)) * SLOT_BYTES); };
 
   // reads of substep (tap t = ky*3+kx in ring position g of its stage, k half j): fragment r in the MFMA's need order
-  // a0 b0 .. b(MB-1) a1
+  // a0 b0 .. b(MB-1) a1 .. a(NA-1)
   auto read_frag = [&](auto rc, auto bufc, auto tc, auto gc_, auto jc, unsigned sl, unsigned hb) {
     constexpr int r = decltype(rc)::value, buf = decltype(bufc)::value, t = decltype(tc)::value, g = decltype(gc_)::value,
                   j = decltype(jc)::value;
     constexpr int ky = t / 3, kx = t % 3;
-    if constexpr (r == 0 || r == NR - 1) {
-      constexpr int n = r == 0 ? 0 : 1;
+    if constexpr (r == 0 || r > MB) {      // a0 first, a1 .. a(NA-1) after the pixel fragments
+      constexpr int n = r == 0 ? 0 : r - MB;
       fa[buf][n] = t3_lds_read<s16x8>(smem, aoff[j] + sl + (unsigned)(g * BN * 64 + n * 2048));
     } else {
       constexpr int m = r - 1;
@@ -310,12 +315,13 @@ __global__ __launch_bounds__(NW * 64, 2) void conv_tall3_kernel(const ConvKArgs 
               }
             }
             // DMA pieces of stage s+D: the halo piece first (the likeliest HBM miss), then two filter pieces per substep
-            if constexpr (q == 0 && i == 1 && si < HPW) {
-              if (!last) dma_halo(hv_cur, c + 1, si, (unsigned)((gc + 1) & 1));
-              else if (has_nxt) dma_halo(hv_nxt, 0, si, (unsigned)((gc + 1) & 1));
+            if constexpr (q == 0 && i >= 1 && i <= HPS && si * HPS + (i - 1) < HPW) {
+              constexpr int hk = si * HPS + (i - 1);
+              if (!last) dma_halo(hv_cur, c + 1, hk, (unsigned)((gc + 1) & 1));
+              else if (has_nxt) dma_halo(hv_nxt, 0, hk, (unsigned)((gc + 1) & 1));
             }
-            if constexpr (q < G && i >= NM - 2) {
-              if (issue) dma_filter(wsD, cD, siD * G + q, i - (NM - 2), slD + q * BN * 64);
+            if constexpr (q < G && i >= NM - FP) {
+              if (issue) dma_filter(wsD, cD, siD * G + q, i - (NM - FP), slD + q * BN * 64);
             }
             __builtin_amdgcn_sched_barrier(0);
           });
@@ -339,9 +345,9 @@ __global__ __launch_bounds__(NW * 64, 2) void conv_tall3_kernel(const ConvKArgs 
         else if constexpr (ACT == FSR_ACT_LEAKY) return fmaxf(x, x * slope);
         else return x;
       };
-      static_for<0, 2>([&](auto nc) {
+      static_for<0, NA>([&](auto nc) {
         constexpr int n = decltype(nc)::value;
-        const int co = onb * BN + wco * 64 + n * 32 + hi * 16;
+        const int co = onb * BN + wco * (NA * 32) + n * 32 + hi * 16;
         static_for<0, MB>([&](auto mc) {
           constexpr int m = decltype(mc)::value;
           const int gy = ogy0 + wpx * 2 * MB + 2 * m + lrow;
@@ -445,9 +451,9 @@ int t3_cus() {
   return cus;
 }
 
-template <typename T, int BN, int NW, int G, int NSLOT, int MB>
+template <typename T, int BN, int NW, int G, int NSLOT, int MB, int NA = 2>
 int t3_launch(ConvKArgs& a, int wg_per_cu, hipStream_t stream) {
-  auto kern = conv_tall3_kernel<T, BN, NW, G, NSLOT, MB>;
+  auto kern = conv_tall3_kernel<T, BN, NW, G, NSLOT, MB, NA>;
   constexpr int lds = t3_lds_bytes<BN, G, NSLOT, MB>();
   static bool attr_set = false;
   if (!attr_set) {
@@ -465,7 +471,7 @@ int t3_launch(ConvKArgs& a, int wg_per_cu, hipStream_t stream) {
   long long grid = (long long)t3_cus() * wg_per_cu;
   if (grid > ntiles || !persist) grid = ntiles;
   hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(NW * 64), lds, stream, a);
-  fsr_note_kernel("conv_tall3_kernel<%s,%d,%d,%d,%d,%d>", std::is_same<T, f16_t>::value ? "f16" : "bf16", BN, NW, G, NSLOT, MB);
+  fsr_note_kernel(NA == 2 ? "conv_tall3_kernel<%s,%d,%d,%d,%d,%d>" : "conv_tall3_kernel<%s,%d,%d,%d,%d,%d,4>", std::is_same<T, f16_t>::value ? "f16" : "bf16", BN, NW, G, NSLOT, MB);
   const int rc = fsr_check_launch("conv_tall3_kernel");
   return rc ? rc : 1;
 }
@@ -510,6 +516,8 @@ int fsr_conv_tall3_try(int dtype, ConvKArgs& a, int S, hipStream_t stream) {
     if (rows < best_rows) { best_rows = rows; best_mb = mb; }
   }
   a.tiles_y = (a.GH + 4 * best_mb - 1) / (4 * best_mb);
+  // FSR_TALL3 & 4 (A/B): the one-wave-per-SIMD form, 128 x 128 per wave (16-row tiles only)
+  if ((mode & 4) && a.Cout % 256 == 0 && best_mb == 4 && dtype == FSR_BF16) return t3_launch<bf16_t, 256, 4, 3, 2, 4, 4>(a, 1, stream);
 #define T3_GO(TT, MBV)                                                         \
   do {                                                                         \
     if (wide) return t3_launch<TT, 256, 8, 3, 2, MBV>(a, 1, stream);           \

@@ -13,7 +13,7 @@ import sys
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
-KERNELS = ("conv_igemm_kernel", "conv64_", "conv_c3_fwd_kernel")      # every forward / data-gradient convolution kernel (conv64_*: all persistent forms)
+KERNELS = ("conv_igemm_kernel", "conv_tall3_kernel", "conv64_", "conv_c3_fwd_kernel")      # every forward / data-gradient convolution kernel (conv64_*: all persistent forms)
 
 
 def total_kb(path, counter):
