@@ -471,7 +471,7 @@ int t3_launch(ConvKArgs& a, int wg_per_cu, hipStream_t stream) {
   long long grid = (long long)t3_cus() * wg_per_cu;
   if (grid > ntiles || !persist) grid = ntiles;
   hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(NW * 64), lds, stream, a);
-  fsr_note_kernel(NA == 2 ? "conv_tall3_kernel<%s,%d,%d,%d,%d,%d>" : "conv_tall3_kernel<%s,%d,%d,%d,%d,%d,4>", std::is_same<T, f16_t>::value ? "f16" : "bf16", BN, NW, G, NSLOT, MB);
+  fsr_note_kernel("conv_tall3_kernel<%s,%d,%d,%d,%d,%d,%d>", std::is_same<T, f16_t>::value ? "f16" : "bf16", BN, NW, G, NSLOT, MB, NA);
   const int rc = fsr_check_launch("conv_tall3_kernel");
   return rc ? rc : 1;
 }

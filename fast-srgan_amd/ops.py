@@ -159,6 +159,17 @@ def _zeros(shape, device):
     return torch.zeros(shape, dtype=torch.float32, device=device)
 
 
+def _assigned(shape, device):
+    """float32 scratch for a result the kernels ASSIGN (the order-fixed second-level reduce overwrites it): from the
+    iteration's arena when one is open, else uninitialised -- inference then launches no fill kernel per statistics tensor."""
+    pool = _zero_pool.get(str(device))
+    if pool is not None and pool.active:
+        t = pool.take(tuple(shape))
+        if t is not None:
+            return t
+    return torch.empty(shape, dtype=torch.float32, device=device)
+
+
 def _const_vec(values, device):
     """Small float constant vector on `device`, uploaded once (no host-to-device copies inside captured steps)."""
     key = (tuple(values), str(device))
@@ -338,7 +349,7 @@ def conv3x3_raw(cd, x, wpk, cout, *, mode=L.CONV_FWD, out_hw=None, stride=1, bia
     oshape = (n, 2 * oh, 2 * ow, cout // 4) if pixel_shuffle else ((n, oh // 2, ow // 2, cout) if pool2 else (n, oh, ow, cout))
     out = torch.empty(oshape, dtype=odt, device=x.device)
     pre = torch.empty(oshape, dtype=odt, device=x.device) if want_preact else None
-    stats = _zeros((n, cout, 2), x.device) if want_stats else None
+    stats = _assigned((n, cout, 2), x.device) if want_stats else None
     d = L.ConvDesc(cd.code, mode, n, ih, iw, cin, oh, ow, cout, stride, act, float(slope), int(pixel_shuffle),
                    int(in_pixel_shuffled), L.OUT_U8 if out_u8 else int(out_f32), int(pool2), int(bool(dact_add)))
     scratch = _workspace(L.lib().fsr_conv3x3_scratch(ctypes.byref(d)), x.device) if want_stats else None

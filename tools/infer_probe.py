@@ -12,8 +12,7 @@ for bsz in (1, 8):
     pipe = pkg.InferencePipeline(G, dev, batch=bsz, depth=2)
     for _ in pipe.run(frames[:2 * bsz]):
         pass
-    plan = pipe._plan(h, w)
-    sl = plan[0]
+    sl = pipe._slot(h, w, 0)
     T = {}
     def tick(name, t0):
         torch.cuda.synchronize()
