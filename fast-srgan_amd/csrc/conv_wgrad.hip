@@ -25,8 +25,13 @@
 //                kernel sums the slabs and adds the result into the OIHW float gradient.
 #include "fsr_common.h"
 #include "fsr_host.h"
+#include <cstdlib>
 
 constexpr int WGRAD_GROUP_MAX = 32;
+
+#ifndef FSR_ABLW
+#define FSR_ABLW 0   // ablation builds (tools/build_variant.sh; results are WRONG on purpose): 1 no staging after a slab's first
+#endif               // tile, 2 no LDS -> MFMA phase (memory only), 3 MFMAs on the first fragments only (no transposing reads in the loop)
 
 struct WgradKArgs {
   const void* x;
@@ -48,9 +53,31 @@ struct WgradGroupOut {
   float* dw[WGRAD_GROUP_MAX];
 };
 
+// Staging by LDS-DMA (16-bit, stride 1, 8-wave blocks): the dy tile and the x halo of tile i+1 go global -> LDS with
+// buffer_load ... lds into the OTHER of two LDS images while tile i is multiplied -- no staging registers, no commit pass,
+// one barrier per tile.  A wave instruction fills 1 KB of LDS linearly, i.e. 64 consecutive 16-byte units of the PADDED pixel
+// rows: lane -> (pixel, unit) by one division, the pad units and the out-of-image pixels get an out-of-range offset (zeros).
+template <typename T, int BM, int BN, int S>
+constexpr bool wgrad_dma() {
+  return sizeof(T) == 2 && S == 1 && BM >= 64 && BN == 64;
+}
 template <typename T, int BM, int BN, int S, int TPH>
-__global__ __launch_bounds__((BM == 64 && BN == 64) ? 512 : 256) void conv_wgrad_kernel(const WgradKArgs a) {
-  constexpr int NW = (BM == 64 && BN == 64) ? 8 : 4;   // waves per workgroup
+constexpr int wgrad_dma_dy_instr() {
+  return (TPH * 16 * ((BM + 16) / (16 / (int)sizeof(T))) + 63) / 64;
+}
+template <typename T, int BM, int BN, int S, int TPH>
+constexpr int wgrad_dma_halo_instr() {
+  return (((TPH - 1) * S + 3) * (15 * S + 3) * ((BN + 16) / (16 / (int)sizeof(T))) + 63) / 64;
+}
+template <typename T, int BM, int BN, int S, int TPH>
+constexpr size_t wgrad_dma_lds_bytes() {   // two images of (dy tile, halo), each region rounded up to whole 1 KB DMA pieces
+  return (size_t)2 * 1024 * (wgrad_dma_dy_instr<T, BM, BN, S, TPH>() + wgrad_dma_halo_instr<T, BM, BN, S, TPH>());
+}
+
+template <typename T, int BM, int BN, int S, int TPH>
+__global__ __launch_bounds__((BM >= 64 && BN == 64) ? 512 : 256) void conv_wgrad_kernel(const WgradKArgs a) {
+  constexpr int NW = (BM >= 64 && BN == 64) ? 8 : 4;   // waves per workgroup
+  static_assert(BM <= 64 || (BM == 128 && BN == 64 && sizeof(T) == 2), "128-row blocks: 16-bit, 64 input channels");
   constexpr int NTHR = NW * 64;
   constexpr int EPB = 16 / (int)sizeof(T);
   constexpr int PAD = 16;
@@ -64,11 +91,13 @@ __global__ __launch_bounds__((BM == 64 && BN == 64) ? 512 : 256) void conv_wgrad
 
   HIP_DYNAMIC_SHARED(char, smem)
   T* dyt = (T*)smem;              // [TPIX][PA]
-  T* halo = dyt + TPIX * PA;      // [HH*HW][PB]
+  T* halo = dyt + TPIX * PA;      // [HH*HW][PB]   (LDS-DMA form: two such images, see below)
+  constexpr bool DMA = wgrad_dma<T, BM, BN, S>();
 
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int l15 = lane & 15, lg = lane >> 4;
-  int bid = (int)blockIdx.x;
+  // the nbm x nbn workgroups of one slab read the same dy / x tiles: consecutive logical ids -> one XCD -> one L2
+  int bid = a.group_n > 0 ? (int)blockIdx.x : xcd_remap((int)blockIdx.x, (int)gridDim.x);
   const int layer = a.group_n > 0 ? bid / a.nslab : 0;
   if (a.group_n > 0) bid -= layer * a.nslab;
   const int bn = bid % a.nbn;
@@ -77,10 +106,11 @@ __global__ __launch_bounds__((BM == 64 && BN == 64) ? 512 : 256) void conv_wgrad
   const int slab = bid / a.nbm;
 
   // 64x64 blocks (8 waves): wave -> (pair of co tiles, one ci tile): a transposed x fragment feeds TWO MFMAs, 22 instead
-  // of 38 transposing reads per 18 MFMAs.  Other blocks: wave -> (one co tile, TPW ci tiles).
-  constexpr bool COPAIR = (BM == 64 && BN == 64);
+  // of 38 transposing reads per 18 MFMAs.  128x64 blocks: wave -> (FOUR co tiles, one ci tile), 26 reads per 36 MFMAs and
+  // 144 accumulator registers.  Other blocks: wave -> (one co tile, TPW ci tiles).
+  constexpr bool COPAIR = (BM >= 64 && BN == 64);
   const bool active = wave * TPW < NPAIR;
-  const int co_t = COPAIR ? (wave / NBT) * 2 : (wave * TPW) / NBT;
+  const int co_t = COPAIR ? (wave / NBT) * TPW : (wave * TPW) / NBT;
   const int ci_t0 = COPAIR ? wave % NBT : (wave * TPW) % NBT;
 
   f32x4 acc[9][TPW];
@@ -164,15 +194,141 @@ __global__ __launch_bounds__((BM == 64 && BN == 64) ? 512 : 256) void conv_wgrad
     }
   };
 
-  if (tile0 < tile1) stage_issue(tile0);
-  for (int tile = tile0; tile < tile1; ++tile) {
-    __syncthreads();  // the previous tile's LDS images are dead
-    stage_commit();
-    __syncthreads();
-    if (tile + 1 < tile1) stage_issue(tile + 1);
-    if (!active) continue;
+  // ---- LDS-DMA staging: per wave IPW pieces of 1 KB; piece g = j * NW + wave of the image [dy region | halo region]
+  constexpr int UPA = PA / EPB, UPB = PB / EPB;
+  constexpr int DYI = wgrad_dma_dy_instr<T, BM, BN, S, TPH>(), HAI = wgrad_dma_halo_instr<T, BM, BN, S, TPH>();
+  constexpr int NPIECE = DYI + HAI, IPW = (NPIECE + NW - 1) / NW;
+  constexpr unsigned IMG_BYTES = NPIECE * 1024u;
+  unsigned rel[DMA ? IPW : 1], pk[DMA ? IPW : 1];   // per piece and lane: element offset relative to the tile origin; py | px << 8 | invalid << 31
+  if constexpr (DMA) {
+#pragma unroll
+    for (int j = 0; j < IPW; ++j) {
+      const int g = j * NW + wave;
+      unsigned r_ = 0, k_ = 0x80000000u;
+      if (g < DYI) {
+        const int slot = g * 64 + lane, p_ = slot / UPA, u_ = slot - p_ * UPA;
+        const int py = p_ >> 4, px = p_ & 15;
+        const int ch = bm * BM + u_ * EPB;
+        if (!a.dy_ps) {
+          r_ = (unsigned)((py * a.OW + px) * a.CoutPad + ch);
+        } else {
+          const int cps = a.CoutPad >> 2;
+          const int q = ch / cps, cc = ch - q * cps;
+          r_ = (unsigned)(((2 * py + (q >> 1)) * (2 * a.OW) + 2 * px + (q & 1)) * cps + cc);
+        }
+        k_ = (unsigned)py | ((unsigned)px << 8) | ((u_ >= BM / EPB || p_ >= TPIX) ? 0x80000000u : 0u);
+      } else if (g < NPIECE) {
+        const int slot = (g - DYI) * 64 + lane, p_ = slot / UPB, u_ = slot - p_ * UPB;
+        const int py = p_ / HW, px = p_ - py * HW;
+        r_ = (unsigned)((py * a.IW + px) * a.CinPad + bn * BN + u_ * EPB);
+        k_ = (unsigned)py | ((unsigned)px << 8) | ((u_ >= BN / EPB || p_ >= HH * HW) ? 0x80000000u : 0u);
+      }
+      rel[j] = r_;
+      pk[j] = k_;
+    }
+  }
+  const fsr_buf_t dy_buf = fsr_make_buf(dyg, DMA ? (unsigned)((size_t)a.N * a.OH * a.OW * a.CoutPad * sizeof(T)) : 0u);
+  const fsr_buf_t x_buf = fsr_make_buf(xg, DMA ? (unsigned)((size_t)a.N * a.IH * a.IW * a.CinPad * sizeof(T)) : 0u);
+  const fsr_lds_addr_t lds0 = FSR_LDS_ADDR(smem);
+  auto dma_issue = [&](int tile, int image) {
+    const int tx = tile % a.tiles_x;
+    const int ty = (tile / a.tiles_x) % a.tiles_y;
+    const int img = tile / (a.tiles_x * a.tiles_y);
+    const int oy0 = ty * TPH, ox0 = tx * 16;
+    const unsigned dy_base = !a.dy_ps ? (unsigned)((img * a.OH + oy0) * a.OW + ox0) * (unsigned)a.CoutPad
+                                      : (unsigned)((img * 2 * a.OH + 2 * oy0) * (2 * a.OW) + 2 * ox0) * (unsigned)(a.CoutPad >> 2);
+    const int iy0 = oy0 * S - 1, ix0 = ox0 * S - 1;
+    const unsigned x_base = (unsigned)((img * a.IH + iy0) * a.IW + ix0) * (unsigned)a.CinPad;   // may wrap; base + rel of a valid pixel does not
+#pragma unroll
+    for (int j = 0; j < IPW; ++j) {
+      const int g = j * NW + wave;
+      if (NPIECE % NW != 0 && g >= NPIECE) continue;
+      const int py = (int)(pk[j] & 0xffu), px = (int)((pk[j] >> 8) & 0xffu);
+      const bool keep = !(pk[j] >> 31);
+      unsigned voff;
+      if (g < DYI) {
+        const bool ok = keep && oy0 + py < a.OH && ox0 + px < a.OW;
+        voff = ok ? (dy_base + rel[j]) * (unsigned)sizeof(T) : 0xffffffffu;
+        FSR_BLDS16(dy_buf, voff, 0u, lds0 + (fsr_lds_addr_t)(image * IMG_BYTES + g * 1024));
+      } else {
+        const bool ok = keep && (unsigned)(iy0 + py) < (unsigned)a.IH && (unsigned)(ix0 + px) < (unsigned)a.IW;
+        voff = ok ? (x_base + rel[j]) * (unsigned)sizeof(T) : 0xffffffffu;
+        FSR_BLDS16(x_buf, voff, 0u, lds0 + (fsr_lds_addr_t)(image * IMG_BYTES + g * 1024));
+      }
+    }
+  };
 
-    if constexpr (sizeof(T) == 2) {
+  int image = 0;
+  if constexpr (DMA) {
+    if (tile0 < tile1) dma_issue(tile0, 0);
+  } else {
+    if (tile0 < tile1) stage_issue(tile0);
+  }
+  for (int tile = tile0; tile < tile1; ++tile) {
+    if constexpr (DMA) {
+      FSR_WAIT_VM(0);     // this wave's pieces of the tile have landed ...
+      FSR_BARRIER();      // ... and everybody's; all waves are also done with the other image
+#if FSR_ABLW == 1
+      if (false)
+#endif
+      if (tile + 1 < tile1) dma_issue(tile + 1, image ^ 1);
+      dyt = (T*)(smem + image * IMG_BYTES);
+      halo = (T*)(smem + image * IMG_BYTES + DYI * 1024);
+      image ^= 1;
+    } else {
+      __syncthreads();  // the previous tile's LDS images are dead
+#if FSR_ABLW == 1
+      if (tile == tile0) stage_commit();
+      __syncthreads();
+#else
+      stage_commit();
+      __syncthreads();
+      if (tile + 1 < tile1) stage_issue(tile + 1);
+#endif
+    }
+    if (!active) continue;
+#if FSR_ABLW == 2
+    continue;
+#endif
+
+    if constexpr (sizeof(T) == 2 && COPAIR) {
+      // The 8-wave blocks: the tile's NS * 9 (K step, tap) stages unrolled and software-pipelined.  A stage = one transposed
+      // x fragment (2 reads) against the wave's TPW dy fragments (TPW MFMAs = TPW * 16 matrix-pipe cycles): the x fragment of
+      // stage i + 2 is requested before the MFMAs of stage i (ring of three), the dy fragments of K step s + 1 in the middle
+      // of step s (two sets), so a transposing read has two stages -- 130 / 260 cycles -- to come back.  K step = 32 pixels =
+      // tile rows 2s, 2s+1; lane group g owns pixels k = 8g..8g+7: row 2s + (g>>1), columns 8(g&1) .. +7; read h (0/1)
+      // fetches pixels 4h..4h+3: group-lane q supplies pixel 4h + (q>>2), channel chunk q&3.
+      constexpr int NS = TPH / 2, NSTAGE = NS * 9;
+      const int qrow = l15 >> 2, qch = (l15 & 3) * 4, c0 = 8 * (lg & 1);
+      const T* pa_base = dyt + ((lg >> 1) * 16 + c0 + qrow) * PA + co_t * 16 + qch;
+      const T* pb_base = halo + ((lg >> 1) * S * HW + (c0 + qrow) * S) * PB + ci_t0 * 16 + qch;
+      auto frag = [&](const T* p0, int second) {
+        const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(FSR_LDS_PTR(s16x4, p0));
+        const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(FSR_LDS_PTR(s16x4, p0 + second));
+        return (s16x8){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+      };
+      auto xfrag = [&](int i) {   // stage i = (K step i / 9, tap i % 9)
+        const int ks = i / 9, t = i % 9;
+        return frag(pb_base + ((ks * 2 * S + t / 3) * HW + t % 3) * PB, 4 * S * PB);
+      };
+      s16x8 af[2][TPW], bf[3];
+#pragma unroll
+      for (int w = 0; w < TPW; ++w) af[0][w] = frag(pa_base + w * 16, 4 * PA);
+      bf[0] = xfrag(0);
+      bf[1] = xfrag(1);
+#pragma unroll
+      for (int i = 0; i < NSTAGE; ++i) {
+        const int ks = i / 9, t = i % 9;
+        if (i + 2 < NSTAGE) bf[(i + 2) % 3] = xfrag(i + 2);
+        if (t == 4 && ks + 1 < NS) {
+#pragma unroll
+          for (int w = 0; w < TPW; ++w) af[(ks + 1) & 1][w] = frag(pa_base + (ks + 1) * 32 * PA + w * 16, 4 * PA);
+        }
+#pragma unroll
+        for (int w = 0; w < TPW; ++w) acc[t][w] = mfma16<T>(af[ks & 1][w], bf[i % 3], acc[t][w]);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    } else if constexpr (sizeof(T) == 2) {
       // K step = 32 pixels = tile rows 2s, 2s+1; lane group g owns pixels k = 8g..8g+7:
       // row 2s + (g>>1), columns 8(g&1) .. +7.  A transposing read h (0/1) fetches pixels 4h..4h+3:
       // group-lane q supplies pixel 4h + (q>>2), channel chunk q&3.
@@ -195,9 +351,13 @@ __global__ __launch_bounds__((BM == 64 && BN == 64) ? 512 : 256) void conv_wgrad
           const int ky = t / 3, kx = t % 3;
           const T* pb0 = halo + ((r * S + ky) * HW + (c0 + qrow) * S + kx) * PB + ci_t0 * 16 + qch;
           if constexpr (COPAIR) {
+#if FSR_ABLW == 3
+            const s16x8 bf = af[(t + 1) & 1];
+#else
             const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(FSR_LDS_PTR(s16x4, pb0));
             const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(FSR_LDS_PTR(s16x4, pb0 + 4 * S * PB));
             const s16x8 bf = (s16x8){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+#endif
 #pragma unroll
             for (int w = 0; w < TPW; ++w) acc[t][w] = mfma16<T>(af[w], bf, acc[t][w]);
           } else {
@@ -314,7 +474,14 @@ int make_plan(const fsr_wgrad_desc* d, WgradPlan& p) {
   p.S = d->stride;
   p.BM = (d->cout_pad % 64 == 0) ? 64 : 16;
   p.BN = (d->cin_pad % 64 == 0) ? 64 : (d->cin_pad % 32 == 0 ? 32 : 16);
-  if (d->dy_pixel_shuffled && (d->cout_pad / 4) % p.BM) p.BM = 16;  // a BM block must stay inside one quadrant slice
+  // 128 output channels per workgroup where the layer has them: x is fetched Cout / BM times and dy Cin / BN times, and the
+  // 64 x 64 block spends 60 % of its time on that traffic (FSR_WGRAD_BM=64 keeps the 64-row block for an A/B)
+  const char* ebm = getenv("FSR_WGRAD_BM");
+  const bool bm64 = ebm && atoi(ebm) == 64;
+  if (d->dtype != FSR_F32 && p.S == 1 && p.BN == 64 && d->cout_pad % 128 == 0 && !bm64) p.BM = 128;   // (stride 2: measured 30 % slower)
+  // pixel-shuffled dy: the staging resolves the quadrant per 16-byte unit, so a block may span quadrant slices as long as
+  // every 64-row part of it lies inside one
+  if (d->dy_pixel_shuffled && (d->cout_pad / 4) % (p.BM == 128 ? 64 : p.BM)) p.BM = 16;
   p.TPH = d->dtype != FSR_F32 ? 8 : 4;
   p.tiles_x = (d->ow + 15) / 16;
   p.tiles_y = (d->oh + p.TPH - 1) / p.TPH;
@@ -325,6 +492,10 @@ int make_plan(const fsr_wgrad_desc* d, WgradPlan& p) {
   // bandwidth-bound with tiny partials, so they get four per CU to keep more loads in flight
   const int target = (p.BM == 16 || p.BN < 64) ? 1024 : 256;
   int want = (target + p.nbm * p.nbn - 1) / (p.nbm * p.nbn);
+  if (const char* e = getenv("FSR_WGRAD_SLABS")) {   // tests: few slabs, so every workgroup walks several tiles
+    const int v = atoi(e);
+    if (v > 0) want = v;
+  }
   if (want > p.tiles_total) want = p.tiles_total;
   if (want < 1) want = 1;
   p.tiles_per_slab = (p.tiles_total + want - 1) / want;
@@ -340,10 +511,11 @@ int launch_wgrad(const WgradKArgs& a, size_t lds, hipStream_t stream) {
   auto kern = conv_wgrad_kernel<T, BM, BN, S, TPH>;
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+    (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr_set = true;
   }
-  hipLaunchKernelGGL(kern, dim3((unsigned)(a.nslab * a.nbm * a.nbn * (a.group_n > 0 ? a.group_n : 1))), dim3((BM == 64 && BN == 64) ? 512 : 256), lds, stream, a);
+  if constexpr (wgrad_dma<T, BM, BN, S>()) lds = wgrad_dma_lds_bytes<T, BM, BN, S, TPH>();
+  hipLaunchKernelGGL(kern, dim3((unsigned)(a.nslab * a.nbm * a.nbn * (a.group_n > 0 ? a.group_n : 1))), dim3((BM >= 64 && BN == 64) ? 512 : 256), lds, stream, a);
   return fsr_check_launch("conv_wgrad_kernel");
 }
 
@@ -352,6 +524,9 @@ int dispatch_wgrad(const WgradPlan& p, const WgradKArgs& a, hipStream_t stream) 
 #define FSR_WG_CASE(bm, bn)                                                           \
   if (p.BM == bm && p.BN == bn)                                                       \
     return p.S == 1 ? launch_wgrad<T, bm, bn, 1, TPH>(a, p.lds, stream) : launch_wgrad<T, bm, bn, 2, TPH>(a, p.lds, stream);
+  if constexpr (sizeof(T) == 2) {
+    if (p.BM == 128 && p.BN == 64 && p.S == 1) return launch_wgrad<T, 128, 64, 1, TPH>(a, p.lds, stream);
+  }
   FSR_WG_CASE(64, 64)
   FSR_WG_CASE(64, 32)
   FSR_WG_CASE(16, 64)

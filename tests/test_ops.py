@@ -36,7 +36,7 @@ def _big(dev):
 
 @pytest.mark.parametrize("cdn", ["f32", "bf16", "f16"])
 @pytest.mark.parametrize("stride,cin,cout,ps", [(1, 32, 64, False), (1, 64, 64, False), (2, 64, 64, False), (1, 32, 128, True), (1, 64, 3, False),
-                                                (1, 64, 128, False), (1, 64, 256, True)])
+                                                (1, 64, 128, False), (1, 64, 256, True), (2, 64, 128, False)])
 def test_conv_fwd_dgrad_wgrad(dev, cdn, stride, cin, cout, ps):
     cd = ops.Compute(cdn)
     torch.manual_seed(1)
@@ -107,6 +107,29 @@ def test_conv_wgrad_grouped(dev, cdn, nlayers):
         F.conv2d(x, wr, None, 1, 1).backward(g)
         assert relerr(a - 0.5, wr.grad) < tol(cdn, 2e-5, 2e-3)
         assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize("cdn", ["bf16", "f16"])
+@pytest.mark.parametrize("cout,ps,bm", [(64, False, 0), (128, False, 0), (128, False, 64), (256, True, 0)])
+def test_conv_wgrad_walks_several_tiles_per_slab(dev, cdn, cout, ps, bm, monkeypatch):
+    """The LDS-DMA staging of the 16-bit stride-1 weight gradient (conv_wgrad.hip: two LDS images, tile i+1 in flight while
+    tile i is multiplied) with FSR_WGRAD_SLABS=2, i.e. every workgroup walks a RANGE of tiles through both images, ragged
+    image edges included; the 128-row block and (FSR_WGRAD_BM=64) the 64-row one; pixel-shuffled dy spanning two quadrants."""
+    monkeypatch.setenv("FSR_WGRAD_SLABS", "2")
+    if bm:
+        monkeypatch.setenv("FSR_WGRAD_BM", str(bm))
+    cd = ops.Compute(cdn)
+    torch.manual_seed(21)
+    n, h, w = (3, 37, 45) if _big(dev) else (2, 11, 21)
+    x = _q(torch.randn(n, 64, h, w), cd)
+    g = _q(torch.randn(n, cout, h, w), cd)
+    wr = leaf(torch.zeros(cout, 64, 3, 3))
+    F.conv2d(x, wr, None, 1, 1).backward(g)
+    gd = _nhwc(F.pixel_shuffle(g, 2), cd, dev) if ps else _nhwc(g, cd, dev)
+    dw = ops.conv3x3_wgrad_raw(cd, _nhwc(x, cd, dev), gd, cout, 64, 1, dy_pixel_shuffled=ps)
+    assert relerr(dw.cpu(), wr.grad) < tol(cdn, 2e-5, 2e-3)
+    dw2 = ops.conv3x3_wgrad_raw(cd, _nhwc(x, cd, dev), gd, cout, 64, 1, dy_pixel_shuffled=ps)
+    assert torch.equal(dw, dw2)
 
 
 @pytest.mark.parametrize("mode", [0, 30, 62, 1374, 1406, 34142])
