@@ -31,7 +31,8 @@ constexpr int WGRAD_GROUP_MAX = 32;
 
 #ifndef FSR_ABLW
 #define FSR_ABLW 0   // ablation builds (tools/build_variant.sh; results are WRONG on purpose): 1 no staging after a slab's first
-#endif               // tile, 2 no LDS -> MFMA phase (memory only), 3 MFMAs on the first fragments only (no transposing reads in the loop)
+#endif               // tile, 2 no LDS -> MFMA phase (memory only), 3 MFMAs on the first fragments only (no transposing reads in the loop),
+                     // 4 no DMA wait, 5 no barrier, 6 neither, 7 DMA pieces with every lane out of range (LDS writes without memory traffic)
 
 struct WgradKArgs {
   const void* x;
@@ -230,32 +231,51 @@ __global__ __launch_bounds__((BM >= 64 && BN == 64) ? 512 : 256) void conv_wgrad
   const fsr_buf_t dy_buf = fsr_make_buf(dyg, DMA ? (unsigned)((size_t)a.N * a.OH * a.OW * a.CoutPad * sizeof(T)) : 0u);
   const fsr_buf_t x_buf = fsr_make_buf(xg, DMA ? (unsigned)((size_t)a.N * a.IH * a.IW * a.CinPad * sizeof(T)) : 0u);
   const fsr_lds_addr_t lds0 = FSR_LDS_ADDR(smem);
-  auto dma_issue = [&](int tile, int image) {
+  struct DmaTile {   // wave-uniform description of the tile being fetched
+    int oy0, ox0, iy0, ix0;
+    unsigned dy_base, x_base;
+    fsr_lds_addr_t lds;
+    bool on;
+  };
+  auto dma_tile = [&](int tile, int image, bool on) {
+    DmaTile d;
     const int tx = tile % a.tiles_x;
     const int ty = (tile / a.tiles_x) % a.tiles_y;
     const int img = tile / (a.tiles_x * a.tiles_y);
-    const int oy0 = ty * TPH, ox0 = tx * 16;
-    const unsigned dy_base = !a.dy_ps ? (unsigned)((img * a.OH + oy0) * a.OW + ox0) * (unsigned)a.CoutPad
-                                      : (unsigned)((img * 2 * a.OH + 2 * oy0) * (2 * a.OW) + 2 * ox0) * (unsigned)(a.CoutPad >> 2);
-    const int iy0 = oy0 * S - 1, ix0 = ox0 * S - 1;
-    const unsigned x_base = (unsigned)((img * a.IH + iy0) * a.IW + ix0) * (unsigned)a.CinPad;   // may wrap; base + rel of a valid pixel does not
-#pragma unroll
-    for (int j = 0; j < IPW; ++j) {
-      const int g = j * NW + wave;
-      if (NPIECE % NW != 0 && g >= NPIECE) continue;
-      const int py = (int)(pk[j] & 0xffu), px = (int)((pk[j] >> 8) & 0xffu);
-      const bool keep = !(pk[j] >> 31);
-      unsigned voff;
-      if (g < DYI) {
-        const bool ok = keep && oy0 + py < a.OH && ox0 + px < a.OW;
-        voff = ok ? (dy_base + rel[j]) * (unsigned)sizeof(T) : 0xffffffffu;
-        FSR_BLDS16(dy_buf, voff, 0u, lds0 + (fsr_lds_addr_t)(image * IMG_BYTES + g * 1024));
-      } else {
-        const bool ok = keep && (unsigned)(iy0 + py) < (unsigned)a.IH && (unsigned)(ix0 + px) < (unsigned)a.IW;
-        voff = ok ? (x_base + rel[j]) * (unsigned)sizeof(T) : 0xffffffffu;
-        FSR_BLDS16(x_buf, voff, 0u, lds0 + (fsr_lds_addr_t)(image * IMG_BYTES + g * 1024));
-      }
+    d.oy0 = ty * TPH;
+    d.ox0 = tx * 16;
+    d.dy_base = !a.dy_ps ? (unsigned)((img * a.OH + d.oy0) * a.OW + d.ox0) * (unsigned)a.CoutPad
+                         : (unsigned)((img * 2 * a.OH + 2 * d.oy0) * (2 * a.OW) + 2 * d.ox0) * (unsigned)(a.CoutPad >> 2);
+    d.iy0 = d.oy0 * S - 1;
+    d.ix0 = d.ox0 * S - 1;
+    d.x_base = (unsigned)((img * a.IH + d.iy0) * a.IW + d.ix0) * (unsigned)a.CinPad;   // may wrap; base + rel of a valid pixel does not
+    d.lds = lds0 + (fsr_lds_addr_t)(image * IMG_BYTES);
+    d.on = on;
+    return d;
+  };
+  auto dma_piece = [&](const DmaTile& d, int j) {   // j: compile-time after unrolling
+    const int g = j * NW + wave;
+    if (!d.on || (NPIECE % NW != 0 && g >= NPIECE)) return;
+    const int py = (int)(pk[j] & 0xffu), px = (int)((pk[j] >> 8) & 0xffu);
+#if FSR_ABLW == 7
+    const bool keep = false;             // every lane out of range: the pieces still write (zeros) to LDS, no memory traffic
+#else
+    const bool keep = !(pk[j] >> 31);
+#endif
+    if (g < DYI) {
+      const bool ok = keep && d.oy0 + py < a.OH && d.ox0 + px < a.OW;
+      const unsigned voff = ok ? (d.dy_base + rel[j]) * (unsigned)sizeof(T) : 0xffffffffu;
+      FSR_BLDS16(dy_buf, voff, 0u, d.lds + (fsr_lds_addr_t)(g * 1024));
+    } else {
+      const bool ok = keep && (unsigned)(d.iy0 + py) < (unsigned)a.IH && (unsigned)(d.ix0 + px) < (unsigned)a.IW;
+      const unsigned voff = ok ? (d.x_base + rel[j]) * (unsigned)sizeof(T) : 0xffffffffu;
+      FSR_BLDS16(x_buf, voff, 0u, d.lds + (fsr_lds_addr_t)(g * 1024));
     }
+  };
+  auto dma_issue = [&](int tile, int image) {
+    const DmaTile d = dma_tile(tile, image, true);
+#pragma unroll
+    for (int j = 0; j < IPW; ++j) dma_piece(d, j);
   };
 
   int image = 0;
@@ -266,12 +286,17 @@ __global__ __launch_bounds__((BM >= 64 && BN == 64) ? 512 : 256) void conv_wgrad
   }
   for (int tile = tile0; tile < tile1; ++tile) {
     if constexpr (DMA) {
+#if FSR_ABLW != 4 && FSR_ABLW != 6
       FSR_WAIT_VM(0);     // this wave's pieces of the tile have landed ...
-      FSR_BARRIER();      // ... and everybody's; all waves are also done with the other image
-#if FSR_ABLW == 1
-      if (false)
 #endif
+#if FSR_ABLW != 5 && FSR_ABLW != 6
+      FSR_BARRIER();      // ... and everybody's; all waves are also done with the other image
+#endif
+      // the next tile's pieces, all at once (spreading them over the tile's stages measured +-0: what the traffic costs is
+      // shader clock and memory-system time, not issue slots or LDS write cycles -- profiles/r03_wgrad_ablation.txt)
+#if FSR_ABLW != 1
       if (tile + 1 < tile1) dma_issue(tile + 1, image ^ 1);
+#endif
       dyt = (T*)(smem + image * IMG_BYTES);
       halo = (T*)(smem + image * IMG_BYTES + DYI * 1024);
       image ^= 1;
