@@ -58,9 +58,9 @@ struct WgradGroupOut {
 // buffer_load ... lds into the OTHER of two LDS images while tile i is multiplied -- no staging registers, no commit pass,
 // one barrier per tile.  A wave instruction fills 1 KB of LDS linearly, i.e. 64 consecutive 16-byte units of the PADDED pixel
 // rows: lane -> (pixel, unit) by one division, the pad units and the out-of-image pixels get an out-of-range offset (zeros).
-template <typename T, int BM, int BN, int S>
-constexpr bool wgrad_dma() {
-  return sizeof(T) == 2 && S == 1 && BM >= 64 && BN == 64;
+template <typename T, int BM, int BN, int S, int TPH>
+constexpr bool wgrad_dma() {   // stride 2: the halo of an 8-row tile is 90 KB, two images only fit with 4-row tiles
+  return sizeof(T) == 2 && BM >= 64 && BN == 64 && (S == 1 || TPH == 4);
 }
 template <typename T, int BM, int BN, int S, int TPH>
 constexpr int wgrad_dma_dy_instr() {
@@ -93,7 +93,7 @@ __global__ __launch_bounds__((BM >= 64 && BN == 64) ? 512 : 256) void conv_wgrad
   HIP_DYNAMIC_SHARED(char, smem)
   T* dyt = (T*)smem;              // [TPIX][PA]
   T* halo = dyt + TPIX * PA;      // [HH*HW][PB]   (LDS-DMA form: two such images, see below)
-  constexpr bool DMA = wgrad_dma<T, BM, BN, S>();
+  constexpr bool DMA = wgrad_dma<T, BM, BN, S, TPH>();
 
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int l15 = lane & 15, lg = lane >> 4;
@@ -503,11 +503,16 @@ int make_plan(const fsr_wgrad_desc* d, WgradPlan& p) {
   // 64 x 64 block spends 60 % of its time on that traffic (FSR_WGRAD_BM=64 keeps the 64-row block for an A/B)
   const char* ebm = getenv("FSR_WGRAD_BM");
   const bool bm64 = ebm && atoi(ebm) == 64;
-  if (d->dtype != FSR_F32 && p.S == 1 && p.BN == 64 && d->cout_pad % 128 == 0 && !bm64) p.BM = 128;   // (stride 2: measured 30 % slower)
+  if (d->dtype != FSR_F32 && p.BN == 64 && d->cout_pad % 128 == 0 && !bm64) p.BM = 128;
   // pixel-shuffled dy: the staging resolves the quadrant per 16-byte unit, so a block may span quadrant slices as long as
   // every 64-row part of it lies inside one
   if (d->dy_pixel_shuffled && (d->cout_pad / 4) % (p.BM == 128 ? 64 : p.BM)) p.BM = 16;
   p.TPH = d->dtype != FSR_F32 ? 8 : 4;
+  {
+    const char* e2 = getenv("FSR_WGRAD_S2");
+    if (d->dtype != FSR_F32 && p.S == 2 && p.BM >= 64 && p.BN == 64 && !(e2 && atoi(e2) == 8)) p.TPH = 4;   // LDS-DMA form, 4-row tiles
+    if (p.S == 2 && p.TPH == 8 && p.BM == 128) p.BM = 64;   // the register-staged 8-row form has no 128-row block
+  }
   p.tiles_x = (d->ow + 15) / 16;
   p.tiles_y = (d->oh + p.TPH - 1) / p.TPH;
   p.tiles_total = p.tiles_x * p.tiles_y * d->n;
@@ -539,13 +544,21 @@ int launch_wgrad(const WgradKArgs& a, size_t lds, hipStream_t stream) {
     (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr_set = true;
   }
-  if constexpr (wgrad_dma<T, BM, BN, S>()) lds = wgrad_dma_lds_bytes<T, BM, BN, S, TPH>();
+  if constexpr (wgrad_dma<T, BM, BN, S, TPH>()) lds = wgrad_dma_lds_bytes<T, BM, BN, S, TPH>();
   hipLaunchKernelGGL(kern, dim3((unsigned)(a.nslab * a.nbm * a.nbn * (a.group_n > 0 ? a.group_n : 1))), dim3((BM >= 64 && BN == 64) ? 512 : 256), lds, stream, a);
   return fsr_check_launch("conv_wgrad_kernel");
 }
 
 template <typename T, int TPH>
 int dispatch_wgrad(const WgradPlan& p, const WgradKArgs& a, hipStream_t stream) {
+  if constexpr (sizeof(T) == 2 && TPH == 8) {
+    if (p.TPH == 4) {   // 16-bit stride 2, 64 input channels per block: LDS-DMA staging with 4-row tiles
+      if (p.S != 2 || p.BN != 64) return fsr_fail(-2, "conv3x3_wgrad: 4-row tiles are a stride-2 configuration");
+      if (p.BM == 128) return launch_wgrad<T, 128, 64, 2, 4>(a, p.lds, stream);
+      if (p.BM == 64) return launch_wgrad<T, 64, 64, 2, 4>(a, p.lds, stream);
+      return fsr_fail(-2, "conv3x3_wgrad: no 4-row kernel for block %dx%d", p.BM, p.BN);
+    }
+  }
 #define FSR_WG_CASE(bm, bn)                                                           \
   if (p.BM == bm && p.BN == bn)                                                       \
     return p.S == 1 ? launch_wgrad<T, bm, bn, 1, TPH>(a, p.lds, stream) : launch_wgrad<T, bm, bn, 2, TPH>(a, p.lds, stream);

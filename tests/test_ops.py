@@ -110,11 +110,13 @@ def test_conv_wgrad_grouped(dev, cdn, nlayers):
 
 
 @pytest.mark.parametrize("cdn", ["bf16", "f16"])
-@pytest.mark.parametrize("cout,ps,bm", [(64, False, 0), (128, False, 0), (128, False, 64), (256, True, 0)])
-def test_conv_wgrad_walks_several_tiles_per_slab(dev, cdn, cout, ps, bm, monkeypatch):
+@pytest.mark.parametrize("cout,ps,bm,stride", [(64, False, 0, 1), (128, False, 0, 1), (128, False, 64, 1), (256, True, 0, 1),
+                                               (64, False, 0, 2), (128, False, 0, 2)])
+def test_conv_wgrad_walks_several_tiles_per_slab(dev, cdn, cout, ps, bm, stride, monkeypatch):
     """The LDS-DMA staging of the 16-bit stride-1 weight gradient (conv_wgrad.hip: two LDS images, tile i+1 in flight while
     tile i is multiplied) with FSR_WGRAD_SLABS=2, i.e. every workgroup walks a RANGE of tiles through both images, ragged
-    image edges included; the 128-row block and (FSR_WGRAD_BM=64) the 64-row one; pixel-shuffled dy spanning two quadrants."""
+    image edges included; the 128-row block and (FSR_WGRAD_BM=64) the 64-row one; pixel-shuffled dy spanning two quadrants;
+    stride 2 (4-row tiles, odd image sizes)."""
     monkeypatch.setenv("FSR_WGRAD_SLABS", "2")
     if bm:
         monkeypatch.setenv("FSR_WGRAD_BM", str(bm))
@@ -122,13 +124,13 @@ def test_conv_wgrad_walks_several_tiles_per_slab(dev, cdn, cout, ps, bm, monkeyp
     torch.manual_seed(21)
     n, h, w = (3, 37, 45) if _big(dev) else (2, 11, 21)
     x = _q(torch.randn(n, 64, h, w), cd)
-    g = _q(torch.randn(n, cout, h, w), cd)
+    g = _q(torch.randn(n, cout, (h - 1) // stride + 1, (w - 1) // stride + 1), cd)
     wr = leaf(torch.zeros(cout, 64, 3, 3))
-    F.conv2d(x, wr, None, 1, 1).backward(g)
+    F.conv2d(x, wr, None, stride, 1).backward(g)
     gd = _nhwc(F.pixel_shuffle(g, 2), cd, dev) if ps else _nhwc(g, cd, dev)
-    dw = ops.conv3x3_wgrad_raw(cd, _nhwc(x, cd, dev), gd, cout, 64, 1, dy_pixel_shuffled=ps)
+    dw = ops.conv3x3_wgrad_raw(cd, _nhwc(x, cd, dev), gd, cout, 64, stride, dy_pixel_shuffled=ps)
     assert relerr(dw.cpu(), wr.grad) < tol(cdn, 2e-5, 2e-3)
-    dw2 = ops.conv3x3_wgrad_raw(cd, _nhwc(x, cd, dev), gd, cout, 64, 1, dy_pixel_shuffled=ps)
+    dw2 = ops.conv3x3_wgrad_raw(cd, _nhwc(x, cd, dev), gd, cout, 64, stride, dy_pixel_shuffled=ps)
     assert torch.equal(dw, dw2)
 
 
