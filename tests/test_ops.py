@@ -4,7 +4,7 @@ import pytest
 import torch
 import torch.nn.functional as F
 
-from backend import BACKENDS, L, ops, relerr, relerr2, select, tol
+from backend import BACKENDS, L, ops, relerr, relerr2, report, select, tol
 from oracle import srgan_cpu as O
 
 
@@ -132,6 +132,31 @@ def test_conv_wgrad_walks_several_tiles_per_slab(dev, cdn, cout, ps, bm, stride,
     assert relerr(dw.cpu(), wr.grad) < tol(cdn, 2e-5, 2e-3)
     dw2 = ops.conv3x3_wgrad_raw(cd, _nhwc(x, cd, dev), gd, cout, 64, stride, dy_pixel_shuffled=ps)
     assert torch.equal(dw, dw2)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("batch", [4, 8])
+@pytest.mark.parametrize("name,cin,cout,hw,stride,ps", [
+    ("G up0", 64, 256, 96, 1, True), ("G up1", 64, 256, 192, 1, True), ("D s2 64", 64, 64, 384, 2, False), ("D 64-128", 64, 128, 192, 1, False),
+    ("D s2 128", 128, 128, 192, 2, False), ("D 128-256", 128, 256, 96, 1, False), ("D s2 256", 256, 256, 96, 2, False),
+    ("D 256-512", 256, 512, 48, 1, False), ("D s2 512", 512, 512, 48, 2, False)])
+def test_conv_wgrad_forms_agree_at_training_shapes(name, cin, cout, hw, stride, ps, batch, monkeypatch):
+    """Both operands are 16-bit and every form accumulates in f32, so the 128-row / 4-row-tile LDS-DMA forms and the 64-row /
+    8-row forms (FSR_WGRAD_BM=64, FSR_WGRAD_S2=8: bit-identical to the round-2 kernel) may differ by summation order only --
+    at the layer shapes of the training iteration (tools/convergence.py's batch 4 / 8), with gradient-like operand scales."""
+    dev = select("hip")
+    cd = ops.Compute("bf16")
+    torch.manual_seed(5)
+    oh = (hw - 1) // stride + 1
+    x = (torch.randn(batch, hw, hw, cin, device=dev) * 0.7).to(cd.torch_dtype)
+    dy = (torch.randn((batch, 2 * oh, 2 * oh, cout // 4) if ps else (batch, oh, oh, cout), device=dev) * 1e-3).to(cd.torch_dtype)
+    new = ops.conv3x3_wgrad_raw(cd, x, dy, cout, cin, stride, dy_pixel_shuffled=ps).clone()
+    monkeypatch.setenv("FSR_WGRAD_BM", "64")
+    monkeypatch.setenv("FSR_WGRAD_S2", "8")
+    old = ops.conv3x3_wgrad_raw(cd, x, dy, cout, cin, stride, dy_pixel_shuffled=ps).clone()
+    err = float((new - old).abs().max() / old.abs().max())
+    report("wgrad forms %s b%d" % (name, batch), err)
+    assert err < 2e-5, (name, err)
 
 
 @pytest.mark.parametrize("mode", [0, 30, 62, 1374, 1406, 34142])

@@ -7,10 +7,15 @@ set (low-pass filtered noise images; LR = antialiased-bicubic 4x reduction, data
 
   * the exact-f32 MFMA mode with label-noise seeds 0, 1, 2  -> the fp32 run-to-run BAND (the kernels are bit-reproducible,
     so the only run-to-run variation real training has is its label noise, trainer.py:175-176,187);
-  * the 16-bit mode(s) with label-noise seed 0.
+  * the 16-bit mode(s) with the SAME three label-noise seeds; the quantity compared with the band is the MEDIAN of the three
+    runs.  (One run per mode was not a measurement: GAN training is chaotic -- a 3e-7 relative change of the weight gradients,
+    i.e. another summation order, moved bf16 / seed 0 from a content loss of 0.0025 to 0.019 and from 14.6 to 6.3 dB PSNR,
+    deterministically, while seeds 1-4 of the same build and seed 0 of three neighbouring builds stayed inside the band:
+    profiles/r03_convergence.txt, tests/probes/bf16_trajectory_probe.py.)
 
 Reported: the four loss curves (box-smoothed) at checkpoints, PSNR / SSIM of the generator on a fixed held-out batch at the
-end, and for every 16-bit quantity its distance from the fp32 band in units of the band's half-width.
+end, and for every 16-bit quantity -- median and the three single runs -- its distance from the fp32 band in units of the band's
+half-width.
 tests/test_convergence.py runs the same code and gates on it; `python tools/convergence.py` writes the table that is committed
 under profiles/.
 """
@@ -100,38 +105,46 @@ def smooth_at(curve, t, window):
     return sum(seg) / len(seg)
 
 
+def _median(xs):
+    xs = sorted(xs)
+    n = len(xs)
+    return xs[n // 2] if n % 2 else 0.5 * (xs[n // 2 - 1] + xs[n // 2])
+
+
 def compare(results, iters, window=25, every=50):
-    """results: {"f32": [run, run, run], "<16-bit mode>": run, ...}.  Returns rows + the worst band distance per mode."""
+    """results: {"f32": [run, run, run], "<16-bit mode>": [run, ...] (or one run), ...}.
+    Returns rows (mode, quantity, iteration, band lo, band hi, MEDIAN of the mode's runs, its distance, the single runs' values),
+    and per mode the worst distance of the median and of any single run."""
     cps = list(range(every, iters + 1, every))
     f32 = results["f32"]
-    rows, worst = [], {}
-    for mode, r in results.items():
+    rows, worst, worst_single = [], {}, {}
+    for mode, rs in results.items():
         if mode == "f32":
             continue
-        w = 0.0
-        keys = list(LOSSES) + (["pretrain_loss"] if "pretrain_loss" in r["curves"] else [])
-        for k in keys:
-            for t in (cps if k != "pretrain_loss" else [c for c in cps if c <= len(r["curves"][k])]):
-                ref = [smooth_at(x["curves"][k], t, window) for x in f32]
-                lo, hi = min(ref), max(ref)
-                mid, half = 0.5 * (lo + hi), max(0.5 * (hi - lo), 0.02 * abs(0.5 * (lo + hi)), 1e-6)
-                v = smooth_at(r["curves"][k], t, window)
-                dist = abs(v - mid) / half          # 1.0 = on the edge of the fp32 band (band floored at +-2 % of the value)
-                w = max(w, dist)
-                rows.append((mode, k, t, lo, hi, v, dist))
-        for q in ("psnr", "ssim"):
-            ref = [x[q] for x in f32]
+        rs = rs if isinstance(rs, list) else [rs]
+        w = ws = 0.0
+        keys = list(LOSSES) + (["pretrain_loss"] if "pretrain_loss" in rs[0]["curves"] else [])
+
+        def judge(k, t, ref, vals, floor_rel, floor_abs):
+            nonlocal w, ws
             lo, hi = min(ref), max(ref)
-            floor = 0.1 if q == "psnr" else 0.002
-            mid, half = 0.5 * (lo + hi), max(0.5 * (hi - lo), floor)
-            dist = abs(r[q] - mid) / half
+            mid, half = 0.5 * (lo + hi), max(0.5 * (hi - lo), floor_rel * abs(0.5 * (lo + hi)), floor_abs)
+            v = _median(vals)
+            dist = abs(v - mid) / half          # 1.0 = on the edge of the fp32 band
             w = max(w, dist)
-            rows.append((mode, q, iters, lo, hi, r[q], dist))
-        worst[mode] = w
-    return rows, worst
+            ws = max(ws, max(abs(x - mid) / half for x in vals))
+            rows.append((mode, k, t, lo, hi, v, dist, tuple(vals)))
+
+        for k in keys:
+            for t in (cps if k != "pretrain_loss" else [c for c in cps if c <= len(rs[0]["curves"][k])]):
+                judge(k, t, [smooth_at(x["curves"][k], t, window) for x in f32], [smooth_at(r["curves"][k], t, window) for r in rs], 0.02, 1e-6)
+        for q in ("psnr", "ssim"):
+            judge(q, iters, [x[q] for x in f32], [r[q] for r in rs], 0.0, 0.1 if q == "psnr" else 0.002)
+        worst[mode], worst_single[mode] = w, ws
+    return rows, worst, worst_single
 
 
-def main(iters=300, modes=("bf16", "f16"), out_json=None, log=print):
+def main(iters=300, modes=("bf16", "f16"), out_json=None, log=print, seeds=(0, 1, 2)):
     pkg = importlib.import_module("fast-srgan_amd")
     pkg._lib.lib()
 
@@ -143,30 +156,32 @@ def main(iters=300, modes=("bf16", "f16"), out_json=None, log=print):
     hr_eval = synthetic_dataset(8, 384, seed=8)
     lr_eval = reduce4(hr_eval)
     results = {"f32": []}
-    for seed in (0, 1, 2):
+    for seed in seeds:
         log("f32, label-noise seed %d" % seed)
         results["f32"].append(run(pkg, "f32", iters, seed, hr_all, lr_all, hr_eval, lr_eval, log=log))
     for mode in modes:
-        log("%s, label-noise seed 0" % mode)
-        results[mode] = run(pkg, mode, iters, 0, hr_all, lr_all, hr_eval, lr_eval, log=log)
-    rows, worst = compare(results, iters)
+        results[mode] = []
+        for seed in seeds:
+            log("%s, label-noise seed %d" % (mode, seed))
+            results[mode].append(run(pkg, mode, iters, seed, hr_all, lr_all, hr_eval, lr_eval, log=log))
+    rows, worst, worst_single = compare(results, iters)
     log("")
-    log("%-5s %-13s %5s   %-25s %10s   %s" % ("mode", "quantity", "iter", "fp32 band (3 noise seeds)", "16-bit", "distance / half-width"))
-    for mode, k, t, lo, hi, v, dist in rows:
-        log("%-5s %-13s %5d   [%10.5f, %10.5f]   %10.5f   %.2f" % (mode, k, t, lo, hi, v, dist))
-    for mode, w in worst.items():
-        log("worst distance from the fp32 band, %s: %.2f half-widths" % (mode, w))
+    log("%-5s %-13s %5s   %-25s %10s  %-9s  %s" % ("mode", "quantity", "iter", "fp32 band (%d noise seeds)" % len(seeds), "median", "distance", "the single runs"))
+    for mode, k, t, lo, hi, v, dist, vals in rows:
+        log("%-5s %-13s %5d   [%10.5f, %10.5f]   %10.5f   %6.2f     %s" % (mode, k, t, lo, hi, v, dist, "  ".join("%.5f" % x for x in vals)))
+    for mode in worst:
+        log("worst distance from the fp32 band, %s: median of %d runs %.2f half-widths, any single run %.2f" % (mode, len(seeds), worst[mode], worst_single[mode]))
     for m in modes:
-        if results[m].get("loss_scale"):
-            log("%s dynamic loss scale: final %.0f, %d skipped iterations" % ((m,) + tuple(results[m]["loss_scale"])))
-    log("final PSNR / SSIM on the held-out batch: f32 %s, %s" % (
+        for r in results[m]:
+            if r.get("loss_scale"):
+                log("%s dynamic loss scale: final %.0f, %d skipped iterations" % ((m,) + tuple(r["loss_scale"])))
+    log("final PSNR / SSIM on the held-out batch: f32 %s; %s" % (
         ", ".join("%.3f dB / %.4f" % (x["psnr"], x["ssim"]) for x in results["f32"]),
-        ", ".join("%s %.3f dB / %.4f" % (m, results[m]["psnr"], results[m]["ssim"]) for m in modes)))
+        "; ".join("%s %s" % (m, ", ".join("%.3f dB / %.4f" % (x["psnr"], x["ssim"]) for x in results[m])) for m in modes)))
     if out_json:
-        slim = {m: ([{k: v for k, v in x.items() if k != "curves"} for x in r] if isinstance(r, list) else {k: v for k, v in r.items() if k != "curves"})
-                for m, r in results.items()}
-        json.dump({"iters": iters, "summary": slim, "worst_band_distance": worst,
-                   "rows": [dict(mode=a, quantity=b, iteration=c, f32_lo=d, f32_hi=e, value=f, distance=g) for a, b, c, d, e, f, g in rows]},
+        slim = {m: [{k: v for k, v in x.items() if k != "curves"} for x in r] for m, r in results.items()}
+        json.dump({"iters": iters, "summary": slim, "worst_band_distance_of_median": worst, "worst_band_distance_single_run": worst_single,
+                   "rows": [dict(mode=a, quantity=b, iteration=c, f32_lo=d, f32_hi=e, median=f, distance=g, runs=list(h)) for a, b, c, d, e, f, g, h in rows]},
                   open(out_json, "w"), indent=1)
     return results, rows, worst
 
