@@ -67,7 +67,7 @@ __device__ __forceinline__ V t3_lds_read(const char* smem, unsigned off) {
   return *FSR_LDS_PTR(const V, smem + off);
 }
 
-template <typename T, int BN, int NW, int G, int NSLOT, int MB, int NA = 2>
+template <typename T, int BN, int NW, int G, int NSLOT, int MB, int NA = 2, bool STATS = false>
 __global__ __launch_bounds__(NW * 64, NA == 4 ? 1 : 2) void conv_tall3_kernel(const ConvKArgs a) {
   // a wave owns 32 * MB pixels x 32 * NA channels.  NA = 2: two waves per SIMD (256 registers each); NA = 4 (with MB = 4: the
   // 128 x 128 wave tile, 256 accumulator registers in the AGPR half of the file): ONE 512-register wave per SIMD, 8 fragment
@@ -377,6 +377,7 @@ __global__ __launch_bounds__(NW * 64, NA == 4 ? 1 : 2) void conv_tall3_kernel(co
             }
           } else if (ok && !(a.t3_dbg & 1)) {
             const unsigned off = (unsigned)((oimg * a.FOH + gy) * a.FOW + gx) * (unsigned)a.Cout + (unsigned)co;
+
             if (maskp) {   // fused activation backward of the producing layer: dz = dx * act'(y), y = the saved forward input
               const u32x4 k0 = *(const u32x4*)(maskp + off), k1 = *(const u32x4*)(maskp + off + 8);
               const float ms = a.dmask_slope;
@@ -411,6 +412,59 @@ __global__ __launch_bounds__(NW * 64, NA == 4 ? 1 : 2) void conv_tall3_kernel(co
         });
       });
     };
+    if constexpr (STATS) {
+      // InstanceNorm statistics of the pre-activation (bias included), from the f32 accumulators, in a pass of its own BEFORE
+      // the store loop and eight channels at a time: beside the accumulators it keeps 16 registers alive (the kernel has
+      // none to spare), not the store loop's temporaries as well.
+      // Sum over the wave's 32 pixel lanes (lane bits 0..4; bit 5 separates the two channel halves) by a butterfly that
+      // HALVES the register set at its first three steps -- a lane keeps the channels whose index bit matches its lane bit
+      // and hands the others to its partner: 4 + 2 + 1 + 1 + 1 shuffles per 8 channels instead of 40, in a fixed order.
+      // Afterwards the four lanes that differ in bits 0, 1 all hold channel 4*b4 + 2*b3 + b2 (b_i = lane bit i) of the 8.
+      auto butterfly = [&](float (&x)[8]) {
+        static_for<0, 3>([&](auto sc) {
+          constexpr int st = decltype(sc)::value, M = 16 >> st, C = 4 >> st;
+          const bool up = (lane & M) != 0;
+#pragma unroll
+          for (int i = 0; i < C; ++i) {
+            const float send = up ? x[i] : x[i + C];
+            const float keep = up ? x[i + C] : x[i];
+            x[i] = keep + __shfl_xor(send, M, 64);
+          }
+        });
+        x[0] += __shfl_xor(x[0], 2, 64);
+        x[0] += __shfl_xor(x[0], 1, 64);
+      };
+      static_for<0, 2 * NA>([&](auto nc) {
+        constexpr int n = decltype(nc)::value / 2, h = decltype(nc)::value % 2;
+        const int co = onb * BN + wco * (NA * 32) + n * 32 + hi * 16 + h * 8;
+        float s1[8], s2[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) s1[e] = s2[e] = 0.f;
+        static_for<0, MB>([&](auto mc) {
+          constexpr int m = decltype(mc)::value;
+          const int gy = ogy0 + wpx * 2 * MB + 2 * m + lrow;
+          if (gy < a.GH && gx < a.GW) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+              const float v = acc[n][m][h * 8 + e];
+              s1[e] += v;
+              s2[e] = fmaf(v, v, s2[e]);
+            }
+          }
+        });
+        butterfly(s1);
+        butterfly(s2);
+        // one partial slot per (tile, pixel-row group of waves): [img][slot][Cout][2], added in slot order by reduce.hip
+        if (!(lane & 3)) {
+          const int e = ((lane >> 4) & 1) * 4 + ((lane >> 3) & 1) * 2 + ((lane >> 2) & 1);
+          const int slot = ((ogy0 / TH) * a.tiles_x + (ogx0 >> 4)) * (NW / WCO) + wpx;
+          float* sp = a.stats + (((size_t)oimg * a.stats_P + slot) * a.Cout + co + e) * 2;
+          sp[0] = s1[0];
+          sp[1] = s2[0];
+        }
+      });
+      __builtin_amdgcn_sched_barrier(0);
+    }
     if (a.act == FSR_ACT_RELU) store_tile(std::integral_constant<int, FSR_ACT_RELU>{});
     else if (a.act == FSR_ACT_LEAKY) store_tile(std::integral_constant<int, FSR_ACT_LEAKY>{});
     else store_tile(std::integral_constant<int, FSR_ACT_NONE>{});
@@ -451,9 +505,13 @@ int t3_cus() {
   return cus;
 }
 
-template <typename T, int BN, int NW, int G, int NSLOT, int MB, int NA = 2>
+template <typename T, int BN, int NW, int G, int NSLOT, int MB, int NA = 2, bool STATS = false>
 int t3_launch(ConvKArgs& a, int wg_per_cu, hipStream_t stream) {
-  auto kern = conv_tall3_kernel<T, BN, NW, G, NSLOT, MB, NA>;
+  auto kern = conv_tall3_kernel<T, BN, NW, G, NSLOT, MB, NA, STATS>;
+  if (STATS) {   // one partial slot per tile and pixel-row group of waves
+    a.stats_P = a.tiles_x * a.tiles_y * (NW / (BN / (NA * 32)));
+    a.stats_tpi = a.stats_per = 0;
+  }
   constexpr int lds = t3_lds_bytes<BN, G, NSLOT, MB>();
   static bool attr_set = false;
   if (!attr_set) {
@@ -471,7 +529,7 @@ int t3_launch(ConvKArgs& a, int wg_per_cu, hipStream_t stream) {
   long long grid = (long long)t3_cus() * wg_per_cu;
   if (grid > ntiles || !persist) grid = ntiles;
   hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(NW * 64), lds, stream, a);
-  fsr_note_kernel("conv_tall3_kernel<%s,%d,%d,%d,%d,%d,%d>", std::is_same<T, f16_t>::value ? "f16" : "bf16", BN, NW, G, NSLOT, MB, NA);
+  fsr_note_kernel(STATS ? "conv_tall3_kernel<%s,%d,%d,%d,%d,%d,%d,stats>" : "conv_tall3_kernel<%s,%d,%d,%d,%d,%d,%d>", std::is_same<T, f16_t>::value ? "f16" : "bf16", BN, NW, G, NSLOT, MB, NA);
   const int rc = fsr_check_launch("conv_tall3_kernel");
   return rc ? rc : 1;
 }
@@ -483,7 +541,8 @@ int fsr_conv_tall3_try(int dtype, ConvKArgs& a, int S, hipStream_t stream) {
   const int mode = t3_mode();
   if (mode == 0 || (dtype != FSR_BF16 && dtype != FSR_F16) || S != 1 || a.ntaps != 9) return 0;
   if (a.Cin < 128 || a.Cin % 32 != 0 || a.Cout % 128 != 0 || a.CoutPad != a.Cout) return 0;
-  if (a.stats || a.preact || a.oscale || a.ps || a.in_ps || a.out_f32) return 0;
+  if (a.preact || a.oscale || a.ps || a.in_ps || a.out_f32) return 0;
+  if (a.stats && (a.pool2 || a.dmask || (mode & 6))) return 0;   // statistics: the shipped 4-wave form, forward launches
   if (a.act != FSR_ACT_NONE && a.act != FSR_ACT_RELU && a.act != FSR_ACT_LEAKY) return 0;
   if (a.act == FSR_ACT_LEAKY && !(a.slope >= 0.f && a.slope <= 1.f)) return 0;   // the epilogue's max(v, slope * v) form
   if (a.osy != 1 || a.osx != 1 || a.ooy != 0 || a.oox != 0 || a.org_y != -1 || a.org_x != -1) return 0;
@@ -518,10 +577,11 @@ int fsr_conv_tall3_try(int dtype, ConvKArgs& a, int S, hipStream_t stream) {
   a.tiles_y = (a.GH + 4 * best_mb - 1) / (4 * best_mb);
   // FSR_TALL3 & 4 (A/B): the one-wave-per-SIMD form, 128 x 128 per wave (16-row tiles only)
   if ((mode & 4) && a.Cout % 256 == 0 && best_mb == 4 && dtype == FSR_BF16) return t3_launch<bf16_t, 256, 4, 3, 2, 4, 4>(a, 1, stream);
-#define T3_GO(TT, MBV)                                                         \
-  do {                                                                         \
-    if (wide) return t3_launch<TT, 256, 8, 3, 2, MBV>(a, 1, stream);           \
-    return t3_launch<TT, 128, 4, 1, 4, MBV>(a, 2, stream);                     \
+#define T3_GO(TT, MBV)                                                                      \
+  do {                                                                                      \
+    if (a.stats) return t3_launch<TT, 128, 4, 1, 4, MBV, 2, true>(a, 2, stream);            \
+    if (wide) return t3_launch<TT, 256, 8, 3, 2, MBV>(a, 1, stream);                        \
+    return t3_launch<TT, 128, 4, 1, 4, MBV>(a, 2, stream);                                  \
   } while (0)
   if (dtype == FSR_F16) {
     if (best_mb == 4) T3_GO(f16_t, 4);

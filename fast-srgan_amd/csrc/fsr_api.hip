@@ -47,10 +47,11 @@ extern "C" int fsr_device_info(char* buf, size_t buflen) {
 }
 
 // Upper bound of the partial slots per image over every kernel configuration the dispatch may pick: one slot per
-// 8x16-pixel tile (the smallest tile), plus one (tile ranges of the persistent kernels straddle image borders).
+// 8x16-pixel tile (the smallest tile) or per 4-row wave group of a conv_tall3 tile (8 / 12 / 16-row tiles, two groups each:
+// at most one per 4 rows), plus one (tile ranges of the persistent kernels straddle image borders).
 static size_t stats_slots_bound(const fsr_conv_desc* d) {
-  const int gh = d->mode == FSR_CONV_FWD ? d->oh : d->oh, gw = d->ow;
-  return (size_t)((gh + 7) / 8) * ((gw + 15) / 16) + 1;
+  const int gh = d->oh, gw = d->ow;
+  return (size_t)((gh + 7) / 4) * ((gw + 15) / 16) + 1;
 }
 
 extern "C" size_t fsr_conv3x3_scratch(const fsr_conv_desc* d) {

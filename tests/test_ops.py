@@ -757,3 +757,15 @@ def test_conv_tall3(dev, cdn, cin, cout, variant, rows, monkeypatch):
     if cin % 128 == 0:
         assert L.lib().fsr_last_kernel().decode().startswith("conv_tall3_kernel"), L.lib().fsr_last_kernel()
     assert relerr(_nchw(dx), want) < tol(cdn, 1e-5, 1e-2)
+    # forward with InstanceNorm statistics of the pre-activation (the discriminator's stride-1 blocks): the 4-wave form's
+    # statistics epilogue, one partial slot per tile and wave row group, ragged tiles excluded pixel by pixel
+    monkeypatch.setenv("FSR_TALL3", "1")
+    y2, _, stats = ops.conv3x3_raw(cd, xd, wpk, cout, bias=bias.to(dev), act=L.ACT_LEAKY, slope=0.2, want_stats=True)
+    assert L.lib().fsr_last_kernel().decode().startswith("conv_tall3_kernel") and b"stats" in L.lib().fsr_last_kernel()
+    pre = F.conv2d(x, wt, bias, 1, 1)
+    assert relerr(_nchw(y2), F.leaky_relu(pre, 0.2)) < tol(cdn, 1e-5, 1e-2)
+    st = stats.cpu()
+    assert relerr(st[..., 0], pre.sum((2, 3))) < tol(cdn, 1e-4, 1e-3)
+    assert relerr(st[..., 1], (pre * pre).sum((2, 3))) < tol(cdn, 1e-4, 1e-3)
+    _, _, stats2 = ops.conv3x3_raw(cd, xd, wpk, cout, bias=bias.to(dev), act=L.ACT_LEAKY, slope=0.2, want_stats=True)
+    assert torch.equal(stats2.cpu(), st)                        # no atomics: bit-reproducible
