@@ -6,8 +6,8 @@
 // multiple of 128 output channels:
 //   torchvision vgg19.features convs 7..32 behind /root/reference/model.py:8 (conv2_2, conv3_x, conv4_x: forward twice per
 //   iteration, trainer.py:190-191, and their data gradients once, trainer.py:195),
-//   /root/reference/model.py:160-177 (Discriminator 128->256 and 256->512 stride-1 blocks: data gradients; their forwards
-//   carry InstanceNorm statistics and stay on conv_igemm.hip).
+//   /root/reference/model.py:160-177 (Discriminator 128->256 and 256->512 stride-1 blocks: forwards -- with the sums and
+//   sums of squares of their InstanceNorm, the STATS instantiation -- and data gradients).
 //
 // Work decomposition
 //   tile      16 x 16 output pixels of one image x BN output channels (BN = 256: 8 waves, one workgroup per CU;
