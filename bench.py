@@ -295,7 +295,10 @@ def measure_roofline(trainer, ops, lr, hr, dtype, ms_per_step, B):
             t = json.load(open(TRAFFIC_FILE))
             if t.get("kernel_sources_sha16") == kernel_sources_hash() and t.get("dtype") == args.dtype and t.get("batch") == B:
                 fam_traffic = t["bytes_per_launch"]
-                traffic = t.get("per_kernel", {}).get(dom_name, {}).get("bytes_per_dispatch")
+                # rocprofv3 prints every template argument (conv_tall3's trailing STATS flag: ",false>" / ",true>"), the library's
+                # own kernel note (fsr_last_kernel) prints "<...>" / "<...,stats>"
+                per = {k.replace(",false>", ">").replace(",true>", ",stats>"): v for k, v in t.get("per_kernel", {}).items()}
+                traffic = per.get(dom_name, {}).get("bytes_per_dispatch")
                 traffic_src = ("rocprofv3 --pmc FETCH_SIZE (x2, gfx950 correction) + WRITE_SIZE over one iteration (%s), "
                                "recorded in profiles/conv_traffic.json for kernel sources %s" % (t.get("files", "?"), t["kernel_sources_sha16"]))
             else:
