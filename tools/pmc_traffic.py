@@ -28,7 +28,10 @@ def total_kb(path, counter):
 def norm(name):
     """rocprofv3's demangled kernel name -> the spelling bench.py / fsr_last_kernel use."""
     n = name.replace("void ", "").replace("(anonymous namespace)::", "").split("(")[0]
-    return n.replace("unsigned short", "bf16").replace("_Float16", "f16").replace("float", "f32").replace(" ", "")
+    n = n.replace("unsigned short", "bf16").replace("_Float16", "f16").replace("float", "f32").replace(" ", "")
+    if n.startswith("conv_tall3_kernel<"):     # its trailing STATS flag: the library's note prints "<...>" / "<...,stats>"
+        n = n.replace(",false>", ">").replace(",true>", ",stats>")
+    return n
 
 
 def per_kernel_kb(path, counter):
