@@ -17,12 +17,18 @@
 //   workgroup -> BM output channels x BN input channels x all 9 taps, for a slab of pixel tiles
 //                (TPH x 16 output pixels each); the dy tile and the x halo of a pixel tile are
 //                staged in LDS once and reused by all 9 taps (x) / all taps and channel tiles (dy);
-//   wave      -> 64x64 blocks (8 waves, two per SIMD covering each other's transposing-read latency): TWO co tiles x
-//                one ci tile x 9 taps (72 accumulator registers) -- every transposed x fragment feeds two MFMAs, 22
-//                transposing reads per 18 MFMAs (one co tile x two ci tiles needs 38: measured 10-20 % slower);
-//                other blocks: one co tile x TPW ci tiles x 9 taps;
+//   wave      -> 128x64 blocks (16-bit, Cout % 128 == 0; 8 waves): FOUR co tiles x one ci tile x 9 taps (144 accumulator
+//                registers), 26 transposing reads per 36 MFMAs, x fetched Cout / 128 times;
+//                64x64 blocks (8 waves, two per SIMD): TWO co tiles x one ci tile x 9 taps (72 accumulator registers), 22
+//                reads per 18 MFMAs (one co tile x two ci tiles needs 38: measured 10-20 % slower);
+//                other blocks (thin layers, f32 edge cases): one co tile x TPW ci tiles x 9 taps;
+//   staging   -> 16-bit 8-wave blocks: LDS-DMA (buffer_load ... lds) into two LDS images, tile i+1 in flight while tile i is
+//                multiplied, one barrier per tile, the tile's 36 (K step, tap) stages unrolled with a two-stage read
+//                lookahead (stride 2: 4-row tiles so that two images fit); everything else: register-prefetched tiles, two
+//                barriers per tile;
 //   split-K   -> slabs write f32 partials [slab][9][cout_pad][cin_pad] to the workspace; a second
-//                kernel sums the slabs and adds the result into the OIHW float gradient.
+//                kernel sums the slabs and adds the result into the OIHW float gradient (no atomics: bit-reproducible).
+// Measurements, ablations and what bounds the kernel now: profiles/r03_wgrad_ablation.txt, DESIGN.md 3.2.
 #include "fsr_common.h"
 #include "fsr_host.h"
 #include <cstdlib>

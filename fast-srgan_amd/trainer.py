@@ -100,6 +100,7 @@ class Trainer:
             for opt in (self.optim_generator, self.optim_discriminator):
                 opt.grad_scale = opt.grad_scale / self.loss_scale
         self._streams = {}
+        self._seed_consts = {}
         self.use_side_stream = os.environ.get("FSR_SIDE_STREAM", "1") != "0"
         self.loss_fn = ops.bce_with_logits      # torch.nn.BCEWithLogitsLoss(), trainer.py:41
         self.l1_loss = ops.smooth_l1            # torch.nn.SmoothL1Loss(), trainer.py:43
@@ -170,14 +171,16 @@ class Trainer:
         # through D as ONE batch of 2B: half the launches, one weight-gradient pass instead of two
         y_both = Dm(torch.cat([hr_images, sr_images.detach()], dim=0))
         y_real, y_fake = y_both[:hr_images.shape[0]], y_both[hr_images.shape[0]:]
-        n0 = torch.rand_like(y_real) if noise is None else noise[0]
-        n1 = torch.rand_like(y_fake) if noise is None else noise[1]
-        real_labels = 0.3 * n0 + 0.8                                            # :175
-        fake_labels = 0.3 * n1                                                  # :176
+        # :175-176  0.3 * rand + 0.8 and 0.3 * rand are U[0.8, 1.1) and U[0, 0.3): ONE generator launch each instead of
+        # rand + mul + add (given noise tensors -- the parity tests -- keep the reference's arithmetic)
+        real_labels = torch.empty_like(y_real).uniform_(0.8, 1.1) if noise is None else 0.3 * noise[0] + 0.8
+        fake_labels = torch.empty_like(y_fake).uniform_(0.0, 0.3) if noise is None else 0.3 * noise[1]
         loss_real = self.loss_fn(y_real, real_labels)                           # :177
         loss_fake = self.loss_fn(y_fake, fake_labels)                           # :178
-        discriminator_loss = 0.5 * loss_real + 0.5 * loss_fake                  # :179
-        discriminator_loss.backward(self._seed)                                 # :180 (seed = the loss scale, if any)
+        # :179-180  backward of 0.5 * loss_real + 0.5 * loss_fake: the weights ride in the two backward seeds (times the loss
+        # scale, if any) -- no scalar-arithmetic kernels and no Mul / Add nodes in the iteration
+        half = self._seeds(lr_images.device)[0]
+        torch.autograd.backward([loss_real, loss_fake], [half, half])
         ops.wgrad_stream_join()
         joined = False
         if join_side and side is not None:      # a captured phase must end with every forked stream joined
@@ -195,18 +198,32 @@ class Trainer:
             p.requires_grad_(False)      # D's weight gradients of this pass are discarded by the reference (:171)
         try:
             y_fake = Dm(st["sr"])                                               # :186 (updated D)
-            n2 = torch.rand_like(y_fake) if noise is None else noise[2]
-            real_labels = 0.3 * n2 + 0.7                                        # :187
-            adv_loss = 1e-1 * self.loss_fn(y_fake, real_labels)                 # :188
+            real_labels = torch.empty_like(y_fake).uniform_(0.7, 1.0) if noise is None else 0.3 * noise[2] + 0.7   # :187
+            bce = self.loss_fn(y_fake, real_labels)
+            adv_loss = bce.detach() * 1e-1                                      # :188 (the reported value)
             if st["side"] is not None and not st["joined"]:
                 st["main"].wait_stream(st["side"])
-            generator_loss = 0.5 * adv_loss + 0.5 * st["content"]               # :194
-            generator_loss.backward(self._seed)                                 # :195
+            # :194-195  backward of 0.5 * (0.1 * bce) + 0.5 * content_loss, the weights in the seeds as above
+            half, adv_w = self._seeds(y_fake.device)
+            torch.autograd.backward([bce, st["content"]], [adv_w, half])
         finally:
             for p in Dm.parameters():
                 p.requires_grad_(True)
         ops.wgrad_stream_join()
         st["adv"] = adv_loss
+
+    def _seeds(self, dev):
+        """(0.5 S, 0.05 S) as 0-dim device tensors, S = the loss scale (1 without one): the backward seeds that carry
+        trainer.py:179 / :188 / :194's loss weights.  Constant scales: made once (before any graph capture: the warm-up
+        iterations come first); the dynamic fp16 scale lives on the device, so its seeds are two tiny launches per phase."""
+        if self._scale_state is not None:
+            return self._seed * 0.5, self._seed * 0.05
+        c = self._seed_consts.get(str(dev))
+        if c is None:
+            s = 1.0 if self._seed is None else float(self.loss_scale)
+            c = self._seed_consts[str(dev)] = (torch.tensor(0.5 * s, dtype=torch.float32, device=dev),
+                                               torch.tensor(0.05 * s, dtype=torch.float32, device=dev))
+        return c
 
     def _update_loss_scale(self):
         if self._scale_state is not None:
