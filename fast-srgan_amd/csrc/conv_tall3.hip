@@ -8,6 +8,7 @@
 //   iteration, trainer.py:190-191, and their data gradients once, trainer.py:195),
 //   /root/reference/model.py:160-177 (Discriminator 128->256 and 256->512 stride-1 blocks: forwards -- with the sums and
 //   sums of squares of their InstanceNorm, the STATS instantiation -- and data gradients).
+//   /root/reference/model.py:154-159 (Discriminator 64->128 block: its data gradient, 128 -> 64 channels, on 64-channel blocks).
 //
 // Work decomposition
 //   tile      16 x 16 output pixels of one image x BN output channels (BN = 256: 8 waves, one workgroup per CU;
@@ -73,7 +74,7 @@ __global__ __launch_bounds__(NW * 64, NA == 4 ? 1 : 2) void conv_tall3_kernel(co
   // 128 x 128 wave tile, 256 accumulator registers in the AGPR half of the file): ONE 512-register wave per SIMD, 8 fragment
   // reads per 16 MFMAs instead of 6 per 8, the 256 x 256 workgroup tile from four waves
   static_assert(BN % (NA * 32) == 0 && NW == 2 * (BN / (NA * 32)), "two pixel-row groups x BN / (32 NA) channel groups of waves");
-  static_assert(NA == 2 || NA == 4, "2 or 4 filter fragments per wave");
+  static_assert(NA == 1 || NA == 2 || NA == 4, "1 (64-channel blocks), 2 or 4 filter fragments per wave");
   static_assert(MB >= 2 && MB <= 4, "8, 12 or 16 tile rows");
   constexpr int TH = 4 * MB;                       // tile rows
   constexpr int T3_HUNITS = t3_hunits<MB>(), T3_NHP = t3_nhp<MB>(), T3_HALO_BYTES = t3_halo_bytes<MB>();
@@ -303,17 +304,21 @@ __global__ __launch_bounds__(NW * 64, NA == 4 ? 1 : 2) void conv_tall3_kernel(co
             constexpr int i = decltype(ic)::value;
             constexpr int n = i / MB, m = i % MB;
             acc[n][m] = Mfma32<T>::run(fa[buf][n], fb[buf][m], acc[n][m]);
-            if constexpr (i < NR) {
-              if constexpr (q + 1 < NQ) {
-                constexpr int q1 = q + 1;
-                read_frag(ic, std::integral_constant<int, buf ^ 1>{}, std::integral_constant<int, si * G + q1 / 2>{},
-                          std::integral_constant<int, q1 / 2>{}, std::integral_constant<int, q1 % 2>{}, sl, hb);
-              } else {
-                if (has_next_stage)
-                  read_frag(ic, std::integral_constant<int, buf ^ 1>{}, std::integral_constant<int, siN * G>{},
-                            std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{}, slN, hbN);
+            auto next_frag = [&](auto rc) {       // fragment rc of the NEXT substep, into the other register set
+              if constexpr (decltype(rc)::value < NR) {
+                if constexpr (q + 1 < NQ) {
+                  constexpr int q1 = q + 1;
+                  read_frag(rc, std::integral_constant<int, buf ^ 1>{}, std::integral_constant<int, si * G + q1 / 2>{},
+                            std::integral_constant<int, q1 / 2>{}, std::integral_constant<int, q1 % 2>{}, sl, hb);
+                } else {
+                  if (has_next_stage)
+                    read_frag(rc, std::integral_constant<int, buf ^ 1>{}, std::integral_constant<int, siN * G>{},
+                              std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{}, slN, hbN);
+                }
               }
-            }
+            };
+            next_frag(ic);                                             // one read per MFMA slot ...
+            next_frag(std::integral_constant<int, i + NM>{});           // ... two where a substep has more reads than MFMAs (NA = 1)
             // DMA pieces of stage s+D: the halo piece first (the likeliest HBM miss), then two filter pieces per substep
             if constexpr (q == 0 && i >= 1 && i <= HPS && si * HPS + (i - 1) < HPW) {
               constexpr int hk = si * HPS + (i - 1);
@@ -485,7 +490,8 @@ __global__ __launch_bounds__(NW * 64, NA == 4 ? 1 : 2) void conv_tall3_kernel(co
 int t3_mode() {
   // FSR_TALL3: 0 = off (A/B against conv_igemm.hip); 1 (default) = on, 4-wave workgroups of 256 px x 128 channels, two per
   // CU; 3 = the 8-wave 256 px x 256 channel workgroup (one per CU, persistent) where Cout allows it.  Measured per layer:
-  // the 4-wave form wins on every benched shape but one (profiles/r03_conv_tall3_ab.txt).
+  // the 4-wave form wins on every benched shape but one (profiles/r03_conv_tall3_ab.txt).  Bit 4: the one-wave-per-SIMD form;
+  // bit 8: no 64-channel block (Cout = 64 launches stay on conv_igemm.hip).
   const char* e = getenv("FSR_TALL3");
   return e ? atoi(e) : 1;
 }
@@ -540,7 +546,11 @@ int t3_launch(ConvKArgs& a, int wg_per_cu, hipStream_t stream) {
 int fsr_conv_tall3_try(int dtype, ConvKArgs& a, int S, hipStream_t stream) {
   const int mode = t3_mode();
   if (mode == 0 || (dtype != FSR_BF16 && dtype != FSR_F16) || S != 1 || a.ntaps != 9) return 0;
-  if (a.Cin < 128 || a.Cin % 32 != 0 || a.Cout % 128 != 0 || a.CoutPad != a.Cout) return 0;
+  if (a.Cin < 128 || a.Cin % 32 != 0 || a.Cout % 64 != 0 || a.CoutPad != a.Cout) return 0;
+  // Cout = 64 (the data gradient of a 64 -> 128 layer): 64-channel blocks, a wave = 32 MB pixels x 32 channels (one filter
+  // fragment, 5 reads per 4 MFMAs); FSR_TALL3 & 8 keeps these launches on conv_igemm.hip (A/B)
+  const bool narrow = a.Cout % 128 != 0;
+  if (narrow && ((mode & 14) || a.stats || a.pool2)) return 0;
   if (a.preact || a.oscale || a.ps || a.in_ps || a.out_f32) return 0;
   if (a.stats && (a.pool2 || a.dmask || (mode & 6))) return 0;   // statistics: the shipped 4-wave form, forward launches
   if (a.act != FSR_ACT_NONE && a.act != FSR_ACT_RELU && a.act != FSR_ACT_LEAKY) return 0;
@@ -579,6 +589,7 @@ int fsr_conv_tall3_try(int dtype, ConvKArgs& a, int S, hipStream_t stream) {
   if ((mode & 4) && a.Cout % 256 == 0 && best_mb == 4 && dtype == FSR_BF16) return t3_launch<bf16_t, 256, 4, 3, 2, 4, 4>(a, 1, stream);
 #define T3_GO(TT, MBV)                                                                      \
   do {                                                                                      \
+    if (narrow) return t3_launch<TT, 64, 4, 1, 4, MBV, 1>(a, 2, stream);                    \
     if (a.stats) return t3_launch<TT, 128, 4, 1, 4, MBV, 2, true>(a, 2, stream);            \
     if (wide) return t3_launch<TT, 256, 8, 3, 2, MBV>(a, 1, stream);                        \
     return t3_launch<TT, 128, 4, 1, 4, MBV>(a, 2, stream);                                  \
