@@ -2,9 +2,20 @@
 
 hydra / omegaconf are not dependencies; PyYAML reads the same file and the result is an attribute tree with
 the reference's 20 keys (configs/config.yaml:1-25) plus `generator.n_upsample` (default 2),
-`training.compute_dtype` (bf16 | f16 | f32, default bf16), `training.loss_scale` (static, default 16384 for f16 else 1), `training.vgg19_weights` (path of torchvision's vgg19 checkpoint) and
-`training.allow_random_vgg` (tests / benchmarks only).
+`training.compute_dtype` (bf16 | f16 | f32, default bf16), `training.vgg19_weights` (path of torchvision's vgg19
+checkpoint), `training.allow_random_vgg` (tests / benchmarks only), `training.hip_graph` (replay the iteration as hipGraphs)
+and the fp16 loss scaler:
+
+* `training.loss_scale` -- the INITIAL scale (default 2**20 for f16, 1 otherwise; must be > 0),
+* `training.dynamic_loss_scale` (default true for f16): the scale is adapted on the device -- a non-finite gradient arena
+  skips BOTH optimizer updates of the iteration and halves the scale; `training.loss_scale_growth_interval` (default 1000,
+  >= 1) clean iterations double it.  With `false` the scale is static.
+
+hydra run directory (/root/reference/train.py:46 is `@hydra.main(version_base="1.1", ...)`, under which hydra changes the
+working directory to `outputs/<date>/<time>` before `main` runs, so `runs/...` checkpoints land there): `enter_run_dir`
+reproduces that, including hydra's own override keys `hydra.run.dir=<path>` and `hydra.job.chdir=false`.
 """
+import datetime
 import os
 import types
 
@@ -43,6 +54,8 @@ def load_config(path=None, overrides=()):
         for group, vals in loaded.items():
             cfg.setdefault(group, {}).update(vals or {})
     for ov in overrides:
+        if ov.startswith("hydra."):                     # hydra's own keys: enter_run_dir reads them
+            continue
         if "=" not in ov:
             raise ValueError("override %r is not of the form a.b=c" % ov)
         key, val = ov.split("=", 1)
@@ -58,3 +71,44 @@ def load_config(path=None, overrides=()):
         warnings.warn("training.device=%s: this framework runs on the MI355X only, using 'cuda'" % cfg["training"]["device"])
         cfg["training"]["device"] = "cuda"
     return _to_node(cfg)
+
+
+def hydra_run_settings(overrides=(), now=None):
+    """(chdir, run_dir) as hydra 1.1 would choose them: chdir on, `outputs/%Y-%m-%d/%H-%M-%S` unless overridden."""
+    chdir, run_dir = True, None
+    for ov in overrides:
+        if ov.startswith("hydra.job.chdir="):
+            chdir = bool(_parse_scalar(ov.split("=", 1)[1]))
+        elif ov.startswith("hydra.run.dir="):
+            run_dir = str(ov.split("=", 1)[1])
+    if run_dir is None:
+        now = now or datetime.datetime.now()
+        run_dir = os.path.join("outputs", now.strftime("%Y-%m-%d"), now.strftime("%H-%M-%S"))
+    return chdir, run_dir
+
+
+def enter_run_dir(cfg, overrides=(), run_dir=None, create=True):
+    """What `@hydra.main(version_base="1.1")` does around the reference's `main` (/root/reference/train.py:46): make the run
+    directory, record the composed config and the overrides under `.hydra/`, and change into it.  Relative `data.*` paths are
+    made absolute first (hydra users call `to_absolute_path` for that; the reference's config holds absolute paths).
+    `run_dir`: the directory rank 0 chose (every rank must enter the same one).  Returns the directory, or None when
+    `hydra.job.chdir=false`."""
+    chdir, chosen = hydra_run_settings(overrides)
+    run_dir = run_dir or chosen
+    for key in ("image_dir", "numpy_dir"):
+        val = getattr(cfg.data, key, "")
+        if val:
+            setattr(cfg.data, key, os.path.abspath(val))
+    if getattr(cfg.training, "vgg19_weights", ""):
+        cfg.training.vgg19_weights = os.path.abspath(cfg.training.vgg19_weights)
+    if not chdir:
+        return None
+    run_dir = os.path.abspath(run_dir)
+    if create:
+        os.makedirs(os.path.join(run_dir, ".hydra"), exist_ok=True)
+        with open(os.path.join(run_dir, ".hydra", "config.yaml"), "w") as f:
+            yaml.safe_dump(cfg.to_dict(), f, sort_keys=False)
+        with open(os.path.join(run_dir, ".hydra", "overrides.yaml"), "w") as f:
+            yaml.safe_dump([o for o in overrides if not o.startswith("hydra.")], f)
+    os.chdir(run_dir)
+    return run_dir

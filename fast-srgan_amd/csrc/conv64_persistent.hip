@@ -1,25 +1,20 @@
-// 64 -> 64 channel 3x3 convolution (stride 1) with the WHOLE filter resident in LDS: a persistent kernel.
+// 64-input-channel 3x3 convolutions with the WHOLE filter resident in LDS: persistent kernels.
 //
 // The 64-channel layers -- ResidualBlock conv1/conv2 and the bottleneck of the Generator
-// (/root/reference/model.py:47-64, 86-93: 17 layers forward + 17 data gradients per iteration) and vgg19
-// conv1_2 (model.py:8) -- have only K = 9*64 = 576: in the generic implicit-GEMM kernel a workgroup spends more
-// time fetching nine 8 KB filter slices from L2 (one barrier each) and in its prologue/epilogue than in its 288
-// MFMAs.  gfx950 has 160 KB of LDS per CU, and the complete bf16 filter is 72 KB:
-//
-//   LDS   : filter [9 taps][64 co][64 ci] (pitch 160 B, conflict-free)  92,160 B   loaded ONCE per workgroup
-//           halo   [18][18][64 ci]        (pitch 160 B)                51,840 B   one 16x16-pixel tile at a time
-//   grid  : one workgroup (8 waves = 2 per SIMD) per CU, walking tiles bid, bid + grid, ...
-//   wave  : 2 pixel rows x all 64 output channels (8 accumulator tiles); a tile is 144 back-to-back MFMAs per
-//           wave with NO barrier inside (nothing is restaged during a tile);
-//   tiles : the halo of the next tile is loaded into registers before the MFMAs of the current one and committed
-//           to LDS after its epilogue -- two barriers per tile instead of ten.
-// (Measured and rejected in round 2: software-pipelining the 18 (tap, half) steps -- the reads of step i + 1 before the MFMAs
-// of step i, double fragment set, 236 instead of 120 VGPRs: +-1 % on every 64-channel layer.  With two waves per SIMD the
-// partner wave already covers the LDS round trips; what bounds this kernel is the per-tile prologue / epilogue and, at
-// 384^2, HBM.)
-// Same operand mapping, tap table, epilogue semantics (bias, ReLU/LeakyReLU/identity, InstanceNorm statistics,
-// fused activation-backward mask) and therefore the same results as conv_igemm_kernel.  bf16 only: the f32
-// filter (144 KB + pads) does not fit next to a halo, the parity mode stays on the generic kernel.
+// (/root/reference/model.py:47-64, 86-93: 17 layers forward + 17 data gradients per iteration), vgg19 conv1_2 / conv2_1
+// (model.py:8), the discriminator's 64 -> 64 / 64 -> 128 blocks (model.py:148-159), the generator's two 64 -> 256
+// up-sampling convolutions (model.py:30-37) and the 64 -> 3 ends (model.py:102-110) -- have only K = 9*64 = 576: in the
+// generic implicit-GEMM kernel a workgroup spends more time fetching nine 8 KB filter slices from L2 (one barrier each) and
+// in its prologue/epilogue than in its 288 MFMAs.  gfx950 has 160 KB of LDS per CU and the complete 16-bit filter block is
+// 72 KB, so a persistent workgroup keeps it next to its halos and walks tiles:
+//   conv64_v2_kernel       64-channel output blocks, stride 1: XOR-swizzled 128-byte rows, halo by LDS-DMA into two
+//                          buffers, one barrier per tile, epilogue deferred into the next tile
+//   conv64_thin_kernel     the 64 -> 3 ends (float / uint8 output): 9 x 16 filter rows, two workgroups per CU
+//   conv64_s2fwd_kernel    64 -> 64 stride-2 forward, streaming (3.1d)
+//   conv64_s2dgrad_kernel  64 -> 64 stride-2 data gradient, all four parity classes per tile (3.1c)
+// Same operand mapping, tap table and epilogue semantics (bias, ReLU / LeakyReLU / identity, InstanceNorm statistics, fused
+// activation-backward mask) -- and therefore the same results -- as conv_igemm_kernel.  16-bit only: the f32 filter
+// (144 KB + pads) does not fit next to a halo, the parity mode stays on the generic kernel.
 #include "fsr_common.h"
 #include "fsr_conv_args.h"
 #include "fsr_host.h"
@@ -31,21 +26,24 @@ namespace {
 constexpr int P64 = 80;          // LDS pitch in bf16 elements (160 B = 10 slots of 16 B: P = 2 mod 4)
 constexpr int HT = 18;           // halo extent of a 16x16 tile, 3x3 footprint
 constexpr int NTHR64 = 512;
-constexpr int W_BYTES = 9 * 64 * P64 * 2;
+constexpr int W_BYTES = 9 * 64 * P64 * 2;   // a whole 64 x 64 x 9 filter at the conflict-free 160-byte pitch (conv64_s2dgrad_kernel)
 constexpr int H_BYTES = HT * HT * P64 * 2;
 constexpr int SRED_BYTES = 8 * 128 * 4;   // per-wave InstanceNorm partial sums
 constexpr int LDS64 = W_BYTES + H_BYTES + SRED_BYTES;
+constexpr size_t LDS_THIN = 9 * 16 * P64 * 2 + H_BYTES + 16;   // conv64_thin_kernel: 9 x 16 filter rows + one halo
 
 __device__ __forceinline__ unsigned tap64(const ConvKArgs& a, int t) {
   return (t < 8) ? (unsigned)((a.taps_lo >> (8 * t)) & 0xffull) : a.taps_hi;
 }
 
-// NT = 16-row tiles of output channels per workgroup: 4 (a 64-channel block) or 1 (THIN: a float output of at most 16
-// channels -- the 64 -> 3 head with its tanh, and the image gradients with their per-channel scale; the filter is then
-// 9 x 16 rows and the kernel streams the 64-channel input at memory speed instead of living one tile per workgroup).
-template <typename T, int NT>
-__global__ __launch_bounds__(NTHR64, 2) void conv64_persistent_kernel(const ConvKArgs a) {
-  constexpr bool THIN = NT == 1;
+// The 64 -> 3 ends (a float or uint8 output of at most 16 channels: the head with its tanh, model.py:102-110, and the image
+// gradients with their per-channel scale): the filter is 9 x 16 rows, two workgroups fit a CU, and the kernel streams the
+// 64-channel input at memory speed instead of living one tile per workgroup.  (This register-staged, two-barriers-per-tile
+// structure was also the FIRST form of the 64-channel-block kernel; conv64_v2_kernel below replaced it in round 2 and the
+// block instantiation was deleted in round 4.)
+template <typename T>
+__global__ __launch_bounds__(NTHR64, 2) void conv64_thin_kernel(const ConvKArgs a) {
+  constexpr int NT = 1;
   constexpr int ROWS = NT * 16;
   constexpr int HUNITS = HT * HT * 8;                   // 16-byte units of one halo
   constexpr int HPT = (HUNITS + NTHR64 - 1) / NTHR64;   // 6
@@ -53,7 +51,6 @@ __global__ __launch_bounds__(NTHR64, 2) void conv64_persistent_kernel(const Conv
   T* wl = (T*)smem;
   constexpr int WB = 9 * NT * 16 * P64 * 2;            // bytes of the resident filter block
   T* halo = (T*)(smem + WB);
-  float* sred = (float*)(smem + WB + H_BYTES);          // [8 waves][64][2] statistics of the tiles walked so far in this image
 
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int l15 = lane & 15, lg = lane >> 4;
@@ -61,13 +58,9 @@ __global__ __launch_bounds__(NTHR64, 2) void conv64_persistent_kernel(const Conv
   const int tiles_per_img = a.tiles_x * a.tiles_y;
   const int ntiles = tiles_per_img * a.N;
 
-  // Output channels come in blocks of 64 (Cout = 64, 128, 256): workgroup w owns block nb = w % nblk for its tile range;
-  // with a fused PixelShuffle (Cout / 4 = 64 channels per quadrant) block nb IS quadrant nb of the packed filter.
-  const int nblk = THIN ? 1 : (a.CoutPad >> 6);
-  const int nb = (int)blockIdx.x % nblk;
-  // ---- the 64 filter rows of this block, all nine taps: [9][64][64] -> LDS (4608 units, 9 per thread), once
+  // ---- the 16 filter rows, all nine taps: [9][16][64] -> LDS, once
   {
-    const T* wpk = (const T*)a.wpk + (size_t)nb * 64 * 64;
+    const T* wpk = (const T*)a.wpk;
     constexpr int WU = 9 * ROWS * 8;                    // 16-byte units of the resident filter block
 #pragma unroll
     for (int i = 0; i < (WU + NTHR64 - 1) / NTHR64; ++i) {
@@ -111,10 +104,6 @@ __global__ __launch_bounds__(NTHR64, 2) void conv64_persistent_kernel(const Conv
   float slope = (a.act == FSR_ACT_PRELU) ? a.prelu[0] : a.slope;
   if (a.act == FSR_ACT_NONE || a.act == FSR_ACT_TANH) slope = 1.f;
   if (a.act == FSR_ACT_RELU) slope = 0.f;
-  const bool want_stats = a.stats != nullptr;
-  T* outp = (T*)a.out;
-  T* prep = (T*)a.preact;
-  const T* maskp = (const T*)a.dmask;
 
   int pixbase[2], wbase[NT];
 #pragma unroll
@@ -125,35 +114,23 @@ __global__ __launch_bounds__(NTHR64, 2) void conv64_persistent_kernel(const Conv
 #pragma unroll
   for (int n = 0; n < NT; ++n) {
     bias[n] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    if (a.bias && THIN) {
+    if (a.bias) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) bias[n][r] = a.bias[lg * 4 + r < a.Cout ? lg * 4 + r : 0];
-    } else if (a.bias) {
-      if (!a.ps) bias[n] = *(const f32x4*)(a.bias + nb * 64 + n * 16 + lg * 4);
-      else
-#pragma unroll
-        for (int r = 0; r < 4; ++r) bias[n][r] = a.bias[4 * (n * 16 + lg * 4 + r) + nb];   // torch order 4*cc + quadrant
     }
   }
 
-  // a workgroup walks a CONTIGUOUS range of tiles (mostly one image): InstanceNorm statistics stay in registers
-  // across tiles and are flushed (lane shuffle -> per-wave LDS slot -> the eight waves added in order -> this workgroup's
-  // slot of the image's partial buffer, plain stores) only when the image changes.  No atomics: reduce.hip adds an
-  // image's slots in order, so the statistics are bit-reproducible.
-  const int tile_begin = ((int)blockIdx.x / nblk) * a.nblk_n;   // nblk_n = tiles per workgroup (set by the host)
+  // a workgroup walks a CONTIGUOUS range of tiles
+  const int tile_begin = (int)blockIdx.x * a.nblk_n;   // nblk_n = tiles per workgroup (set by the host)
   const int tile_end = (tile_begin + a.nblk_n < ntiles) ? tile_begin + a.nblk_n : ntiles;
-  f32x4 oscale = (f32x4){1.f, 1.f, 1.f, 1.f};     // THIN: optional per-channel scale (VGG normalisation in the image gradient)
-  if (THIN && a.oscale) {
+  f32x4 oscale = (f32x4){1.f, 1.f, 1.f, 1.f};     // optional per-channel scale (VGG normalisation in the image gradient)
+  if (a.oscale) {
 #pragma unroll
     for (int r = 0; r < 4; ++r) oscale[r] = a.oscale[lg * 4 + r < a.Cout ? lg * 4 + r : 0];
   }
-  f32x4 s1acc[NT], s2acc[NT];
-#pragma unroll
-  for (int n = 0; n < NT; ++n) s1acc[n] = s2acc[n] = (f32x4){0.f, 0.f, 0.f, 0.f};
-
   int tile = tile_begin;
   if (tile < tile_end) halo_issue(tile);
-  __syncthreads();                 // filter + zeroed statistics visible
+  __syncthreads();                 // filter visible
   if (tile < tile_end) halo_commit();
   __syncthreads();
 
@@ -192,133 +169,29 @@ __global__ __launch_bounds__(NTHR64, 2) void conv64_persistent_kernel(const Conv
     const int ty = rem / a.tiles_x, tx = rem - ty * a.tiles_x;
     const int gx = tx * 16 + l15, gyb = ty * 16 + wave * 2;
     const bool col_ok = gx < a.GW;
-    if constexpr (THIN) {
-      // float output, Cout <= 16 valid channels (lane group lg holds channels 4 lg .. 4 lg + 3): scale, bias, tanh / slope
+    // float output, Cout <= 16 valid channels (lane group lg holds channels 4 lg .. 4 lg + 3): scale, bias, tanh / slope
 #pragma unroll
-      for (int m = 0; m < 2; ++m) {
-        if (col_ok && gyb + m < a.GH) {
-          const size_t off = (((size_t)img * a.FOH + gyb + m) * a.FOW + gx) * a.Cout + lg * 4;
+    for (int m = 0; m < 2; ++m) {
+      if (col_ok && gyb + m < a.GH) {
+        const size_t off = (((size_t)img * a.FOH + gyb + m) * a.FOW + gx) * a.Cout + lg * 4;
 #pragma unroll
-          for (int r = 0; r < 4; ++r)
-            if (lg * 4 + r < a.Cout) {
-              float v = acc[m][0][r] * oscale[r] + bias[0][r];
-              v = (a.act == FSR_ACT_TANH) ? tanhf(v) : (v > 0.f ? v : v * slope);
-              if (a.out_f32 == FSR_OUT_U8) ((unsigned char*)a.out)[off + r] = image_u8(v);   // HWC uint8 image (inference)
-              else ((float*)a.out)[off + r] = v;
-            }
-        }
+        for (int r = 0; r < 4; ++r)
+          if (lg * 4 + r < a.Cout) {
+            float v = acc[m][0][r] * oscale[r] + bias[0][r];
+            v = (a.act == FSR_ACT_TANH) ? tanhf(v) : (v > 0.f ? v : v * slope);
+            if (a.out_f32 == FSR_OUT_U8) ((unsigned char*)a.out)[off + r] = image_u8(v);   // HWC uint8 image (inference)
+            else ((float*)a.out)[off + r] = v;
+          }
       }
-      __syncthreads();
-      if (next < tile_end) halo_commit();
-      __syncthreads();
-      continue;
     }
-    if (a.pool2) {
-      // MaxPool2d(2,2) fused (no-grad vgg19 passes): the wave's two rows and the columns (l15, l15 ^ 1) of neighbouring
-      // lanes; even lanes store pixel (gy / 2, gx / 2) of the [N][FOH/2][FOW/2][Cout] tensor
-      static_for<0, NT>([&](auto nc) {
-        constexpr int n = decltype(nc)::value;
-        f32x4 v = acc[0][n] + bias[n], w = acc[1][n] + bias[n];
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          float x = fmaxf(v[r], w[r]);
-          x = fmaxf(x, __shfl_xor(x, 1, 64));
-          v[r] = fmaxf(x, 0.f) + slope * fminf(x, 0.f);
-        }
-        if (col_ok && gyb < a.GH && !(l15 & 1)) {
-          const unsigned off = (unsigned)((img * (a.FOH >> 1) + (gyb >> 1)) * (a.FOW >> 1) + (gx >> 1)) * (unsigned)a.Cout + (unsigned)(nb * 64 + n * 16 + lg * 4);
-          u32x2 pk;
-          pk.x = pack2<T>(v[0], v[1]);
-          pk.y = pack2<T>(v[2], v[3]);
-          *(u32x2*)(outp + off) = pk;
-        }
-      });
-      __syncthreads();
-      if (next < tile_end) halo_commit();
-      __syncthreads();
-      continue;
-    }
-    // plain: pixel (gy, gx), channels nb*64 + ...; PixelShuffle(2): pixel (2 gy + (nb >> 1), 2 gx + (nb & 1)) of the
-    // [2 FOH, 2 FOW, 64] tensor, channels 0..63
-    const unsigned rstride = a.ps ? (unsigned)(4 * a.FOW * 64) : (unsigned)(a.FOW * a.Cout);
-    const unsigned base0 = a.ps ? (unsigned)((img * 2 * a.FOH + 2 * gyb + (nb >> 1)) * (2 * a.FOW) + 2 * gx + (nb & 1)) * 64u + (unsigned)(lg * 4)
-                                : (unsigned)((img * a.FOH + gyb) * a.FOW + gx) * (unsigned)a.Cout + (unsigned)(nb * 64 + lg * 4);
-    const bool flush = want_stats && (next >= tile_end || next / tiles_per_img != img);
-    // mask vectors of the whole tile before its first store (see conv64_s2dgrad_kernel)
-    u32x2 mkv[2][4];
-    if (maskp) {
-#pragma unroll
-      for (int m = 0; m < 2; ++m)
-#pragma unroll
-        for (int n = 0; n < NT; ++n)
-          mkv[m][n] = (col_ok && gyb + m < a.GH) ? *(const u32x2*)(maskp + (base0 + m * rstride + n * 16)) : (u32x2){0u, 0u};
-    }
-    static_for<0, NT>([&](auto nc) {
-      constexpr int n = decltype(nc)::value;
-      static_for<0, 2>([&](auto mc) {
-        constexpr int m = decltype(mc)::value;
-        if (col_ok && gyb + m < a.GH) {
-          const unsigned off = base0 + m * rstride + n * 16;
-          f32x4 v = acc[m][n] + bias[n];
-          if (maskp) {
-            const u32x2 t = mkv[m][n];
-            const float mk[4] = {cvt_lo<T>(t.x), cvt_hi<T>(t.x),
-                                 cvt_lo<T>(t.y), cvt_hi<T>(t.y)};
-#pragma unroll
-            for (int r = 0; r < 4; ++r) v[r] = a.dmask_add ? v[r] + mk[r] : (mk[r] > 0.f ? v[r] : v[r] * a.dmask_slope);
-          }
-          if (want_stats) {
-            s1acc[n] += v;
-            s2acc[n] += v * v;
-          }
-          if (prep) {
-            u32x2 pp;
-            pp.x = pack2<T>(v[0], v[1]);
-            pp.y = pack2<T>(v[2], v[3]);
-            *(u32x2*)(prep + off) = pp;
-          }
-#pragma unroll
-          for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f) + slope * fminf(v[r], 0.f);
-          u32x2 pk;
-          pk.x = pack2<T>(v[0], v[1]);
-          pk.y = pack2<T>(v[2], v[3]);
-          *(u32x2*)(outp + off) = pk;
-        }
-      });
-      if (flush) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          float x1 = s1acc[n][r], x2 = s2acc[n][r];
-#pragma unroll
-          for (int o = 8; o >= 1; o >>= 1) {
-            x1 += __shfl_xor(x1, o, 64);
-            x2 += __shfl_xor(x2, o, 64);
-          }
-          if (l15 == 0) {
-            const int cl = n * 16 + lg * 4 + r;
-            sred[(wave * 64 + cl) * 2] = x1;
-            sred[(wave * 64 + cl) * 2 + 1] = x2;
-          }
-        }
-        s1acc[n] = s2acc[n] = (f32x4){0.f, 0.f, 0.f, 0.f};
-      }
-    });
-    __syncthreads();   // every wave is done with the halo (and with its statistics contributions)
-    if (flush && tid < 128) {
-      float s = sred[tid];
-#pragma unroll
-      for (int w = 1; w < 8; ++w) s += sred[w * 128 + tid];
-      // slot of this tile range among the ranges that intersect the image (fsr_launch_reduce_partials knows the rule)
-      const int slot = (int)blockIdx.x / nblk - (img * tiles_per_img) / a.nblk_n;
-      a.stats[(((size_t)img * a.stats_P + slot) * a.Cout + nb * 64 + (tid >> 1)) * 2 + (tid & 1)] = s;
-    }
+    __syncthreads();   // every wave is done with the halo
     if (next < tile_end) halo_commit();
     __syncthreads();
   }
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-// The 64-channel-block kernel, second form (NT = 4 only; the thin kernel above keeps the first form, whose small LDS
+// The 64-channel-block kernel (second form; the thin kernel above keeps the structure of the first, whose small LDS
 // footprint admits two workgroups per CU).  Measured on the first form at 96^2 (tools/conv_bench.py, batch 32 .. 256): a
 // workgroup needs 6.5 us per tile, of which the 288 MFMAs per SIMD are 1.9 us -- prefetch, MFMAs, epilogue, barrier,
 // LDS commit, barrier run one after the other and all eight waves walk them in lock step.  This form takes the phases
@@ -950,7 +823,7 @@ __global__ __launch_bounds__(NTHR64, 2) void conv64_s2dgrad_kernel(const ConvKAr
       __builtin_amdgcn_sched_barrier(0);   // 128 accumulators + the prefetched halo: keep fragment live ranges to one tap
     });
 
-    FSR_WAIT_LOADS();   // (see conv64_persistent_kernel)
+    FSR_WAIT_LOADS();   // (see conv64_thin_kernel)
     const int img = tile / tiles_per_img;
     const int rem = tile - img * tiles_per_img;
     const int ty = rem / a.tiles_x, tx = rem - ty * a.tiles_x;
@@ -1118,10 +991,8 @@ int fsr_conv64_persistent_try(int dtype, ConvKArgs& a, int S, hipStream_t stream
   if (ntiles <= 0 || ntiles > 0x7fffffffLL) return 0;
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute((const void*)conv64_persistent_kernel<bf16_t, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS64);
-    (void)hipFuncSetAttribute((const void*)conv64_persistent_kernel<bf16_t, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS64);
-    (void)hipFuncSetAttribute((const void*)conv64_persistent_kernel<f16_t, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS64);
-    (void)hipFuncSetAttribute((const void*)conv64_persistent_kernel<f16_t, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS64);
+    (void)hipFuncSetAttribute((const void*)conv64_thin_kernel<bf16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_THIN);
+    (void)hipFuncSetAttribute((const void*)conv64_thin_kernel<f16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_THIN);
     (void)hipFuncSetAttribute((const void*)conv64_v2_kernel<bf16_t, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS64V2);
     (void)hipFuncSetAttribute((const void*)conv64_v2_kernel<bf16_t, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS64V2);
     (void)hipFuncSetAttribute((const void*)conv64_v2_kernel<bf16_t, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS64V2);
@@ -1130,7 +1001,6 @@ int fsr_conv64_persistent_try(int dtype, ConvKArgs& a, int S, hipStream_t stream
     (void)hipFuncSetAttribute((const void*)conv64_v2_kernel<f16_t, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS64V2);
     attr_set = true;
   }
-  static const bool first_form = getenv("FSR_CONV64_V1") && atoi(getenv("FSR_CONV64_V1")) != 0;   // A/B switch
   const int cus = persistent_slots();    // one persistent workgroup per CU (LDS admits exactly one)
   const int nblk = thin ? 1 : a.Cout / 64;                   // channel blocks: workgroup w -> block w % nblk
   int slots = thin ? 2 * cus : cus / nblk;                   // tile ranges (the thin kernel's LDS admits two workgroups per CU)
@@ -1142,21 +1012,18 @@ int fsr_conv64_persistent_try(int dtype, ConvKArgs& a, int S, hipStream_t stream
   a.stats_per = per;
   a.stats_P = (a.stats_tpi + per - 1) / per + 1;
   const int grid = (int)((ntiles + per - 1) / per) * nblk;
-  const size_t lds_thin = 9 * 16 * P64 * 2 + H_BYTES + 16;
   if (dtype == FSR_F16) {
-    if (thin) hipLaunchKernelGGL((conv64_persistent_kernel<f16_t, 1>), dim3(grid), dim3(NTHR64), lds_thin, stream, a);
-    else if (first_form) hipLaunchKernelGGL((conv64_persistent_kernel<f16_t, 4>), dim3(grid), dim3(NTHR64), LDS64, stream, a);
+    if (thin) hipLaunchKernelGGL((conv64_thin_kernel<f16_t>), dim3(grid), dim3(NTHR64), LDS_THIN, stream, a);
     else if (a.stats) hipLaunchKernelGGL((conv64_v2_kernel<f16_t, true, false>), dim3(grid), dim3(NTHR64), LDS64V2, stream, a);
     else if (a.dmask) hipLaunchKernelGGL((conv64_v2_kernel<f16_t, false, true>), dim3(grid), dim3(NTHR64), LDS64V2, stream, a);
     else hipLaunchKernelGGL((conv64_v2_kernel<f16_t, false, false>), dim3(grid), dim3(NTHR64), LDS64V2, stream, a);
   } else {
-    if (thin) hipLaunchKernelGGL((conv64_persistent_kernel<bf16_t, 1>), dim3(grid), dim3(NTHR64), lds_thin, stream, a);
-    else if (first_form) hipLaunchKernelGGL((conv64_persistent_kernel<bf16_t, 4>), dim3(grid), dim3(NTHR64), LDS64, stream, a);
+    if (thin) hipLaunchKernelGGL((conv64_thin_kernel<bf16_t>), dim3(grid), dim3(NTHR64), LDS_THIN, stream, a);
     else if (a.stats) hipLaunchKernelGGL((conv64_v2_kernel<bf16_t, true, false>), dim3(grid), dim3(NTHR64), LDS64V2, stream, a);
     else if (a.dmask) hipLaunchKernelGGL((conv64_v2_kernel<bf16_t, false, true>), dim3(grid), dim3(NTHR64), LDS64V2, stream, a);
     else hipLaunchKernelGGL((conv64_v2_kernel<bf16_t, false, false>), dim3(grid), dim3(NTHR64), LDS64V2, stream, a);
   }
-  fsr_note_kernel(thin ? "conv64_persistent_kernel<1>" : (first_form ? "conv64_persistent_kernel<4>" : "conv64_v2_kernel"));
-  int rc = fsr_check_launch("conv64_persistent_kernel");
+  fsr_note_kernel(thin ? "conv64_thin_kernel" : "conv64_v2_kernel");
+  int rc = fsr_check_launch(thin ? "conv64_thin_kernel" : "conv64_v2_kernel");
   return rc ? rc : 1;
 }

@@ -207,7 +207,11 @@ def _workspace(nbytes, device):
             # capture can have seen is simply dropped, so a run of growing requests does not pile up)
             if _capture_seen.get(key):
                 _ws_retired.append(buf)
-            nbytes = max(nbytes, 2 * buf.numel() * 4)      # geometric growth: O(log) reallocations, not one per larger request
+            # geometric growth (O(log) reallocations, not one per larger request), capped: doubling below 64 MB, +25 % above --
+            # a retired generation stays pinned for as long as a captured graph may address it, so large split-K workspaces
+            # must not double their way to hundreds of MB each
+            old = buf.numel() * 4
+            nbytes = max(nbytes, 2 * old if old < (64 << 20) else old + old // 4)
         buf = torch.empty((max(nbytes, 1 << 20) + 3) // 4, dtype=torch.float32, device=device)
         _ws[key] = buf
         _capture_seen[key] = False

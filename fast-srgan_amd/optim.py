@@ -92,7 +92,13 @@ class ArenaAdamW(torch.optim.Optimizer):
                         "exp_avg_sq": self.exp_avg_sq[off:off + n].view(shape).clone()}
         g = dict(self.param_groups[0])
         g["params"] = list(range(len(self._params)))
-        return {"state": state, "param_groups": [g]}
+        sd = {"state": state, "param_groups": [g]}
+        if self.scale_state is not None:
+            # extra top-level key (torch.optim.Optimizer.load_state_dict reads only "state" / "param_groups", so reference-format
+            # loaders ignore it): {scale, clean iterations, non-finite flag, skipped iterations} of the dynamic fp16 loss scale --
+            # a resumed run continues at the scale it had backed off to instead of overflowing its way down again
+            sd["fsr_loss_scale_state"] = self.scale_state.detach().cpu().clone()
+        return sd
 
     def load_state_dict(self, sd):
         for i, (off, n) in enumerate(self._slices):
@@ -105,3 +111,8 @@ class ArenaAdamW(torch.optim.Optimizer):
         for k in ("lr", "betas", "eps", "weight_decay"):
             if k in sd["param_groups"][0]:
                 self.param_groups[0][k] = sd["param_groups"][0][k]
+        saved = sd.get("fsr_loss_scale_state")
+        if saved is not None and self.scale_state is not None:
+            v = saved.to(torch.float32).reshape(-1).clone()
+            v[2] = 0.0                                   # never resume with the non-finite flag up
+            self.scale_state.copy_(v)

@@ -13,7 +13,7 @@ import numpy as np
 import torch
 
 from . import distributed as D
-from .config import load_config
+from .config import enter_run_dir, hydra_run_settings, load_config
 from .dataloader import DeviceBatchLoader, NumpyImagesDataset
 from .trainer import Trainer
 
@@ -37,11 +37,22 @@ def write_images_to_numpy_arrays(image_list, output_dir):
             executor.submit(_write, image_path, os.path.join(output_dir, os.path.basename(image_path).replace(".png", "")))
 
 
-def main(argv=None):
-    config = load_config("configs/config.yaml", sys.argv[1:] if argv is None else argv)
+def main(argv=None, config_dir="configs"):
+    argv = sys.argv[1:] if argv is None else list(argv)
+    config = load_config(os.path.join(config_dir, "config.yaml"), argv)
     rank, world, local_rank = D.init_from_env()
     if torch.cuda.is_available():
         torch.cuda.set_device(local_rank)
+    # hydra 1.1 (train.py:46) runs `main` inside outputs/<date>/<time>: rank 0 names the directory, every rank enters it
+    run_dir = [hydra_run_settings(argv)[1]]
+    if world > 1:
+        torch.distributed.broadcast_object_list(run_dir, src=0)
+    if rank == 0:
+        enter_run_dir(config, argv, run_dir[0])
+    if world > 1:
+        torch.distributed.barrier()
+    if rank != 0:
+        enter_run_dir(config, argv, run_dir[0], create=False)
     if rank == 0 and not os.path.exists(config.data.numpy_dir):
         write_images_to_numpy_arrays([os.path.join(config.data.image_dir, x) for x in os.listdir(config.data.image_dir)
                                       if x.endswith(".png")], config.data.numpy_dir)

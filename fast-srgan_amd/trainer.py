@@ -81,6 +81,10 @@ class Trainer:
         # Dynamic (the fp16 default): S lives on the device; every optimizer step checks its gradient arena for inf / NaN
         # and skips the update when it finds one, the iteration then halves S, and 1000 clean iterations double it
         # (fsr_grad_nonfinite / fsr_adamw_step_scaled / fsr_loss_scale_update: decided on the device, so hipGraph replays adapt).
+        # COUPLED skip, unlike torch.amp.GradScaler's per-optimizer found_inf: both optimizers share one non-finite flag, so a
+        # discriminator overflow also skips the generator update of that iteration (its gradients went through the same
+        # too-large scale).  The flag is cleared at the START of every iteration as well as by the scale update, so an
+        # exception between a flagged step and the update cannot leave it up for the next iteration.
         # The initial 2^20 is measured (tools/f16_scale_probe.py, profiles/r03_f16_loss_scale.txt): at 2^14 nothing overflows
         # but part of the perceptual gradient underflows and 300 iterations end with a content loss 5-10x the fp32 runs';
         # 2^20 .. 2^22 track fp32; 2^26 overflows, is halved four times in the first iterations and then tracks fp32 too.
@@ -89,6 +93,8 @@ class Trainer:
             raise ValueError("training.loss_scale must be a positive finite number, got %r" % (self.loss_scale,))
         self.dynamic_loss_scale = bool(getattr(config.training, "dynamic_loss_scale", cdt == "f16"))
         self.loss_scale_growth_interval = float(getattr(config.training, "loss_scale_growth_interval", 1000))
+        if not self.loss_scale_growth_interval >= 1.0:
+            raise ValueError("training.loss_scale_growth_interval must be >= 1, got %r" % (self.loss_scale_growth_interval,))
         self._scale_state = None
         if self.dynamic_loss_scale:
             self._scale_state = torch.tensor([self.loss_scale, 0.0, 0.0, 0.0], dtype=torch.float32, device=dev)
@@ -142,6 +148,7 @@ class Trainer:
         dev = lr_images.device
         ops.zero_pool_reset(dev)        # one memset for all statistics / reduction scratch of the iteration
         ops.wgrad_stream_begin(dev)     # weight gradients run beside the data-gradient chain (ops.py)
+        self._clear_nonfinite_flag()
         # The frozen perceptual branch (VGG(hr), VGG(sr) and its backward: ~45 % of the kernel time) runs on a second
         # HIP stream: it only meets the rest of the iteration at `sr_images` and at the loss sum, so its kernels
         # fill the gaps the discriminator / generator kernels leave (tails, 1-workgroup-per-CU weight gradients,
@@ -224,6 +231,10 @@ class Trainer:
             c = self._seed_consts[str(dev)] = (torch.tensor(0.5 * s, dtype=torch.float32, device=dev),
                                                torch.tensor(0.05 * s, dtype=torch.float32, device=dev))
         return c
+
+    def _clear_nonfinite_flag(self):
+        if self._scale_state is not None:
+            self._scale_state[2:3].zero_()
 
     def _update_loss_scale(self):
         if self._scale_state is not None:
@@ -341,6 +352,7 @@ class Trainer:
         """trainer.py:107-111."""
         ops.zero_pool_reset(lr_images.device)
         try:
+            self._clear_nonfinite_flag()
             self.optim_generator.zero_grad()
             fake_hr_images = self.generator(lr_images)
             gen_loss = self.l1_loss(fake_hr_images, hr_images)

@@ -32,7 +32,10 @@ def test_train_entry_point_runs_and_checkpoints(tmp_path, monkeypatch):
         train.main([f"data.numpy_dir={npdir}", "data.lr_image_size=16", "data.scale_factor=4", "generator.n_filters=32",
                     "generator.n_layers=1", "discriminator.n_filters=32", "training.batch_size=2",
                     "training.pretrain_iterations=2", "training.iterations=3", "training.log_iter=1",
-                    "training.checkpoint_iter=3", "experiment.name=cli"])
+                    "training.checkpoint_iter=3", "experiment.name=cli", "hydra.run.dir=run1"])
+    # hydra 1.1 semantics (train.py:46): main ran inside the run directory, so `runs/` lies there, next to .hydra/
+    assert os.path.exists(tmp_path / "run1" / ".hydra" / "config.yaml") and os.path.exists(tmp_path / "run1" / ".hydra" / "overrides.yaml")
+    tmp_path = tmp_path / "run1"
     for f in ("generator_epoch_3.pt", "discriminator_epoch_3.pt", "generator_optim_epoch_3.pt", "discriminator_optim_epoch_3.pt"):
         assert os.path.exists(tmp_path / "runs" / "cli" / f), f            # trainer.py:143-156 file names
     assert os.path.exists(tmp_path / "runs" / "pretrain_generator.pt")

@@ -1,4 +1,5 @@
 """Step-level parity (trainer.py:171-196) and the host logic around it."""
+import importlib
 import os
 import random
 import types
@@ -111,6 +112,33 @@ def test_config_loader_keys_and_overrides(pkg, tmp_path):
     assert cfg.training.generator_lr == 2e-4 and cfg.training.discriminator_lr == 1e-4
     with pytest.raises(ValueError):
         pkg.load_config(None, ["nonsense"])
+
+
+def test_reference_defaults_and_hydra_run_directory(pkg, tmp_path, monkeypatch):
+    """configs/config.yaml carries the reference's values (configs/config.yaml:7,22), and train.main reproduces what
+    `@hydra.main(version_base="1.1")` does around the reference's main (train.py:46): outputs/<date>/<time>, .hydra/."""
+    import datetime
+    import yaml
+    cfgmod = importlib.import_module("fast-srgan_amd.config")
+    root = os.path.dirname(os.path.dirname(__file__))
+    cfg = pkg.load_config(os.path.join(root, "configs", "config.yaml"))
+    assert cfg.data.lr_image_size == 24 and cfg.training.batch_size == 24 and cfg.data.scale_factor == 4
+    assert cfg.training.pretrain_iterations == 100 and cfg.generator.n_layers == 8 and cfg.discriminator.n_layers == 7
+    now = datetime.datetime(2024, 12, 18, 7, 8, 9)
+    assert cfgmod.hydra_run_settings([], now) == (True, os.path.join("outputs", "2024-12-18", "07-08-09"))
+    assert cfgmod.hydra_run_settings(["hydra.job.chdir=false", "a.b=1"], now)[0] is False
+    assert cfgmod.hydra_run_settings(["hydra.run.dir=x/y"], now) == (True, "x/y")
+    monkeypatch.chdir(tmp_path)
+    ov = ["data.numpy_dir=np", "hydra.run.dir=x/y", "training.batch_size=3"]
+    cfg = pkg.load_config(None, ov)                       # hydra.* keys are not config keys
+    assert not hasattr(cfg, "hydra") and cfg.training.batch_size == 3
+    got = cfgmod.enter_run_dir(cfg, ov)
+    assert got == str(tmp_path / "x" / "y") and os.getcwd() == got
+    assert cfg.data.numpy_dir == str(tmp_path / "np")     # relative data paths survive the chdir
+    assert yaml.safe_load(open(".hydra/overrides.yaml")) == ["data.numpy_dir=np", "training.batch_size=3"]
+    assert yaml.safe_load(open(".hydra/config.yaml"))["training"]["batch_size"] == 3
+    monkeypatch.chdir(tmp_path)
+    assert cfgmod.enter_run_dir(pkg.load_config(None, []), ["hydra.job.chdir=false"]) is None and os.getcwd() == str(tmp_path)
 
 
 def test_resize_taps_match_oracle(pkg):
@@ -226,11 +254,37 @@ def test_trainer_rejects_bad_loss_scale(pkg):
     import types
     ns = types.SimpleNamespace
     for bad in (0.0, -4.0, float("nan")):
-        cfg = ns(experiment=ns(name="t", seed=1), generator=ns(n_filters=16, n_layers=1), discriminator=ns(n_filters=16, n_layers=7),
+        cfg = ns(experiment=ns(name="t", seed=1), generator=ns(n_filters=32, n_layers=1), discriminator=ns(n_filters=32, n_layers=7),
                  training=ns(compiled=False, device="cpu", log_iter=1, checkpoint_iter=10 ** 9, generator_lr=1e-4, discriminator_lr=1e-4,
                              batch_size=1, compute_dtype="f16", loss_scale=bad))
-        with pytest.raises(ValueError):
-            pkg.Trainer(cfg, perceptual_network=pkg.VGG19(compute_dtype="f16", width_div=8, seed=1))
+        with pytest.raises(ValueError, match="loss_scale"):
+            pkg.Trainer(cfg, perceptual_network=pkg.VGG19(compute_dtype="f16", width_div=2, seed=1))
+    for bad in (0, 0.5, float("nan")):            # validated on the host, not at the first device step
+        cfg.training.loss_scale, cfg.training.loss_scale_growth_interval = 1024.0, bad
+        with pytest.raises(ValueError, match="growth_interval"):
+            pkg.Trainer(cfg, perceptual_network=pkg.VGG19(compute_dtype="f16", width_div=2, seed=1))
+
+
+def test_loss_scale_state_survives_a_checkpoint(pkg):
+    """the device-side {scale, clean count, flag, skipped} of the dynamic fp16 loss scale rides in the
+    optimizer checkpoint as an extra key (torch's own load_state_dict ignores it) and is restored on resume -- with the
+    non-finite flag down."""
+    select("emu")
+    ps = [torch.nn.Parameter(torch.randn(4, 4, 3, 3))]
+    opt = pkg.ArenaAdamW(ps, lr=1e-3)
+    assert "fsr_loss_scale_state" not in opt.state_dict()          # static scale: the reference's format, nothing added
+    opt.scale_state = torch.tensor([4096.0, 17.0, 1.0, 3.0])
+    sd = opt.state_dict()
+    assert sd["fsr_loss_scale_state"].tolist() == [4096.0, 17.0, 1.0, 3.0]
+    ref = torch.optim.AdamW([torch.nn.Parameter(torch.randn(4, 4, 3, 3))], lr=1e-3)
+    ref.load_state_dict({k: v for k, v in sd.items()})             # a reference-format loader takes the file as it is
+    opt2 = pkg.ArenaAdamW([torch.nn.Parameter(torch.randn(4, 4, 3, 3))], lr=1e-3)
+    opt2.scale_state = torch.tensor([1048576.0, 0.0, 0.0, 0.0])
+    opt2.load_state_dict(sd)
+    assert opt2.scale_state.tolist() == [4096.0, 17.0, 0.0, 3.0]
+    opt3 = pkg.ArenaAdamW([torch.nn.Parameter(torch.randn(4, 4, 3, 3))], lr=1e-3)   # a static-scale run ignores the key
+    opt3.load_state_dict(sd)
+    assert opt3.scale_state is None
 
 
 @pytest.mark.gpu
