@@ -27,6 +27,11 @@ Extra keys of that line:
   cpu_baseline  the oracle's CPU restatement of the same iteration AND of generator inference at 90x160 / 180x320 (BASELINE.md
                 section 3: "inference + one G/D step"), timed on the host cores (N=1, rank 0); `cores` = threads used,
                 `host_cores` = what the box has;
+  cfg5          (default N = 1 run) BASELINE configs[4] as a measured configuration: 12 residual blocks, three pixel-shuffle stages,
+                128x128 -> 1024x1024, fp16 MFMA with the dynamic loss scale, batch 4 on this GPU, >= 100 steps and >= 5 s of hipGraph
+                replays, with its own roofline (`python bench.py --workload cfg5` prints the same workload as the main line);
+  allreduce     (a process group exists) ms per step the main stream spends in the two RCCL gradient exchanges, from HIP events
+                around each (10 extra steps outside the timed region), per exchange and as the maximum over ranks;
   inference     generator-only FPS at 90x160 and 180x320 (BASELINE.json configs[1]), batch 1 and batch 32, plus the
                 end-to-end rate of the uint8 frame pipeline (host bytes -> H2D -> G -> uint8 epilogue -> D2H).
 """
@@ -61,11 +66,11 @@ def ns(**k):
 
 WORKLOADS = {
     # BASELINE.json configs[2] (and [3] per GPU): the headline metric
-    "cfg3": dict(n_layers=8, n_upsample=2, lr=96, batch=32, gflop_ref=686.71,
+    "cfg3": dict(n_layers=8, n_upsample=2, lr=96, batch=32, gflop_ref=686.71, dtype="bf16",
                  name="BASELINE configs[2]: full GAN training step, 8 residual blocks / 64 filters, 96x96->384x384",
                  metric="SR train-step images/sec (96->384 4x, full GAN step: G+D+VGG perceptual loss)"),
-    # BASELINE.json configs[4]: 12 blocks, three pixel-shuffle stages, 128 -> 1024 (16-bit MFMA: bf16 here)
-    "cfg5": dict(n_layers=12, n_upsample=3, lr=128, batch=4, gflop_ref=None,
+    # BASELINE.json configs[4]: 12 blocks, three pixel-shuffle stages, 128 -> 1024, fp16 MFMA (the dtype that config names)
+    "cfg5": dict(n_layers=12, n_upsample=3, lr=128, batch=4, gflop_ref=None, dtype="f16",
                  name="BASELINE configs[4]: full GAN training step, 12 residual blocks / 64 filters, three pixel-shuffle stages, 128x128->1024x1024",
                  metric="SR train-step images/sec (128->1024 8x, full GAN step: G+D+VGG perceptual loss)"),
 }
@@ -340,7 +345,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--batch", type=int, default=None, help="per-GPU batch (default: 32 for cfg3, 4 for cfg5)")
     ap.add_argument("--workload", default="cfg3", choices=sorted(WORKLOADS), help="cfg3 = the headline metric; cfg5 = BASELINE configs[4]")
-    ap.add_argument("--dtype", default="bf16", choices=["bf16", "f16", "f32"])
+    ap.add_argument("--dtype", default=None, choices=["bf16", "f16", "f32"], help="default: the workload's (cfg3 bf16, cfg5 f16)")
+    ap.add_argument("--no-cfg5", action="store_true", help="skip the BASELINE configs[4] leg of the default N = 1 line")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-inference", action="store_true")
     ap.add_argument("--no-f32", action="store_true", help="skip the exact-f32 (reference precision) leg")
@@ -367,8 +373,10 @@ def main():
     wl = WORKLOADS[args.workload]
     if args.batch is None:
         args.batch = wl["batch"]
+    if args.dtype is None:
+        args.dtype = wl["dtype"]
     if args.workload != "cfg3":
-        args.no_inference = args.no_f32 = args.no_cpu_baseline = True     # those legs belong to the headline workload
+        args.no_inference = args.no_f32 = args.no_cpu_baseline = args.no_cfg5 = True     # those legs belong to the headline workload
     torch.manual_seed(1234)
     trainer = pkg.Trainer(make_config(args.batch, args.dtype, device, wl), perceptual_network=pkg.VGG19(compute_dtype=args.dtype, seed=1234))
     torch.manual_seed(100 + rank)
@@ -393,8 +401,32 @@ def main():
                 "ms_per_step": round(el / n * 1e3, 3), "clock": c.summary()}
 
     sustained = None
-    if not args.no_sustained and args.workload == "cfg3" and elapsed < 5.0:
+    if not args.no_sustained and elapsed < 5.0:
         sustained = sustained_leg(step_fn, ms_per_step, B)
+
+    # N > 1 (or a 1-rank RCCL world): what the two gradient exchanges cost a step, outside the timed region -- HIP events from
+    # the moment the main stream hands a gradient arena to RCCL to the moment it may continue (distributed.GradSync.record)
+    allreduce = None
+    if dist_mod.is_distributed():
+        dist_mod.GradSync.record = []
+        n_ar = 10
+        for _ in range(n_ar):
+            step_fn(lr, hr)
+        torch.cuda.synchronize()
+        rec, dist_mod.GradSync.record = dist_mod.GradSync.record, None
+        per = {}
+        for tag, e0, e1 in rec:
+            per[tag] = per.get(tag, 0.0) + e0.elapsed_time(e1)
+        allreduce = {"ms_in_allreduce": round(sum(per.values()) / n_ar, 4),
+                     "per_exchange_ms": {k: round(v / n_ar, 4) for k, v in per.items()},
+                     "bytes": {"discriminator": trainer.optim_discriminator.flat_grad.numel() * 4, "generator": trainer.optim_generator.flat_grad.numel() * 4},
+                     "steps": n_ar, "rank": rank,
+                     "what": "HIP events on the main stream around each exchange (start of the RCCL all-reduce -> the stream may continue); "
+                             "under phase graphs nothing overlaps an exchange, so this is its exposed cost"}
+        if world > 1:   # the slowest rank's figure is the one that matters
+            t = torch.tensor([allreduce["ms_in_allreduce"]], device=device, dtype=torch.float64)
+            torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+            allreduce["ms_in_allreduce_max_over_ranks"] = round(float(t.item()), 4)
 
     roofline, executed_gflop_per_image = measure_roofline(trainer, ops, lr, hr, args.dtype, ms_per_step, B)
 
@@ -430,6 +462,8 @@ def main():
                                          "note": "clock = mean over the timed iterations (all kernels), not the dominant kernel alone"}
     if sustained is not None:
         out["sustained"] = sustained
+    if allreduce is not None:
+        out["allreduce"] = allreduce
     if rank == 0 and world == 1 and not args.no_f32 and args.dtype != "f32":
         # the same iteration at the reference's own precision (exact-f32 MFMA: the mode inside north_star's 1e-3 tolerance),
         # with the SAME --steps / --warmup and its own roofline against the f32 MFMA peak
@@ -451,6 +485,38 @@ def main():
         if sustained is not None and el < 5.0:
             out["f32_mode"]["sustained"] = sustained_leg(fn32, ms32, B)
         del t32, fn32
+        torch.cuda.empty_cache()
+
+    if rank == 0 and world == 1 and not args.no_cfg5:
+        # BASELINE configs[4] as a measured configuration (round-3 verdict): 12 blocks, three pixel-shuffle stages, 128 -> 1024,
+        # fp16 MFMA with the dynamic loss scale, batch 4 on one GPU (configs[4] names 8 GPUs: weak scaling repeats this per GPU),
+        # >= 100 steps and >= 5 s timed, hipGraph replay, its own roofline
+        w5 = WORKLOADS["cfg5"]
+        b5, dt5 = w5["batch"], w5["dtype"]
+        torch.manual_seed(1234)
+        t5 = pkg.Trainer(make_config(b5, dt5, device, w5), perceptual_network=pkg.VGG19(compute_dtype=dt5, seed=1234))
+        hr5 = w5["lr"] * 2 ** w5["n_upsample"]
+        lr_5 = torch.rand(b5, 3, w5["lr"], w5["lr"], device=device) * 2 - 1
+        hr_5 = torch.rand(b5, 3, hr5, hr5, device=device) * 2 - 1
+        fn5, launch5 = build_step(pkg, t5, lr_5, hr_5, not args.no_graph)
+        el = time_steps(fn5, lr_5, hr_5, 10, 3, 1, device)                      # a first estimate of the step time
+        n5 = max(100, int(5500.0 / (el / 10 * 1e3)) + 1)
+        with ClockSampler(local_rank) as clk5:
+            el = time_steps(fn5, lr_5, hr_5, n5, 2, 1, device)
+        ms5 = el / n5 * 1e3
+        roof5, gflop5 = measure_roofline(t5, ops, lr_5, hr_5, dt5, ms5, b5)
+        for k in ("traffic", "traffic_source", "family", "lds_fed_mfma_ceiling"):
+            roof5.pop(k, None)
+        roof5["kernels"] = roof5["kernels"][:5]
+        scale5 = t5.loss_scale_state()
+        out["cfg5"] = {"metric": w5["metric"], "workload": w5["name"], "value": round(b5 * n5 / el, 3), "unit": "images/s",
+                       "per_gpu_batch": b5, "n_gpus": 1, "dtype": dt5, "steps": n5, "timed_region_s": round(el, 3), "ms_per_step": round(ms5, 3),
+                       "launch": launch5, "clock": clk5.summary(), "step_gflop_executed_per_image": round(gflop5, 2),
+                       "step_tflops_executed": round(b5 * n5 / el * gflop5 / 1e3, 2),
+                       "loss_scale": {"final": scale5[0], "skipped_iterations": scale5[1]} if scale5 else None,
+                       "parity": "tests/test_parity_bench.py::test_train_step_cfg5_three_stage_generator_f16, ::test_generator_cfg5_full_size_vs_oracle",
+                       "roofline": roof5}
+        del t5, fn5, lr_5, hr_5
         torch.cuda.empty_cache()
 
     if rank == 0 and not args.no_inference:

@@ -47,16 +47,28 @@ def is_distributed():
 
 
 class GradSync:
-    """Gradient exchange for one optimizer's flat gradient buffer."""
+    """Gradient exchange for one optimizer's flat gradient buffer.
 
-    def __init__(self, optimizer):
+    `GradSync.record = []` (bench.py, N > 1): every exchange appends (tag, start event, end event) -- the start recorded on
+    the current stream when the all-reduce is enqueued, the end after the current stream has been made to wait for it -- so
+    the time a step's main stream spends between handing its gradients to RCCL and being allowed to continue can be reported
+    per step (`ms_in_allreduce`).  None (the default) records nothing."""
+
+    record = None
+
+    def __init__(self, optimizer, tag=""):
         self.optimizer = optimizer
         self.work = None
+        self.tag = tag
+        self._ev0 = None
         optimizer.grad_scale = 1.0 / world_size()
 
     def start(self):
         """Launch the all-reduce (asynchronously where the backend allows); call wait() before step()."""
         if is_distributed():
+            if GradSync.record is not None and self.optimizer.flat_grad.is_cuda:
+                self._ev0 = torch.cuda.Event(enable_timing=True)
+                self._ev0.record()
             self.work = dist.all_reduce(self.optimizer.flat_grad, op=dist.ReduceOp.SUM, async_op=True)
 
     def run(self):
@@ -67,6 +79,12 @@ class GradSync:
         if self.work is not None:
             self.work.wait()
             self.work = None
+            if self._ev0 is not None:
+                ev1 = torch.cuda.Event(enable_timing=True)
+                ev1.record()
+                if GradSync.record is not None:
+                    GradSync.record.append((self.tag, self._ev0, ev1))
+                self._ev0 = None
 
 
 def all_ranks_ok(ok, device=None):

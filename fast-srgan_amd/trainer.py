@@ -72,8 +72,8 @@ class Trainer:
         self.optim_discriminator = ArenaAdamW(self.discriminator.parameters(), lr=self.config.training.discriminator_lr)
         D.broadcast_parameters(self.optim_generator)
         D.broadcast_parameters(self.optim_discriminator)
-        self._sync_g = D.GradSync(self.optim_generator)
-        self._sync_d = D.GradSync(self.optim_discriminator)
+        self._sync_g = D.GradSync(self.optim_generator, "generator")
+        self._sync_d = D.GradSync(self.optim_discriminator, "discriminator")
         # Loss scaling (extension keys training.loss_scale, training.dynamic_loss_scale; defaults 1 / off, and 2^20 / on in
         # the fp16 mode): both backward passes are seeded with S and AdamW divides the gradients by S again.  fp16 activation
         # gradients need it: the content loss is a mean over N x 512 x 24 x 24 values, its per-element gradient (~4e-8) lies

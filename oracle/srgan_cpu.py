@@ -190,43 +190,65 @@ def adamw_step(params, grads, state, lr=1e-4, betas=(0.9, 0.999), eps=1e-8, wd=1
         params[k].addcdiv_(m, denom, value=-lr / bc1)
 
 
-def train_step(g_sd, d_sd, v_sd, lr_images, hr_images, noise, g_state, d_state, g_lr=1e-4, d_lr=1e-4, grads_out=None, q=None):
+def train_step(g_sd, d_sd, v_sd, lr_images, hr_images, noise, g_state, d_state, g_lr=1e-4, d_lr=1e-4, grads_out=None, q=None,
+               chunk=None):
     """One iteration of Trainer.train's loop body, trainer.py:171-196, line for line.  `noise` is the
     three torch.rand_like draws of :175, :176, :187 (injected: device RNG streams differ).
     g_sd / d_sd are updated in place; returns the four logged losses (:199-218).  grads_out (optional dict) receives the
     gradients of the two backward passes under "d.<key>" / "g.<key>".  q = Q_BF16: the same iteration with the bf16
-    mode's storage roundings."""
+    mode's storage roundings.
+    chunk (optional, must divide the batch): the batch is walked in slices of `chunk` samples and the gradients are
+    accumulated -- the SAME iteration, because every layer of the three networks is per-sample (InstanceNorm, no BatchNorm) and
+    every loss is a batch mean, so loss = sum_c (|c| / B) loss_c and likewise its gradient.  It bounds the autograd memory of
+    the batch-32 parity test to that of a batch of `chunk` (tests/test_oracle.py checks chunked == whole)."""
+    B = lr_images.shape[0]
+    chunk = B if chunk is None else int(chunk)
+    if chunk <= 0 or B % chunk != 0:
+        raise ValueError("chunk must divide the batch")
+    slices = [slice(i, i + chunk) for i in range(0, B, chunk)]
+    wgt = float(chunk) / float(B)
+
+    def accumulate(total, part):
+        return [p.detach().clone() for p in part] if total is None else [t.add_(p.detach()) for t, p in zip(total, part)]
+
     # ---- discriminator step, :171-181
     dp = {k: v.detach().clone().requires_grad_(True) for k, v in d_sd.items()}
-    y_real = discriminator_forward(dp, hr_images, q)                           # :172
-    with torch.no_grad():
-        sr = generator_forward(g_sd, lr_images, q)                             # :173 (.detach())
-    y_fake = discriminator_forward(dp, sr, q)                                  # :174
-    real_labels = 0.3 * noise[0] + 0.8                                         # :175
-    fake_labels = 0.3 * noise[1]                                               # :176
-    loss_real = bce_with_logits(y_real, real_labels)                           # :177
-    loss_fake = bce_with_logits(y_fake, fake_labels)                           # :178
-    d_loss = 0.5 * loss_real + 0.5 * loss_fake                                 # :179
-    grads = torch.autograd.grad(d_loss, list(dp.values()))                     # :180
+    grads, loss_real, loss_fake = None, 0.0, 0.0
+    for sl in slices:
+        y_real = discriminator_forward(dp, hr_images[sl], q)                   # :172
+        with torch.no_grad():
+            sr = generator_forward(g_sd, lr_images[sl], q)                     # :173 (.detach())
+        y_fake = discriminator_forward(dp, sr, q)                              # :174
+        real_labels = 0.3 * noise[0][sl] + 0.8                                 # :175
+        fake_labels = 0.3 * noise[1][sl]                                       # :176
+        lr_c = bce_with_logits(y_real, real_labels)                            # :177
+        lf_c = bce_with_logits(y_fake, fake_labels)                            # :178
+        d_loss = 0.5 * lr_c + 0.5 * lf_c                                       # :179
+        grads = accumulate(grads, torch.autograd.grad(wgt * d_loss, list(dp.values())))   # :180
+        loss_real = loss_real + wgt * lr_c.detach()
+        loss_fake = loss_fake + wgt * lf_c.detach()
     if grads_out is not None:
         grads_out.update({"d." + k: g.detach().clone() for k, g in zip(dp.keys(), grads)})
     adamw_step(d_sd, dict(zip(dp.keys(), grads)), d_state, lr=d_lr)            # :181
     # ---- generator step, :184-196
     gp = {k: v.detach().clone().requires_grad_(True) for k, v in g_sd.items()}
-    sr = generator_forward(gp, lr_images, q)                                   # :185
-    y_fake = discriminator_forward(d_sd, sr, q)                                # :186 (updated D)
-    real_labels = 0.3 * noise[2] + 0.7                                         # :187
-    adv_loss = 1e-1 * bce_with_logits(y_fake, real_labels)                     # :188
-    fake_features = vgg_forward(v_sd, sr, q)                                   # :190
-    real_features = vgg_forward(v_sd, hr_images, q)                            # :191
-    content_loss = smooth_l1(fake_features, real_features)                     # :192
-    g_loss = 0.5 * adv_loss + 0.5 * content_loss                               # :194
-    grads = torch.autograd.grad(g_loss, list(gp.values()))                     # :195
+    grads, adv_loss, content_loss = None, 0.0, 0.0
+    for sl in slices:
+        sr = generator_forward(gp, lr_images[sl], q)                           # :185
+        y_fake = discriminator_forward(d_sd, sr, q)                            # :186 (updated D)
+        real_labels = 0.3 * noise[2][sl] + 0.7                                 # :187
+        adv_c = 1e-1 * bce_with_logits(y_fake, real_labels)                    # :188
+        fake_features = vgg_forward(v_sd, sr, q)                               # :190
+        real_features = vgg_forward(v_sd, hr_images[sl], q)                    # :191
+        content_c = smooth_l1(fake_features, real_features)                    # :192
+        g_loss = 0.5 * adv_c + 0.5 * content_c                                 # :194
+        grads = accumulate(grads, torch.autograd.grad(wgt * g_loss, list(gp.values())))   # :195
+        adv_loss = adv_loss + wgt * adv_c.detach()
+        content_loss = content_loss + wgt * content_c.detach()
     if grads_out is not None:
         grads_out.update({"g." + k: g.detach().clone() for k, g in zip(gp.keys(), grads)})
     adamw_step(g_sd, dict(zip(gp.keys(), grads)), g_state, lr=g_lr)            # :196
-    return {"loss_real": loss_real.detach(), "loss_fake": loss_fake.detach(),
-            "adv_loss": adv_loss.detach(), "content_loss": content_loss.detach()}
+    return {"loss_real": loss_real, "loss_fake": loss_fake, "adv_loss": adv_loss, "content_loss": content_loss}
 
 
 def pretrain_step(g_sd, lr_images, hr_images, g_state, g_lr=1e-4):

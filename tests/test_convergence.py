@@ -2,7 +2,8 @@
 
 tools/convergence.py trains the BASELINE cfg #1-size networks from one initialisation on identical batches: three exact-f32
 runs that differ only in their label noise (the fp32 run-to-run band) and three bf16 / f16 runs with the same three noise
-seeds; the gated quantity is the MEDIAN of a mode's three runs.  Gates, in half-widths of the band (floored at +-2 % of the
+seeds; the gated quantities are the MEDIAN of a mode's three runs and, per checkpoint, the NUMBER of single runs beyond the
+same gate (at most one of three; the table also lists, per seed, how many checkpoints a run spends outside the band).  Gates, in half-widths of the band (floored at +-2 % of the
 value): every smoothed loss from iteration 100 on within 6, the first 50 iterations -- where the three f32 runs have not
 spread yet and the band is a hair -- within 12, final PSNR / SSIM of the generator on a held-out batch within 4.5; everything
 finite.  Why the median: GAN training is chaotic.  With ONE run per mode (round 3's first form of this test) a re-ordering of
@@ -45,8 +46,19 @@ def test_16bit_training_tracks_fp32_training(pkg):
     pre = results["f32"][0]["curves"]["pretrain_loss"]
     assert sum(pre[-10:]) < 0.5 * sum(pre[:10]), (pre[:3], pre[-3:])
     bad = []
-    for mode, k, t, lo, hi, v, dist, _runs in rows:
+    for row in rows:
+        mode, k, t, lo, hi, v, dist, _runs = row
         gate = QUALITY if k in ("psnr", "ssim") else (LATE if t >= 100 and k != "pretrain_loss" else EARLY)
         if not dist < gate:
             bad.append((mode, k, t, round(lo, 5), round(hi, 5), round(v, 5), round(dist, 2)))
+        # per seed, not only the median (round-3 verdict): at most ONE of a mode's three runs may be beyond the gate at any
+        # checkpoint -- a mode where two trajectories leave is not tracking fp32, whatever its median does
+        far = [round(d, 2) for d in conv.row_distances(row) if not d < gate]
+        if len(far) > 1:
+            bad.append((mode, k, t, "single runs beyond the gate", far))
     assert not bad, bad
+    # and at most one of a mode's runs may spend most of its checkpoints outside the band proper (distance > 1; a band of three
+    # f32 runs is narrow -- round 3: bf16 seeds 0 / 1 / 2 were outside at 18 / 8 / 5 of 28 checkpoints, f16 at 11 / 11 / 10)
+    for mode, per_seed in conv.single_run_exits(rows).items():
+        mostly_out = [seed for seed, (n_out, n_rows, _far) in enumerate(per_seed) if n_out > 0.6 * n_rows]
+        assert len(mostly_out) <= 1, (mode, per_seed)

@@ -795,3 +795,68 @@ def test_conv_tall3(dev, cdn, cin, cout, variant, rows, monkeypatch):
     assert relerr(st[..., 1], (pre * pre).sum((2, 3))) < tol(cdn, 1e-4, 1e-3)
     _, _, stats2 = ops.conv3x3_raw(cd, xd, wpk, cout, bias=bias.to(dev), act=L.ACT_LEAKY, slope=0.2, want_stats=True)
     assert torch.equal(stats2.cpu(), st)                        # no atomics: bit-reproducible
+
+
+# (name, cin, cout, h, w, stride, batch, variant): the launches of the timed iteration whose PERSISTENT WALKS only exist at the
+# benched batch -- conv_tall3's 2.25 / 4.5 / 9 tile rounds over 512 workgroup slots at batch 32 and twice that at the
+# discriminator's 2B = 64, conv64_v2's tile ranges, the stride-2 layers' class launches (round-3 verdict: "the walks at batch
+# 32 / 64 are never compared with anything").
+_TIMED_BATCH_SHAPES = [
+    ("vgg 256->256 @96 b32 (4.5 rounds)", 256, 256, 96, 96, 1, 32, "relu"),
+    ("vgg 512->512 @48 b32 (2.25 rounds)", 512, 512, 48, 48, 1, 32, "relu"),
+    ("vgg 128->128 @192 b32 (9 rounds)", 128, 128, 192, 192, 1, 32, "pool"),
+    ("vgg 512->512 @24 b32 (12-row tiles)", 512, 512, 24, 24, 1, 32, "relu"),
+    ("D 128->256 @96 b64 stats", 128, 256, 96, 96, 1, 64, "stats"),
+    ("D 256->512 @48 b64 stats", 256, 512, 48, 48, 1, 64, "stats"),
+    ("D 64->128 @192 b64 stats (64-channel dgrad block)", 64, 128, 192, 192, 1, 64, "stats"),
+    ("D 128->128 s2 @192 b64", 128, 128, 192, 192, 2, 64, "stats"),
+    ("D 256->256 s2 @96 b64", 256, 256, 96, 96, 2, 64, "stats"),
+    ("D 512->512 s2 @48 b64", 512, 512, 48, 48, 2, 64, "stats"),
+    ("D 64->64 s2 @384 b64", 64, 64, 384, 384, 2, 64, "stats"),
+    ("G 64->64 @96 b32 stats", 64, 64, 96, 96, 1, 32, "stats"),
+]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape", _TIMED_BATCH_SHAPES, ids=lambda s: s[0].split(" (")[0].replace(" ", "_").replace("->", "to"))
+def test_conv_at_the_timed_batch_gpu(shape):
+    """Forward (with the epilogue the iteration uses: ReLU, ReLU + fused 2x2 max-pool, or raw + InstanceNorm statistics) and
+    data gradient (with the fused LeakyReLU mask) of the bf16 kernels at the batch bench.py times, against torch's fp32
+    convolution of the same bf16-rounded operands on the same device."""
+    name, cin, cout, h, w, stride, n, variant = shape
+    dev = select("hip")
+    cd = ops.Compute("bf16")
+    torch.manual_seed(23)
+    oh, ow = (h - 1) // stride + 1, (w - 1) // stride + 1
+    x = torch.randn(n, h, w, cin, device=dev).to(cd.torch_dtype)                     # NHWC, bf16-rounded
+    wt = (torch.randn(cout, cin, 3, 3, device=dev) * (2.0 / (9 * cin)) ** 0.5).to(cd.torch_dtype).float()
+    bias = None if variant == "stats" else (torch.randn(cout, device=dev) * 0.1)
+    wpk = ops.packed_filter(cd, wt, L.PACK_FWD, cin)
+    y, _, stats = ops.conv3x3_raw(cd, x, wpk, cout, stride=stride, bias=bias, act=(L.ACT_NONE if variant == "stats" else L.ACT_RELU),
+                                  want_stats=(variant == "stats"), pool2=(variant == "pool"))
+    kern_f = L.lib().fsr_last_kernel().decode()
+    xr = x.float().permute(0, 3, 1, 2)                                              # a view: torch's conv takes channels-last strides
+    ref = F.conv2d(xr, wt, bias, stride, 1)
+    if variant != "stats":
+        ref = F.relu(ref)
+    if variant == "pool":
+        ref = F.max_pool2d(ref, 2, 2)
+    got = y.float().permute(0, 3, 1, 2)
+    scale = float(ref.abs().max())
+    e = report("timed_batch.%s.fwd" % name.split(" (")[0], float((got - ref).abs().max()) / scale)
+    assert e < 1e-2, (name, kern_f, e)
+    if stats is not None:
+        assert relerr(stats[..., 0], ref.sum((2, 3))) < 2e-3 and relerr(stats[..., 1], (ref * ref).sum((2, 3))) < 2e-3, (name, kern_f)
+    del got, ref, y
+    # data gradient with the LeakyReLU(0.2) backward of the producing layer fused (mask = that layer's output)
+    g = torch.randn(n, oh, ow, cout, device=dev).to(cd.torch_dtype)
+    mask = torch.randn(n, h, w, cin, device=dev).to(cd.torch_dtype)
+    wpk_d = ops.packed_filter(cd, wt, L.PACK_DGRAD, cout)
+    dx, _, _ = ops.conv3x3_raw(cd, g, wpk_d, cin, mode=L.CONV_DGRAD, out_hw=(h, w), stride=stride, dact_mask=mask, dact_slope=0.2)
+    kern_d = L.lib().fsr_last_kernel().decode()
+    want = torch.nn.grad.conv2d_input((n, cin, h, w), wt, g.float().permute(0, 3, 1, 2), stride=stride, padding=1)
+    mk = mask.float().permute(0, 3, 1, 2)
+    want = want * torch.where(mk > 0, torch.ones_like(mk), torch.full_like(mk, 0.2))
+    e = report("timed_batch.%s.dgrad" % name.split(" (")[0], float((dx.float().permute(0, 3, 1, 2) - want).abs().max()) / float(want.abs().max()))
+    assert e < 1e-2, (name, kern_d, e)
+    report("timed_batch.%s.kernels %s | %s" % (name.split(" (")[0], kern_f, kern_d), 0.0)

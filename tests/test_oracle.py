@@ -91,6 +91,34 @@ def test_train_steps_match_reference_trainer():
             assert upd > 0 and (p - p2).abs().mean() <= 0.08 * upd, (pre, k)
 
 
+def test_chunked_train_step_is_the_same_iteration():
+    """O.train_step(chunk=c) walks the batch in slices and accumulates gradients (every layer is per-sample, every loss a
+    batch mean): same losses and gradients as the whole batch.  It is what lets the batch-32 parity test
+    (tests/test_parity_bench.py) run its oracle in the memory of a batch of 4.
+    Checked with the discriminator's update switched off (d_lr = 0): through a live AdamW step, which normalises every
+    element's update to ~lr, the 1e-7 summation-order differences of D's gradients reach the generator's gradients as
+    per-cent differences -- the conditioning DESIGN.md section 5 describes, not a property of chunking."""
+    z = load_npz("train_steps.npz")
+    v = O.vgg_standin_state_dict(int(z["vgg_seed"]), int(z["vgg_width_div"]))
+    lr, hr = torch.from_numpy(z["lr0"]), torch.from_numpy(z["hr0"])
+    B = lr.shape[0]
+    assert B % 2 == 0
+    noise = [torch.from_numpy(z[f"noise{j}"]) for j in range(3)]
+    for d_lr in (0.0, 1e-4):
+        res = []
+        for chunk in (None, B // 2):
+            g, d, grads = sd_from(z, "g0."), sd_from(z, "d0."), {}
+            res.append((O.train_step(g, d, v, lr, hr, noise, {}, {}, grads_out=grads, chunk=chunk, d_lr=d_lr), grads))
+        (o0, g0), (o1, g1) = res
+        for k in o0:
+            assert abs(float(o0[k]) - float(o1[k])) <= (2e-6 if d_lr == 0.0 else 2e-5) * abs(float(o0[k])), (k, float(o0[k]), float(o1[k]))
+        for k in g0:
+            if k.startswith("d.") or d_lr == 0.0:
+                assert rel(g1[k], g0[k]) < (2e-4 if k.startswith("d.") else 1e-3), k
+    with np.testing.assert_raises(ValueError):
+        O.train_step(sd_from(z, "g0."), sd_from(z, "d0."), v, lr, hr, noise, {}, {}, chunk=B + 1)
+
+
 def test_dataset_item_matches_reference_dataset():
     z = load_npz("dataset.npz")
     random.seed(int(z["seed"]))

@@ -27,7 +27,13 @@ def ns(**k):
 #    forward outputs keep the north-star 1e-3;
 #  * the bf16 mode is held to the oracle with the bf16 storage roundings (O.Q_BF16); its distance to the plain fp32 oracle is
 #    reported and loosely bounded.
-F32_VGG_DX, F32_D_GRAD, F32_G_GRAD, F32_G_COS = 2e-2, 2e-2, 0.2, 0.98
+F32_VGG_DX = 2e-2
+# f32-mode gradients of the cfg #1 iteration (round-3 verdict: "bound the kernels, not the network's conditioning"): both the
+# HIP-f32 gradients and the oracle's own float32 gradients are compared with the oracle evaluated in FLOAT64; the HIP error may
+# be at most F64_NET x the oracle's float32 error over a whole network (all tensors concatenated) and F64_TENSOR x per tensor
+# (+ F64_FLOOR of the tensor's norm: tensors the oracle reproduces to 1e-6 would otherwise gate at 1e-6).  A kernel bug shows
+# as a ratio of tens to thousands; summation order shows as ~1.
+F64_NET, F64_TENSOR, F64_FLOOR = 1.5, 2.5, 2e-4
 VGGQ_OUT, VGGQ_DX, VGG_BF16_OUT, VGG_BF16_DX = 1.2e-2, 0.45, 2e-2, 0.7
 #    Measured at cfg #1 (bf16 kernels vs the bf16-storage oracle): the four losses 3e-5, 3e-5, 1.7e-4, 3e-6; gradient tensors
 #    0.15-0.5 relative L2 with norm ratios 0.94-1.01 and cosines 0.995 (D) / 0.90 (G): the forward pass is reproduced to 1e-3,
@@ -120,8 +126,27 @@ def test_train_step_at_baseline_cfg1_size(pkg, cdn):
     if cdn == "f32":
         want, ref = oracle(None)
         losses("f32", want, 1e-3)
-        bad = check_grads("cfg1.f32.grad", named_d, ref, t_tensor=F32_D_GRAD, t_cos=0.9995)
-        bad += check_grads("cfg1.f32.grad", named_g, ref, t_tensor=F32_G_GRAD, t_cos=F32_G_COS)
+        # float64 oracle: the same restatement on double tensors (tests/probes/conditioning_probe.py)
+        ref64 = {}
+        dt = torch.float64
+        O.train_step({k: v.to(dt) for k, v in g0.items()}, {k: v.to(dt) for k, v in d0.items()}, {k: v.to(dt) for k, v in v_sd.items()},
+                     lr.to(dt), hr.to(dt), [n.to(dt) for n in noise], {}, {}, grads_out=ref64)
+        bad = []
+        for tag, named in (("d", named_d), ("g", named_g)):
+            num_h = num_o = den = 0.0
+            for n, g in named:
+                r64 = ref64[n].double()
+                eh, eo, nr = float((g.detach().double().cpu() - r64).norm()), float((ref[n].double() - r64).norm()), float(r64.norm())
+                num_h, num_o, den = num_h + eh * eh, num_o + eo * eo, den + nr * nr
+                report("cfg1.f32.vs_f64.hip.%s" % n, eh / max(nr, 1e-300))
+                report("cfg1.f32.vs_f64.oracle32.%s" % n, eo / max(nr, 1e-300))
+                if g.numel() > 1 and not eh <= F64_TENSOR * eo + F64_FLOOR * nr:
+                    bad.append((n, eh / max(nr, 1e-300), eo / max(nr, 1e-300)))
+            eh, eo = (num_h / den) ** 0.5, (num_o / den) ** 0.5
+            report("cfg1.f32.vs_f64.hip.%s_network" % tag, eh)
+            report("cfg1.f32.vs_f64.oracle32.%s_network" % tag, eo)
+            if not eh <= F64_NET * eo + F64_FLOOR:
+                bad.append((tag + " network", eh, eo))
         assert not bad, bad
         return
     want, ref = oracle(O.Q_BF16)
@@ -181,3 +206,103 @@ def test_generator_cfg5_full_size_vs_oracle(pkg):
             y16 = G16.to(dev).eval()(x.to(dev)).cpu()
         assert report("cfg5.%s.mean_abs" % cdn, float((y16 - want).abs().mean())) < t_mean
         assert report("cfg5.%s.max_abs" % cdn, float((y16 - want).abs().max())) < t_max
+
+
+def _adam_state_for_oracle(opt, names):
+    """The trainer's AdamW moments in the oracle's state format (O.adamw_step): {"step": t, ("m", key): ..., ("v", key): ...}."""
+    sd = opt.state_dict()
+    st = {"step": int(float(sd["state"][0]["step"]))}
+    for i, n in enumerate(names):
+        st[("m", n)] = sd["state"][i]["exp_avg"].detach().cpu().clone()
+        st[("v", n)] = sd["state"][i]["exp_avg_sq"].detach().cpu().clone()
+    return st
+
+
+def test_graph_replayed_bf16_iteration_at_the_benched_batch(pkg):
+    """THE configuration bench.py times (BASELINE configs[2]): batch 32 (the discriminator sees 2B = 64), 96 -> 384, bf16, the
+    iteration replayed as ONE hipGraph with the perceptual branch and the weight gradients on their side streams -- against
+    the oracle with the bf16 storage model (trainer.py:171-196), evaluated in slices of 4 samples (O.train_step(chunk=4), the
+    same iteration: tests/test_oracle.py).  One eager iteration warms the buffers and moves the weights off their
+    initialisation; the replay then runs on a NEW batch, so it demonstrably reads the graph's static inputs."""
+    dev = select("hip")
+    torch.manual_seed(9)
+    B = 32
+    cfg = ns(experiment=ns(name="cfg2", seed=1234), generator=ns(n_filters=64, n_layers=8),
+             discriminator=ns(n_filters=64, n_layers=7),
+             training=ns(compiled=False, device=str(dev), log_iter=1, checkpoint_iter=10 ** 9, generator_lr=1e-4,
+                         discriminator_lr=1e-4, batch_size=B, compute_dtype="bf16"))
+    T = pkg.Trainer(cfg, perceptual_network=pkg.VGG19(compute_dtype="bf16", seed=1234))
+    assert T.use_side_stream
+    v_sd = O.vgg_standin_state_dict(1234, 1)
+
+    def batch():
+        return (torch.rand(B, 3, 96, 96) * 2 - 1, torch.rand(B, 3, 384, 384) * 2 - 1, [torch.rand(B, 1, 24, 24) for _ in range(3)])
+
+    lr0, hr0, n0 = batch()
+    T.capture_train_step(lr0.to(dev), hr0.to(dev), warmup=1, noise=[t.to(dev) for t in n0])
+    torch.cuda.synchronize()
+    assert len(T._graphs) == 1
+    g1 = {k: v.detach().cpu().clone() for k, v in T.generator.state_dict().items()}
+    d1 = {k: v.detach().cpu().clone() for k, v in T.discriminator.state_dict().items()}
+    g_state = _adam_state_for_oracle(T.optim_generator, [k for k, _ in T.generator.named_parameters()])
+    d_state = _adam_state_for_oracle(T.optim_discriminator, [k for k, _ in T.discriminator.named_parameters()])
+    assert g_state["step"] == 1 and d_state["step"] == 1
+    lr, hr, noise = batch()
+    got = T.graphed_train_step(lr.to(dev), hr.to(dev), noise=[t.to(dev) for t in noise])
+    torch.cuda.synchronize()
+    got = {k: float(v) for k, v in got.items()}
+    named_d = [("d." + k, p.grad.detach().cpu().clone()) for k, p in T.discriminator.named_parameters()]
+    named_g = [("g." + k, p.grad.detach().cpu().clone()) for k, p in T.generator.named_parameters()]
+    ref = {}
+    want = O.train_step(g1, d1, v_sd, lr, hr, noise, g_state, d_state, grads_out=ref, q=O.Q_BF16, chunk=4)
+    for k in want:
+        e = report("cfg2_b32_graph.bf16q.%s" % k, abs(got[k] - float(want[k])) / abs(float(want[k])))
+        assert e < STEPQ_LOSS, (k, got[k], float(want[k]))
+    bad = check_grads("cfg2_b32_graph.bf16q.grad", named_d, ref, t_tensor=STEPQ_D_GRAD, t_slope=STEPQ_SLOPE, t_cos=STEPQ_COS_D, t_norm=STEP_NORM)
+    bad += check_grads("cfg2_b32_graph.bf16q.grad", named_g, ref, t_tensor=STEPQ_G_GRAD, t_slope=STEPQ_SLOPE, t_cos=STEPQ_COS_G, t_norm=STEP_NORM)
+    assert not bad, bad
+    for model in (T.generator, T.discriminator):
+        for k, p in model.named_parameters():
+            assert torch.isfinite(p).all(), k
+
+
+# cfg #5 (BASELINE configs[4]) train-step gates: fp16 kernels against the PLAIN fp32 oracle, ~1.5x the values measured on the
+# MI355X (profiles/r04_parity_errors.log).
+CFG5_LOSS, CFG5_D_GRAD, CFG5_G_GRAD, CFG5_COS, CFG5_SLOPE = 2e-3, 0.5, 0.75, 0.98, 0.2
+
+
+def test_train_step_cfg5_three_stage_generator_f16(pkg):
+    """BASELINE configs[4] as a TRAINING iteration (trainer.py:171-196): 12 residual blocks, three pixel-shuffle stages
+    (128 -> 1024, batch 1), fp16 MFMA with the dynamic loss scale, the discriminator and a quarter-width VGG19 stand-in on the
+    1024^2 images: four losses and both backward passes against the fp32 oracle."""
+    dev = select("hip")
+    torch.manual_seed(10)
+    cfg = ns(experiment=ns(name="cfg5", seed=1234), generator=ns(n_filters=64, n_layers=12, n_upsample=3),
+             discriminator=ns(n_filters=64, n_layers=7),
+             training=ns(compiled=False, device=str(dev), log_iter=1, checkpoint_iter=10 ** 9, generator_lr=1e-4,
+                         discriminator_lr=1e-4, batch_size=1, compute_dtype="f16"))
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        T = pkg.Trainer(cfg, perceptual_network=pkg.VGG19(compute_dtype="f16", width_div=4, seed=1234))
+    g0 = {k: v.detach().cpu().clone() for k, v in T.generator.state_dict().items()}
+    d0 = {k: v.detach().cpu().clone() for k, v in T.discriminator.state_dict().items()}
+    v_sd = O.vgg_standin_state_dict(1234, 4)
+    lr, hr = torch.rand(1, 3, 128, 128) * 2 - 1, torch.rand(1, 3, 1024, 1024) * 2 - 1
+    noise = [torch.rand(1, 1, 64, 64) for _ in range(3)]
+    got = T.train_step(lr.to(dev), hr.to(dev), [n.to(dev) for n in noise])
+    torch.cuda.synchronize()
+    scale, skipped = T.loss_scale_state()
+    assert skipped == 0, (scale, skipped)          # the 2^20 start does not overflow at this size
+    # the arenas hold S x gradient (AdamW divides on the device): undo the scale for the comparison
+    inv = 1.0 / 1048576.0
+    named_d = [("d." + k, p.grad.detach().cpu() * inv) for k, p in T.discriminator.named_parameters()]
+    named_g = [("g." + k, p.grad.detach().cpu() * inv) for k, p in T.generator.named_parameters()]
+    ref = {}
+    want = O.train_step(g0, d0, v_sd, lr, hr, noise, {}, {}, grads_out=ref)
+    for k in want:
+        e = report("cfg5.f16.step.%s" % k, abs(float(got[k]) - float(want[k])) / abs(float(want[k])))
+        assert e < CFG5_LOSS, (k, float(got[k]), float(want[k]))
+    bad = check_grads("cfg5.f16.step.grad", named_d, ref, t_tensor=CFG5_D_GRAD, t_slope=CFG5_SLOPE, t_norm=STEP_NORM)
+    bad += check_grads("cfg5.f16.step.grad", named_g, ref, t_tensor=CFG5_G_GRAD, t_slope=CFG5_SLOPE, t_norm=STEP_NORM)
+    bad += check_grads("cfg5.f16.step.grad.all", named_d + named_g, ref, t_tensor=CFG5_G_GRAD, t_slope=CFG5_SLOPE, t_cos=CFG5_COS)
+    assert not bad, bad

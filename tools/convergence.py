@@ -144,6 +144,28 @@ def compare(results, iters, window=25, every=50):
     return rows, worst, worst_single
 
 
+def row_distances(row):
+    """Distances of the single runs of one `compare` row from the fp32 band, in half-widths (same floors as the median's)."""
+    mode, k, t, lo, hi, _v, _dist, vals = row
+    floor_rel, floor_abs = (0.0, 0.1 if k == "psnr" else 0.002) if k in ("psnr", "ssim") else (0.02, 1e-6)
+    mid = 0.5 * (lo + hi)
+    half = max(0.5 * (hi - lo), floor_rel * abs(mid), floor_abs)
+    return [abs(x - mid) / half for x in vals]
+
+
+def single_run_exits(rows):
+    """{mode: [(rows outside the band, rows, farthest distance) per seed]}."""
+    out = {}
+    for row in rows:
+        ds = row_distances(row)
+        per = out.setdefault(row[0], [[0, 0, 0.0] for _ in ds])
+        for i, d in enumerate(ds):
+            per[i][0] += d > 1.0
+            per[i][1] += 1
+            per[i][2] = max(per[i][2], d)
+    return {m: [tuple(x) for x in v] for m, v in out.items()}
+
+
 def main(iters=300, modes=("bf16", "f16"), out_json=None, log=print, seeds=(0, 1, 2)):
     pkg = importlib.import_module("fast-srgan_amd")
     pkg._lib.lib()
@@ -171,6 +193,11 @@ def main(iters=300, modes=("bf16", "f16"), out_json=None, log=print, seeds=(0, 1
         log("%-5s %-13s %5d   [%10.5f, %10.5f]   %10.5f   %6.2f     %s" % (mode, k, t, lo, hi, v, dist, "  ".join("%.5f" % x for x in vals)))
     for mode in worst:
         log("worst distance from the fp32 band, %s: median of %d runs %.2f half-widths, any single run %.2f" % (mode, len(seeds), worst[mode], worst_single[mode]))
+    # per SEED (round-3 verdict: the median hides a trajectory that leaves the band): how many of a mode's checkpoint rows each
+    # single run spends outside the fp32 band proper (distance > 1), and how far out it gets
+    for mode, per_seed in single_run_exits(rows).items():
+        for i, (n_out, n_rows, far) in enumerate(per_seed):
+            log("%s seed %d: outside the fp32 band at %d of %d checkpoints, at most %.2f half-widths out" % (mode, seeds[i], n_out, n_rows, far))
     for m in modes:
         for r in results[m]:
             if r.get("loss_scale"):
