@@ -949,6 +949,7 @@ int fsr_conv64_s2fwd_try(int dtype, ConvKArgs& a, int S, hipStream_t stream) {
   a.stats_tpi = a.tiles_x * a.tiles_y;
   a.stats_per = per;
   a.stats_P = (a.stats_tpi + per - 1) / per + 1;
+  if (a.stats && a.stats_P > a.stats_P_max) return fsr_fail(-3, "conv64: %d partial slots per image exceed the scratch buffer's %d", a.stats_P, a.stats_P_max);
   const int grid = (int)((ntiles + per - 1) / per);
   if (dtype == FSR_F16) {
     if (a.stats) hipLaunchKernelGGL((conv64_s2fwd_kernel<f16_t, true>), dim3(grid), dim3(NTHR64), LDS64S2F, stream, a);
@@ -1011,6 +1012,7 @@ int fsr_conv64_persistent_try(int dtype, ConvKArgs& a, int S, hipStream_t stream
   a.stats_tpi = a.tiles_x * a.tiles_y;
   a.stats_per = per;
   a.stats_P = (a.stats_tpi + per - 1) / per + 1;
+  if (a.stats && a.stats_P > a.stats_P_max) return fsr_fail(-3, "conv64: %d partial slots per image exceed the scratch buffer's %d", a.stats_P, a.stats_P_max);
   const int grid = (int)((ntiles + per - 1) / per) * nblk;
   if (dtype == FSR_F16) {
     if (thin) hipLaunchKernelGGL((conv64_thin_kernel<f16_t>), dim3(grid), dim3(NTHR64), LDS_THIN, stream, a);

@@ -681,6 +681,7 @@ static int launch_cfg(ConvKArgs& a, hipStream_t stream, ConvKArgs* more = nullpt
   }
   cls.n = nmore + 1;
   a.stats_P = a.tiles_x * a.tiles_y;   // one partial slot per tile of an image (one-tile workgroups)
+  if (a.stats && a.stats_P > a.stats_P_max) return fsr_fail(-3, "conv3x3: %d partial slots per image exceed the scratch buffer's %d", a.stats_P, a.stats_P_max);
   a.stats_tpi = a.stats_per = 0;
   const size_t lds = ((size_t)a.HH * a.HW * PITCHX + (DMA ? 2 * G * (size_t)BN * KC : (G == 1 ? 2 : G) * (size_t)BN * PITCHW)) * sizeof(T);
   auto kern = conv_igemm_kernel<T, TH, BN, WM, WN, KC, S, G, DMA>;
@@ -788,7 +789,7 @@ int fsr_conv_igemm_dispatch(int dtype, ConvKArgs& a, int S, hipStream_t stream) 
   if (const int rc = fsr_conv64_persistent_try(dtype, a, S, stream)) return rc < 0 ? rc : 0;
   // 64 -> 64 channel stride-2 forward (Discriminator block 0): persistent streaming kernel (conv64_persistent.hip)
   if (const int rc = fsr_conv64_s2fwd_try(dtype, a, S, stream)) return rc < 0 ? rc : 0;
-  // 128..512-channel stride-1 layers without statistics: 32x32x16 MFMA, both operands by LDS-DMA (conv_tall3.hip)
+  // 128..512-channel layers, stride 1 and the stride-2 forward: 32x32x16 MFMA, both operands by LDS-DMA (conv_tall3.hip)
   if (const int rc = fsr_conv_tall3_try(dtype, a, S, stream)) return rc < 0 ? rc : 0;
   if (dtype == FSR_BF16) return dispatch_T<bf16_t, 64, 32>(a, S, stream);
   if (dtype == FSR_F16) return dispatch_T<f16_t, 64, 32>(a, S, stream);

@@ -1,6 +1,6 @@
-// 3x3 stride-1 convolution for the 128..512-channel layers: persistent implicit GEMM on v_mfma_f32_32x32x16_{bf16,f16}
+// 3x3 convolution for the 128..512-channel layers: persistent implicit GEMM on v_mfma_f32_32x32x16_{bf16,f16}
 // with BOTH operands arriving by LDS-DMA.  (Round 3: replaces the 16x16x32 "tall" configuration of conv_igemm.hip on the
-// layers that dominate the GAN iteration.)
+// layers that dominate the GAN iteration.  Round 4: the stride-2 forward of the same layers, template parameter S = 2.)
 //
 // Replaces the torch.nn.Conv2d(k=3, p=1, stride 1) calls of the reference with 128 or more input channels and a
 // multiple of 128 output channels:
@@ -9,6 +9,8 @@
 //   /root/reference/model.py:160-177 (Discriminator 128->256 and 256->512 stride-1 blocks: forwards -- with the sums and
 //   sums of squares of their InstanceNorm, the STATS instantiation -- and data gradients).
 //   /root/reference/model.py:154-159 (Discriminator 64->128 block: its data gradient, 128 -> 64 channels, on 64-channel blocks).
+//   /root/reference/model.py:160-183, strides 2 at :162, :172, :182 (Discriminator 128->128 @192^2, 256->256 @96^2,
+//   512->512 @48^2: the stride-2 FORWARDS with their InstanceNorm sums, S = 2 below).
 //
 // Work decomposition
 //   tile      16 x 16 output pixels of one image x BN output channels (BN = 256: 8 waves, one workgroup per CU;
@@ -29,13 +31,34 @@
 //   issued after it overwrites.  With G = 3 that is one barrier per 48 MFMAs (1536 matrix-pipe cycles) per wave.
 // Output mapping: LDS filter row i of a 32-row block holds output channel 16*((i>>2)&1) + (i&3) + 4*(i>>3), so a lane's
 //   16 accumulator registers are 16 CONSECUTIVE channels of one pixel: two 16-byte stores per fragment pair.
+//
+// Stride 2 (S = 2): output pixel (oy, ox) reads input (2 oy + ky - 1, 2 ox + kx - 1).  Split by the PARITY of (ky, kx) the
+//   input of a tile is four planes, and inside a plane tap (ky, kx) reads position (oy + (ky >> 1), ox + (kx >> 1)): a
+//   stride-1 access with offsets 0 / 1 -- the fragment read and the swizzle of the stride-1 kernel, unchanged.  The LDS-DMA
+//   GATHERS the planes (a lane's source pixel is 2 hx + px, 2 hy + py of the tile's 17 x 33 input window: no layout change in
+//   HBM): plane (0,0) serves taps (0,0) (0,2) (2,0) (2,2), plane (0,1) taps (0,1) (2,1), plane (1,0) taps (1,0) (1,2),
+//   plane (1,1) tap (1,1) -- the nine stages of a 32-channel chunk walk the planes in that order.  An 8 x 16-output tile
+//   keeps each plane in its OWN buffer (9 x 18 pixels x 64 B = 11 pieces; 4 x 11 KB + the 32 KB filter ring = 79 KB: two
+//   workgroups per CU), refilled for the next chunk as soon as its last tap has been read: the 44 pieces of a chunk are dealt
+//   round-robin over the four waves (11 each, so every wave issues the same number of pieces per stage and the counted
+//   vmcnt waits stay compile-time constants) and issued on a fixed schedule, one or two per stage, each at least three
+//   stages before its plane's first use.  Four times the input pixels per output pixel make this form DMA-issue-heavy (3.2
+//   pieces per 8 MFMAs and wave against 2.7 per 16 at stride 1); that, not LDS capacity, is what bounds it.
 #include "fsr_common.h"
 #include "fsr_conv_args.h"
 #include "fsr_host.h"
 
 #include <stdlib.h>
 
+// Ablation builds (tools/build_variant.sh -DFSR_ABL3=<mask>; results WRONG on purpose, the product library is built with 0):
+//   1 no stores   2 no DMA   4 no main loop   16 lgkmcnt(0) before every barrier   32 no barriers   64 no DMA waits
+#ifndef FSR_ABL3
+#define FSR_ABL3 0
+#endif
+
 namespace {
+
+constexpr int T3_ABL = FSR_ABL3;
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
@@ -51,6 +74,11 @@ template <> struct Mfma32<f16_t> {
   }
 };
 
+// stride 2: the tap served by position p of a chunk's nine stages (plane by plane: (0,0) x 4, (0,1) x 2, (1,0) x 2, (1,1))
+constexpr int T3_S2_TAP[9] = {0, 2, 6, 8, 1, 7, 3, 5, 4};
+template <int S> constexpr int t3_tap_at(int pos) { return S == 2 ? T3_S2_TAP[pos] : pos; }
+constexpr int t3_plane_of_tap(int t) { return ((t / 3) & 1) * 2 + ((t % 3) & 1); }
+
 constexpr int T3_P = 18;                           // halo columns (16 outputs + the 3 x 3 footprint)
 constexpr int T3_PIXB = 64, T3_ROWB = T3_P * T3_PIXB;   // bytes per halo pixel / halo row
 // A tile is TH = 4 * MB output rows x 16 columns (MB = pixel fragments of two rows per wave: 4, 3 or 2 -> 16, 12, 8 rows)
@@ -58,7 +86,12 @@ template <int MB> constexpr int t3_hunits() { return (4 * MB + 2) * T3_P * 4; } 
 template <int MB> constexpr int t3_nhp() { return (t3_hunits<MB>() + 63) / 64; }         // DMA pieces per halo chunk
 template <int MB> constexpr int t3_halo_bytes() { return t3_nhp<MB>() * 1024; }
 
-template <int BN, int G, int NSLOT, int MB> constexpr int t3_lds_bytes() { return 2 * t3_halo_bytes<MB>() + NSLOT * G * BN * 64 + 2 * 1024; }   // + two bias pieces
+// stride 2: one buffer per parity plane, (TH + 1) rows x 18 columns (17 used) of 64-byte pixels, whole DMA pieces
+template <int MB> constexpr int t3_s2_plane_units() { return (4 * MB + 1) * T3_P * 4; }
+template <int MB> constexpr int t3_s2_npp() { return (t3_s2_plane_units<MB>() + 63) / 64; }       // pieces per plane (11)
+template <int MB, int S> constexpr int t3_halo_total() { return S == 2 ? 4 * t3_s2_npp<MB>() * 1024 : 2 * t3_halo_bytes<MB>(); }
+
+template <int BN, int G, int NSLOT, int MB, int S = 1> constexpr int t3_lds_bytes() { return t3_halo_total<MB, S>() + NSLOT * G * BN * 64 + 2 * 1024; }   // + two bias pieces
 
 __device__ __forceinline__ int t3_swz_row(int R) { return (R >> 2) & 3; }
 __device__ __forceinline__ int t3_swz_col(int x) { return (x >> 1) & 3; }
@@ -68,16 +101,20 @@ __device__ __forceinline__ V t3_lds_read(const char* smem, unsigned off) {
   return *FSR_LDS_PTR(const V, smem + off);
 }
 
-template <typename T, int BN, int NW, int G, int NSLOT, int MB, int NA = 2, bool STATS = false>
-__global__ __launch_bounds__(NW * 64, NA == 4 ? 1 : 2) void conv_tall3_kernel(const ConvKArgs a) {
-  // a wave owns 32 * MB pixels x 32 * NA channels.  NA = 2: two waves per SIMD (256 registers each); NA = 4 (with MB = 4: the
-  // 128 x 128 wave tile, 256 accumulator registers in the AGPR half of the file): ONE 512-register wave per SIMD, 8 fragment
-  // reads per 16 MFMAs instead of 6 per 8, the 256 x 256 workgroup tile from four waves
+template <typename T, int BN, int NW, int G, int NSLOT, int MB, int NA = 2, bool STATS = false, int S = 1>
+__global__ __launch_bounds__(NW * 64, 2) void conv_tall3_kernel(const ConvKArgs a) {
+  // a wave owns 32 * MB pixels x 32 * NA channels; two waves per SIMD (256 registers each), from two workgroups.  (The
+  // 128 x 128 wave tile with 256 accumulators in AGPRs and ONE 512-register wave per SIMD was built and measured in round 3 --
+  // 620..800 TFLOP/s against 1130..1200, profiles/r03_conv_tall3_one_wave_per_simd.txt -- and removed.)
   static_assert(BN % (NA * 32) == 0 && NW == 2 * (BN / (NA * 32)), "two pixel-row groups x BN / (32 NA) channel groups of waves");
-  static_assert(NA == 1 || NA == 2 || NA == 4, "1 (64-channel blocks), 2 or 4 filter fragments per wave");
+  static_assert(NA == 1 || NA == 2, "1 (64-channel blocks) or 2 filter fragments per wave");
   static_assert(MB >= 2 && MB <= 4, "8, 12 or 16 tile rows");
+  static_assert(S == 1 || (S == 2 && G == 1 && NSLOT == 4 && NW == 4 && MB == 2), "stride 2: the 8 x 16-output tile, one-tap stages, four waves");
   constexpr int TH = 4 * MB;                       // tile rows
   constexpr int T3_HUNITS = t3_hunits<MB>(), T3_NHP = t3_nhp<MB>(), T3_HALO_BYTES = t3_halo_bytes<MB>();
+  constexpr int HALO_TOTAL = t3_halo_total<MB, S>();                                        // bytes of all halo buffers
+  constexpr int S2_PUNITS = t3_s2_plane_units<MB>(), S2_NPP = t3_s2_npp<MB>();              // stride 2: units / pieces of one plane
+  static_assert(S == 1 || (4 * S2_NPP) % NW == 0, "stride 2: the planes' pieces divide evenly over the waves");
   constexpr int NM = NA * MB;                      // MFMAs per substep (NA filter x MB pixel fragments)
   constexpr int NR = NA + MB;                      // fragment reads per substep
   static_assert(9 % G == 0 && (9 / G) % NSLOT == 1, "stage s lives in slot s % NSLOT == (chunk + stage in chunk) % NSLOT");
@@ -86,11 +123,12 @@ __global__ __launch_bounds__(NW * 64, NA == 4 ? 1 : 2) void conv_tall3_kernel(co
   constexpr int NQ = 2 * G;                        // substeps per stage
   constexpr int D = NSLOT - 1;                     // the DMA runs D stages ahead
   constexpr int FP = BN / 16 / NW;                 // filter pieces per tap and wave (2)
-  constexpr int HPW = (T3_NHP + NW - 1) / NW;      // halo pieces per chunk and wave
+  constexpr int HPW = S == 2 ? 4 * S2_NPP / NW : (T3_NHP + NW - 1) / NW;      // halo pieces per chunk and wave (stride 2: 11, dealt round-robin)
   constexpr int SLOT_BYTES = G * BN * 64;
   constexpr int HPS = (HPW + SPC - 1) / SPC > 1 ? (HPW + SPC - 1) / SPC : 1;   // halo pieces a wave issues per stage
-  static_assert((HPW + HPS - 1) / HPS + D <= SPC + 1, "halo pieces must land before their chunk starts");
-  static_assert(FP >= 1 && FP <= NM && HPS + 1 <= NM, "one DMA piece per MFMA slot at most");
+  static_assert(S == 2 || (HPW + HPS - 1) / HPS + D <= SPC + 1, "halo pieces must land before their chunk starts");
+  static_assert(FP >= 1 && FP <= NM && (S == 2 || HPS + 1 <= NM), "one DMA piece per MFMA slot at most");
+  static_assert(S == 1 || (NM - FP >= 2 && HPW == 11 && D == 3), "stride 2: MFMA slots 0 and 1 of a stage's first substep carry its halo pieces (schedule below)");
 
   HIP_DYNAMIC_SHARED(char, smem)
   const int tid = threadIdx.x, lane = tid & 63;
@@ -99,7 +137,7 @@ __global__ __launch_bounds__(NW * 64, NA == 4 ? 1 : 2) void conv_tall3_kernel(co
   const int l31 = lane & 31, hi = lane >> 5, l15 = lane & 15, lrow = (lane >> 4) & 1;
 
   const fsr_lds_addr_t halo_addr = FSR_LDS_ADDR(smem);
-  const fsr_lds_addr_t ring_addr = halo_addr + 2 * T3_HALO_BYTES;
+  const fsr_lds_addr_t ring_addr = halo_addr + HALO_TOTAL;
   const fsr_buf_t in_buf = fsr_make_buf(a.in, (unsigned)((size_t)a.N * a.IH * a.IW * a.Cin * sizeof(T)));
   const fsr_buf_t w_buf = fsr_make_buf(a.wpk, (unsigned)((size_t)9 * a.CoutPad * a.Cin * sizeof(T)));
   const int nchunks = a.Cin >> 5;
@@ -110,9 +148,10 @@ __global__ __launch_bounds__(NW * 64, NA == 4 ? 1 : 2) void conv_tall3_kernel(co
   {
     const int R = wco * (NA * 32) + l31;
 #pragma unroll
-    for (int j = 0; j < 2; ++j) aoff[j] = (unsigned)(2 * T3_HALO_BYTES + R * 64 + (((2 * j + hi) ^ t3_swz_row(R)) << 4));
+    for (int j = 0; j < 2; ++j) aoff[j] = (unsigned)(HALO_TOTAL + R * 64 + (((2 * j + hi) ^ t3_swz_row(R)) << 4));
   }
   // pixel fragment m of tap (ky, kx), k half j, halo buffer hb: hb*HALO + (2m + ky)*ROWB + boff[kx][j]
+  // (stride 2: plane*PLANE + (2m + (ky >> 1))*ROWB + boff[kx >> 1][j] -- the same per-lane bases)
   unsigned boff[3][2];
 #pragma unroll
   for (int kx = 0; kx < 3; ++kx)
@@ -147,6 +186,25 @@ __global__ __launch_bounds__(NW * 64, NA == 4 ? 1 : 2) void conv_tall3_kernel(co
     tc.gy0 = ty * TH;
     tc.gx0 = tx * 16;
     ws = (unsigned)(tc.nb * BN * a.Cin * (int)sizeof(T));
+    if constexpr (S == 2) {
+      // piece g = wave + 4 k of the chunk's 44: plane g / 11 = (py, px), piece g % 11 of that plane; halo pixel (hy, hx) of the
+      // plane is input pixel (2 gy0 - 1 + 2 hy + py, 2 gx0 - 1 + 2 hx + px); rows beyond TH - py / columns beyond 16 - px are
+      // never read (written as zeros like the image border)
+#pragma unroll
+      for (int k = 0; k < HPW; ++k) {
+        const int g = wave + k * NW;
+        const int plane = g / S2_NPP, py = plane >> 1, px = plane & 1;
+        const int U = (g - plane * S2_NPP) * 64 + lane;
+        const int hp = U >> 2, ul = U & 3;
+        const int hy = hp / T3_P, hx = hp - hy * T3_P;
+        const int iy = 2 * tc.gy0 - 1 + 2 * hy + py, ix = 2 * tc.gx0 - 1 + 2 * hx + px;
+        unsigned o = ~0u;
+        if (U < S2_PUNITS && hy <= TH - py && hx <= 16 - px && iy >= 0 && iy < a.IH && ix >= 0 && ix < a.IW)
+          o = (unsigned)((((tc.img * a.IH + iy) * a.IW + ix) * a.Cin + ((ul ^ t3_swz_col(hx)) << 3)) * (int)sizeof(T));
+        hv[k] = o;
+      }
+      return;
+    }
 #pragma unroll
     for (int k = 0; k < HPW; ++k) {
       const int U = (wave + k * NW) * 64 + lane;
@@ -161,12 +219,19 @@ __global__ __launch_bounds__(NW * 64, NA == 4 ? 1 : 2) void conv_tall3_kernel(co
   };
   // DMA pieces.  Halo piece k of tile-chunk c -> halo buffer (global chunk parity); filter pieces of tap t of chunk c -> ring
   auto dma_halo = [&](const unsigned (&hv)[HPW], int c, int k, unsigned par) {
-    if (wave + k * NW < T3_NHP && !(a.t3_dbg & 2))
-      FSR_BLDS16(in_buf, hv[k], (unsigned)(c * 64), halo_addr + (fsr_lds_addr_t)(par * T3_HALO_BYTES + (wave + k * NW) * 1024));
+    if constexpr (!(T3_ABL & 2))
+      if (wave + k * NW < T3_NHP)
+        FSR_BLDS16(in_buf, hv[k], (unsigned)(c * 64), halo_addr + (fsr_lds_addr_t)(par * T3_HALO_BYTES + (wave + k * NW) * 1024));
   };
-  auto dma_filter = [&](unsigned ws, int c, int t, int k, unsigned slot_tap_off) {
-    if (!(a.t3_dbg & 2)) FSR_BLDS16(w_buf, wvoff[k], a.t3_woff[t] + ws + (unsigned)(c * 64),
-               ring_addr + (fsr_lds_addr_t)(slot_tap_off + (wave + k * NW) * 1024));
+  // stride 2: piece wave + 4 k of chunk c's four planes (the planes lie back to back: piece g goes to g * 1 KB)
+  auto dma_halo2 = [&](const unsigned (&hv)[HPW], int c, int k) {
+    if constexpr (!(T3_ABL & 2))
+      FSR_BLDS16(in_buf, hv[k], (unsigned)(c * 64), halo_addr + (fsr_lds_addr_t)((wave + k * NW) * 1024));
+  };
+  // filter pieces of the tap at position `pos` of chunk c's stages (stride 1: the tap itself; stride 2: T3_S2_TAP[pos])
+  auto dma_filter = [&](unsigned ws, int c, unsigned woff_tap, int k, unsigned slot_tap_off) {
+    if constexpr (!(T3_ABL & 2))
+      FSR_BLDS16(w_buf, wvoff[k], woff_tap + ws + (unsigned)(c * 64), ring_addr + (fsr_lds_addr_t)(slot_tap_off + (wave + k * NW) * 1024));
   };
   // The bias of a tile's channel block comes by DMA as well (one piece of BN floats, wave 0, double buffered by tile parity):
   // an ordinary global load next to the epilogue's stores would make hipcc drain vmcnt -- the whole DMA pipeline -- per tile.
@@ -174,7 +239,7 @@ __global__ __launch_bounds__(NW * 64, NA == 4 ? 1 : 2) void conv_tall3_kernel(co
   const fsr_lds_addr_t bias_addr = ring_addr + NSLOT * SLOT_BYTES;
   const fsr_buf_t bias_buf = fsr_make_buf(a.bias, a.bias ? (unsigned)(a.Cout * 4) : 0u);
   auto dma_bias = [&](int nbk, unsigned par) {
-    if (wave == 0 && a.bias && !(a.t3_dbg & 2)) {
+    if (!(T3_ABL & 2) && wave == 0 && a.bias) {
       const unsigned vo = lane * 16 < BIAS_BYTES ? (unsigned)(nbk * BIAS_BYTES + lane * 16) : ~0u;
       FSR_BLDS16(bias_buf, vo, 0u, bias_addr + (fsr_lds_addr_t)(par * 1024));
     }
@@ -188,7 +253,7 @@ __global__ __launch_bounds__(NW * 64, NA == 4 ? 1 : 2) void conv_tall3_kernel(co
 #pragma unroll
       for (int e = 0; e < 16; ++e) b0[e] = 0.f;
       if (a.bias) {
-        const unsigned bo = (unsigned)(2 * T3_HALO_BYTES + NSLOT * SLOT_BYTES) + par * 1024 + (unsigned)((wco * (NA * 32) + n * 32 + hi * 16) * 4);
+        const unsigned bo = (unsigned)(HALO_TOTAL + NSLOT * SLOT_BYTES) + par * 1024 + (unsigned)((wco * (NA * 32) + n * 32 + hi * 16) * 4);
 #pragma unroll
         for (int e4 = 0; e4 < 4; ++e4) {
           const f32x4 b = t3_lds_read<f32x4>(smem, bo + 16 * e4);
@@ -205,15 +270,17 @@ __global__ __launch_bounds__(NW * 64, NA == 4 ? 1 : 2) void conv_tall3_kernel(co
   // reads of substep (tap t = ky*3+kx in ring position g of its stage, k half j): fragment r in the MFMA's need order
   // a0 b0 .. b(MB-1) a1 .. a(NA-1)
   auto read_frag = [&](auto rc, auto bufc, auto tc, auto gc_, auto jc, unsigned sl, unsigned hb) {
-    constexpr int r = decltype(rc)::value, buf = decltype(bufc)::value, t = decltype(tc)::value, g = decltype(gc_)::value,
+    constexpr int r = decltype(rc)::value, buf = decltype(bufc)::value, t = t3_tap_at<S>(decltype(tc)::value), g = decltype(gc_)::value,
                   j = decltype(jc)::value;
-    constexpr int ky = t / 3, kx = t % 3;
+    // stride 2: the tap's parity plane (its own buffer) and its offset inside the plane
+    constexpr int ky = S == 2 ? (t / 3) >> 1 : t / 3, kx = S == 2 ? (t % 3) >> 1 : t % 3;
+    constexpr unsigned plane_off = S == 2 ? (unsigned)(t3_plane_of_tap(t) * S2_NPP * 1024) : 0u;
     if constexpr (r == 0 || r > MB) {      // a0 first, a1 .. a(NA-1) after the pixel fragments
       constexpr int n = r == 0 ? 0 : r - MB;
       fa[buf][n] = t3_lds_read<s16x8>(smem, aoff[j] + sl + (unsigned)(g * BN * 64 + n * 2048));
     } else {
       constexpr int m = r - 1;
-      fb[buf][m] = t3_lds_read<s16x8>(smem, boff[kx][j] + hb + (unsigned)((2 * m + ky) * T3_ROWB));
+      fb[buf][m] = t3_lds_read<s16x8>(smem, boff[kx][j] + hb + plane_off + (unsigned)((2 * m + ky) * T3_ROWB));
     }
   };
 
@@ -233,15 +300,21 @@ __global__ __launch_bounds__(NW * 64, NA == 4 ? 1 : 2) void conv_tall3_kernel(co
   int gc = 0;                      // global chunk counter of this workgroup (halo buffer = gc & 1, ring slot = (gc + si) % NSLOT)
   unsigned tpar = 0;               // tile parity (bias buffer)
   dma_bias(cur.nb, tpar);
+  if constexpr (S == 2) {
+    // what the steady-state schedule issues before a chunk starts: its pieces 0..4 (plane (0,0) and the head of plane (0,1))
 #pragma unroll
-  for (int k = 0; k < HPW; ++k) dma_halo(hv_cur, 0, k, 0u);
+    for (int k = 0; k < 5; ++k) dma_halo2(hv_cur, 0, k);
+  } else {
+#pragma unroll
+    for (int k = 0; k < HPW; ++k) dma_halo(hv_cur, 0, k, 0u);
+  }
   static_for<0, D>([&](auto sc) {
     constexpr int s = decltype(sc)::value;
     static_assert(D < SPC, "the first D stages lie in chunk 0");
     static_for<0, G>([&](auto gc_) {
       constexpr int g = decltype(gc_)::value;
 #pragma unroll
-      for (int k = 0; k < FP; ++k) dma_filter(ws_cur, 0, s * G + g, k, slot_of(0, s) + g * BN * 64);
+      for (int k = 0; k < FP; ++k) dma_filter(ws_cur, 0, a.t3_woff[t3_tap_at<S>(s * G + g)], k, slot_of(0, s) + g * BN * 64);
     });
   });
   int next = tile + nround;
@@ -254,9 +327,10 @@ __global__ __launch_bounds__(NW * 64, NA == 4 ? 1 : 2) void conv_tall3_kernel(co
               std::integral_constant<int, 0>{}, slot_of(0, 0), 0u);
   });
   int issued_prev = 1;             // did the preceding stage issue filter pieces (counted waits, D = 3)
+  bool full_prev = true;           // stride 2: did the preceding stage issue its complete static set of pieces
 
   for (;;) {
-    for (int c = 0; c < ((a.t3_dbg & 4) ? 0 : nchunks); ++c, ++gc) {
+    for (int c = 0; c < ((T3_ABL & 4) ? 0 : nchunks); ++c, ++gc) {
       const bool last = c + 1 == nchunks;
       if (last && has_nxt) {         // from here on the DMA feeds the next tile
         setup(logical(next), nxt, hv_nxt, ws_nxt);
@@ -265,7 +339,7 @@ __global__ __launch_bounds__(NW * 64, NA == 4 ? 1 : 2) void conv_tall3_kernel(co
       static_for<0, SPC>([&](auto sic) {
         constexpr int si = decltype(sic)::value;
         const unsigned sl = slot_of(gc, si);
-        const unsigned hb = (unsigned)((gc & 1) * T3_HALO_BYTES);
+        const unsigned hb = S == 2 ? 0u : (unsigned)((gc & 1) * T3_HALO_BYTES);
         // the stage whose pieces this stage issues: D stages ahead, possibly in the next tile
         constexpr int siD = (si + D) % SPC, dcD = (si + D) / SPC;
         const bool crossD = c + dcD >= nchunks;
@@ -277,7 +351,10 @@ __global__ __launch_bounds__(NW * 64, NA == 4 ? 1 : 2) void conv_tall3_kernel(co
         constexpr int siN = (si + 1) % SPC, dcN = (si + 1) / SPC;
         const bool has_next_stage = (c + dcN < nchunks) || has_nxt;
         const unsigned slN = slot_of(gc + dcN, siN);
-        const unsigned hbN = (unsigned)(((gc + dcN) & 1) * T3_HALO_BYTES);
+        const unsigned hbN = S == 2 ? 0u : (unsigned)(((gc + dcN) & 1) * T3_HALO_BYTES);
+        // stride 2: this stage's pieces are its FP filter pieces + one halo piece (+ a second one in stages 4, 5), all issued
+        // in its first substep; the set is complete when the filter stage ahead exists and (stages 4..8) a next chunk does
+        const bool full_this = S == 2 ? (issue && (si < 4 || !last || has_nxt)) : true;
 
         static_for<0, NQ>([&](auto qc) {
           constexpr int q = decltype(qc)::value;
@@ -286,8 +363,16 @@ __global__ __launch_bounds__(NW * 64, NA == 4 ? 1 : 2) void conv_tall3_kernel(co
             // publish the next stage: this wave's pieces of stage s+1 have landed when at most the pieces of the D-1 younger
             // stages are outstanding.  Loads retire in order, so halo / bias pieces and the previous tile's stores in the
             // queue can only make the wait longer, never shorter.
-            if (a.t3_dbg & 64) {
+            if constexpr ((T3_ABL & 64) != 0) {
               // EXPERIMENT (wrong results): no wait for the DMA
+            } else if constexpr (S == 2) {
+              // everything issued two or more stages ago has landed when at most the pieces of the previous and of this stage
+              // are outstanding (a stage issues all its pieces in its first substep, i.e. before this wait): 3 per stage, 4 in
+              // stages 4 and 5.  A stage that issued less (the last tile's end) makes the count meaningless: wait for all.
+              constexpr int sp = (si + SPC - 1) % SPC;
+              constexpr int allowed = FP * G + 1 + (sp == 4 || sp == 5 ? 1 : 0) + FP * G + 1 + (si == 4 || si == 5 ? 1 : 0);
+              if (full_prev && full_this) FSR_WAIT_VM(allowed);
+              else FSR_WAIT_VM(0);
             } else if constexpr (D == 1) {
               FSR_WAIT_VM(0);
             } else {
@@ -297,8 +382,8 @@ __global__ __launch_bounds__(NW * 64, NA == 4 ? 1 : 2) void conv_tall3_kernel(co
               else if (young == 1) FSR_WAIT_VM(G * FP);
               else FSR_WAIT_VM(2 * G * FP);
             }
-            if (a.t3_dbg & 16) FSR_WAIT_LGKM0();   // (strict form; the reads of a slot are >= 400 cycles older than any DMA into it)
-            if (!(a.t3_dbg & 32)) FSR_BARRIER();   // (EXPERIMENT bit 32: no barrier, wrong results)
+            if constexpr ((T3_ABL & 16) != 0) FSR_WAIT_LGKM0();   // (strict form; the reads of a slot are >= 400 cycles older than any DMA into it)
+            if constexpr (!(T3_ABL & 32)) FSR_BARRIER();          // (EXPERIMENT bit 32: no barrier, wrong results)
           }
           static_for<0, NM>([&](auto ic) {
             constexpr int i = decltype(ic)::value;
@@ -320,18 +405,29 @@ __global__ __launch_bounds__(NW * 64, NA == 4 ? 1 : 2) void conv_tall3_kernel(co
             next_frag(ic);                                             // one read per MFMA slot ...
             next_frag(std::integral_constant<int, i + NM>{});           // ... two where a substep has more reads than MFMAs (NA = 1)
             // DMA pieces of stage s+D: the halo piece first (the likeliest HBM miss), then two filter pieces per substep
-            if constexpr (q == 0 && i >= 1 && i <= HPS && si * HPS + (i - 1) < HPW) {
+            if constexpr (S == 2) {
+              // halo schedule of stride 2 (piece k of a chunk = piece wave + 4 k of its 44; every piece is issued >= 3 stages
+              // before its plane's first read and after that plane's last read of the previous chunk):
+              //   stage    0  1  2  3  4  5        this chunk's pieces 5 .. 10   (planes (0,1) tail, (1,0), (1,1))
+              //   stage    4  5  6  7  8           the NEXT chunk's pieces 0 .. 4 (plane (0,0), head of (0,1))
+              if constexpr (q == 0 && i == 1 && si <= 5) dma_halo2(hv_cur, c, si + 5);
+              if constexpr (q == 0 && i == (si <= 5 ? 0 : 1) && si >= 4) {
+                if (!last) dma_halo2(hv_cur, c + 1, si - 4);
+                else if (has_nxt) dma_halo2(hv_nxt, 0, si - 4);
+              }
+            } else if constexpr (q == 0 && i >= 1 && i <= HPS && si * HPS + (i - 1) < HPW) {
               constexpr int hk = si * HPS + (i - 1);
               if (!last) dma_halo(hv_cur, c + 1, hk, (unsigned)((gc + 1) & 1));
               else if (has_nxt) dma_halo(hv_nxt, 0, hk, (unsigned)((gc + 1) & 1));
             }
             if constexpr (q < G && i >= NM - FP) {
-              if (issue) dma_filter(wsD, cD, siD * G + q, i - (NM - FP), slD + q * BN * 64);
+              if (issue) dma_filter(wsD, cD, a.t3_woff[t3_tap_at<S>(siD * G + q)], i - (NM - FP), slD + q * BN * 64);
             }
             __builtin_amdgcn_sched_barrier(0);
           });
         });
         issued_prev = issue ? 1 : 0;
+        full_prev = full_this;
       });
     }
 
@@ -369,7 +465,7 @@ __global__ __launch_bounds__(NW * 64, NA == 4 ? 1 : 2) void conv_tall3_kernel(co
               x = fmaxf(x, __shfl_xor(x, 1, 64));
               v[e] = activate(x);
             }
-            if (ok && lrow == 0 && !(l15 & 1) && !(a.t3_dbg & 1)) {
+            if (!(T3_ABL & 1) && ok && lrow == 0 && !(l15 & 1)) {
               const unsigned off = (unsigned)((oimg * (a.FOH >> 1) + (gy >> 1)) * (a.FOW >> 1) + (gx >> 1)) * (unsigned)a.Cout + (unsigned)co;
               u32x4 p0, p1;
 #pragma unroll
@@ -380,7 +476,7 @@ __global__ __launch_bounds__(NW * 64, NA == 4 ? 1 : 2) void conv_tall3_kernel(co
               *(u32x4*)(outp + off) = p0;
               *(u32x4*)(outp + off + 8) = p1;
             }
-          } else if (ok && !(a.t3_dbg & 1)) {
+          } else if (!(T3_ABL & 1) && ok) {
             const unsigned off = (unsigned)((oimg * a.FOH + gy) * a.FOW + gx) * (unsigned)a.Cout + (unsigned)co;
 
             if (maskp) {   // fused activation backward of the producing layer: dz = dx * act'(y), y = the saved forward input
@@ -487,16 +583,9 @@ __global__ __launch_bounds__(NW * 64, NA == 4 ? 1 : 2) void conv_tall3_kernel(co
   }
 }
 
-int t3_mode() {
-  // FSR_TALL3: 0 = off (A/B against conv_igemm.hip); 1 (default) = on, 4-wave workgroups of 256 px x 128 channels, two per
-  // CU; 3 = the 8-wave 256 px x 256 channel workgroup (one per CU, persistent) where Cout allows it.  Measured per layer:
-  // the 4-wave form wins on every benched shape but one (profiles/r03_conv_tall3_ab.txt).  Bit 4: the one-wave-per-SIMD form;
-  // bit 8: no 64-channel block (Cout = 64 launches stay on conv_igemm.hip).
-  const char* e = getenv("FSR_TALL3");
-  return e ? atoi(e) : 1;
-}
-
 int t3_cus() {
+  // FSR_PERSIST_CUS=<n> (tests): number of CUs the persistent walk is sized for -- few, so that every workgroup walks several
+  // tiles and the DMA stream runs on across tile boundaries.  Read per launch (the tests change it between launches).
   if (const char* e = getenv("FSR_PERSIST_CUS")) {
     const int v = atoi(e);
     if (v > 0) return v;
@@ -511,31 +600,33 @@ int t3_cus() {
   return cus;
 }
 
-template <typename T, int BN, int NW, int G, int NSLOT, int MB, int NA = 2, bool STATS = false>
+template <typename T, int BN, int NW, int G, int NSLOT, int MB, int NA = 2, bool STATS = false, int S = 1>
 int t3_launch(ConvKArgs& a, int wg_per_cu, hipStream_t stream) {
-  auto kern = conv_tall3_kernel<T, BN, NW, G, NSLOT, MB, NA, STATS>;
-  if (STATS) {   // one partial slot per tile and pixel-row group of waves
-    a.stats_P = a.tiles_x * a.tiles_y * (NW / (BN / (NA * 32)));
-    a.stats_tpi = a.stats_per = 0;
-  }
-  constexpr int lds = t3_lds_bytes<BN, G, NSLOT, MB>();
+  auto kern = conv_tall3_kernel<T, BN, NW, G, NSLOT, MB, NA, STATS, S>;
+  constexpr int lds = t3_lds_bytes<BN, G, NSLOT, MB, S>();
   static bool attr_set = false;
   if (!attr_set) {
     (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     attr_set = true;
   }
-  a.nblk_n = a.Cout / BN;
-  const long long ntiles = (long long)a.tiles_x * a.tiles_y * a.N * a.nblk_n;
+  // nothing of `a` is written before the launch is certain (a refused shape falls through to conv_igemm.hip with `a` intact)
+  const int nblk_n = a.Cout / BN;
+  const long long ntiles = (long long)a.tiles_x * a.tiles_y * a.N * nblk_n;
   if (ntiles <= 0 || ntiles > 0x7fffffffLL) return 0;
+  if (STATS) {   // one partial slot per tile and pixel-row group of waves; the caller's scratch holds stats_P_max of them
+    const long long slots = (long long)a.tiles_x * a.tiles_y * (NW / (BN / (NA * 32)));
+    if (slots > a.stats_P_max) return 0;
+    a.stats_P = (int)slots;
+    a.stats_tpi = a.stats_per = 0;
+  }
+  a.nblk_n = nblk_n;
   a.t3_ntiles = (int)ntiles;
-  a.t3_dbg = getenv("FSR_T3_DBG") ? atoi(getenv("FSR_T3_DBG")) : 0;
-  // persistent tile walk, wg_per_cu workgroups per CU; FSR_T3_PERSIST=0 launches one workgroup per tile instead (A/B: the
-  // hardware dispatcher balances better, but every tile then pays a cold prologue)
-  static const bool persist = !(getenv("FSR_T3_PERSIST") && atoi(getenv("FSR_T3_PERSIST")) == 0);
-  long long grid = (long long)t3_cus() * wg_per_cu;
-  if (grid > ntiles || !persist) grid = ntiles;
+  long long grid = (long long)t3_cus() * wg_per_cu;     // persistent tile walk, wg_per_cu workgroups per CU
+  if (grid > ntiles) grid = ntiles;
   hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(NW * 64), lds, stream, a);
-  fsr_note_kernel(STATS ? "conv_tall3_kernel<%s,%d,%d,%d,%d,%d,%d,stats>" : "conv_tall3_kernel<%s,%d,%d,%d,%d,%d,%d>", std::is_same<T, f16_t>::value ? "f16" : "bf16", BN, NW, G, NSLOT, MB, NA);
+  fsr_note_kernel(S == 2 ? (STATS ? "conv_tall3_kernel<%s,%d,%d,%d,%d,%d,%d,stats,s2>" : "conv_tall3_kernel<%s,%d,%d,%d,%d,%d,%d,s2>")
+                         : (STATS ? "conv_tall3_kernel<%s,%d,%d,%d,%d,%d,%d,stats>" : "conv_tall3_kernel<%s,%d,%d,%d,%d,%d,%d>"),
+                  std::is_same<T, f16_t>::value ? "f16" : "bf16", BN, NW, G, NSLOT, MB, NA);
   const int rc = fsr_check_launch("conv_tall3_kernel");
   return rc ? rc : 1;
 }
@@ -544,22 +635,25 @@ int t3_launch(ConvKArgs& a, int wg_per_cu, hipStream_t stream) {
 
 // 1 = launched, 0 = not this kernel's shape (the caller falls through to conv_igemm.hip), < 0 = error.
 int fsr_conv_tall3_try(int dtype, ConvKArgs& a, int S, hipStream_t stream) {
-  const int mode = t3_mode();
-  if (mode == 0 || (dtype != FSR_BF16 && dtype != FSR_F16) || S != 1 || a.ntaps != 9) return 0;
+  if ((dtype != FSR_BF16 && dtype != FSR_F16) || (S != 1 && S != 2) || a.ntaps != 9) return 0;
+#ifdef FSR_NO_T3S2     // A/B builds (tools/build_variant.sh): stride-2 forwards stay on conv_igemm.hip
+  if (S == 2) return 0;
+#endif
   if (a.Cin < 128 || a.Cin % 32 != 0 || a.Cout % 64 != 0 || a.CoutPad != a.Cout) return 0;
   // Cout = 64 (the data gradient of a 64 -> 128 layer): 64-channel blocks, a wave = 32 MB pixels x 32 channels (one filter
-  // fragment, 5 reads per 4 MFMAs); FSR_TALL3 & 8 keeps these launches on conv_igemm.hip (A/B)
+  // fragment, 5 reads per 4 MFMAs)
   const bool narrow = a.Cout % 128 != 0;
-  if (narrow && ((mode & 14) || a.stats || a.pool2)) return 0;
+  if (narrow && (a.stats || a.pool2 || S == 2)) return 0;
   if (a.preact || a.oscale || a.ps || a.in_ps || a.out_f32) return 0;
-  if (a.stats && (a.pool2 || a.dmask || (mode & 6))) return 0;   // statistics: the shipped 4-wave form, forward launches
+  if (a.stats && (a.pool2 || a.dmask)) return 0;   // statistics: forward launches
   if (a.act != FSR_ACT_NONE && a.act != FSR_ACT_RELU && a.act != FSR_ACT_LEAKY) return 0;
   if (a.act == FSR_ACT_LEAKY && !(a.slope >= 0.f && a.slope <= 1.f)) return 0;   // the epilogue's max(v, slope * v) form
   if (a.osy != 1 || a.osx != 1 || a.ooy != 0 || a.oox != 0 || a.org_y != -1 || a.org_x != -1) return 0;
-  if (a.pool2 && (a.dmask || (a.GH & 1) || (a.GW & 1))) return 0;
+  if (a.pool2 && (a.dmask || (a.GH & 1) || (a.GW & 1) || S == 2)) return 0;
   if ((long long)a.N * a.IH * a.IW * a.Cin >= (1LL << 31) || (long long)a.N * a.FOH * a.FOW * a.Cout >= (1LL << 31)) return 0;
   // canonical tap order (ky, kx): which filter slice serves the tap that reads halo offset (ky, kx)
   int slice[9];
+  unsigned woff[9];
   for (int t = 0; t < 9; ++t) slice[t] = -1;
   for (int t = 0; t < 9; ++t) {
     if (a.tdy[t] < 0 || a.tdy[t] > 2 || a.tdx[t] < 0 || a.tdx[t] > 2) return 0;
@@ -567,40 +661,47 @@ int fsr_conv_tall3_try(int dtype, ConvKArgs& a, int S, hipStream_t stream) {
   }
   for (int t = 0; t < 9; ++t) {
     if (slice[t] < 0) return 0;
-    a.t3_woff[t] = (unsigned)((size_t)slice[t] * a.CoutPad * a.Cin * 2);
+    woff[t] = (unsigned)((size_t)slice[t] * a.CoutPad * a.Cin * 2);
   }
-  a.tiles_x = (a.GW + 15) / 16;
-  const bool wide = a.Cout % 256 == 0 && (mode & 2);
   // Tile height (16, 12 or 8 rows): the tallest one that pads the map least -- 16 rows everywhere except the 24-row maps
   // (two 12-row tiles; 16-row tiles would compute 32 rows: measured 906 against 752 TFLOP/s on 512 -> 512 @ 24^2).  Whole
   // tile rounds do NOT decide: 12-row tiles give 512 -> 512 @ 48^2 exactly 3 rounds instead of 2.25 and still measured
   // 0..4 % slower -- a workgroup whose partner has finished runs faster alone, and the shorter tile pays more staging per
-  // MFMA (profiles/r03_conv_tall3_ab.txt).  FSR_T3_ROWS forces a height (A/B, tests).
+  // MFMA (profiles/r03_conv_tall3_ab.txt).  FSR_T3_ROWS forces a height (tests).  Stride 2: 8-row tiles (four plane buffers).
   int best_mb = 4, best_rows = 1 << 30;
-  const int forced = getenv("FSR_T3_ROWS") ? atoi(getenv("FSR_T3_ROWS")) : 0;
+  const char* rows_env = getenv("FSR_T3_ROWS");
+  const int forced = rows_env ? atoi(rows_env) : 0;
   for (int mb = 4; mb >= 2; --mb) {
     const int th = 4 * mb;
     if (forced && forced != th) continue;
     const int rows = (a.GH + th - 1) / th * th;
     if (rows < best_rows) { best_rows = rows; best_mb = mb; }
   }
-  a.tiles_y = (a.GH + 4 * best_mb - 1) / (4 * best_mb);
-  // FSR_TALL3 & 4 (A/B): the one-wave-per-SIMD form, 128 x 128 per wave (16-row tiles only)
-  if ((mode & 4) && a.Cout % 256 == 0 && best_mb == 4 && dtype == FSR_BF16) return t3_launch<bf16_t, 256, 4, 3, 2, 4, 4>(a, 1, stream);
-#define T3_GO(TT, MBV)                                                                      \
-  do {                                                                                      \
-    if (narrow) return t3_launch<TT, 64, 4, 1, 4, MBV, 1>(a, 2, stream);                    \
-    if (a.stats) return t3_launch<TT, 128, 4, 1, 4, MBV, 2, true>(a, 2, stream);            \
-    if (wide) return t3_launch<TT, 256, 8, 3, 2, MBV>(a, 1, stream);                        \
-    return t3_launch<TT, 128, 4, 1, 4, MBV>(a, 2, stream);                                  \
+  if (S == 2) best_mb = 2;
+  ConvKArgs b = a;          // `a` stays untouched unless a launch is taken
+  for (int t = 0; t < 9; ++t) b.t3_woff[t] = woff[t];
+  b.tiles_x = (b.GW + 15) / 16;
+  b.tiles_y = (b.GH + 4 * best_mb - 1) / (4 * best_mb);
+  int rc = 0;
+#define T3_GO(TT, MBV)                                                                            \
+  do {                                                                                            \
+    if (narrow) rc = t3_launch<TT, 64, 4, 1, 4, MBV, 1>(b, 2, stream);                            \
+    else if (b.stats) rc = t3_launch<TT, 128, 4, 1, 4, MBV, 2, true>(b, 2, stream);               \
+    else rc = t3_launch<TT, 128, 4, 1, 4, MBV>(b, 2, stream);                                     \
   } while (0)
-  if (dtype == FSR_F16) {
+  if (S == 2) {
+    if (dtype == FSR_F16) rc = b.stats ? t3_launch<f16_t, 128, 4, 1, 4, 2, 2, true, 2>(b, 2, stream) : t3_launch<f16_t, 128, 4, 1, 4, 2, 2, false, 2>(b, 2, stream);
+    else rc = b.stats ? t3_launch<bf16_t, 128, 4, 1, 4, 2, 2, true, 2>(b, 2, stream) : t3_launch<bf16_t, 128, 4, 1, 4, 2, 2, false, 2>(b, 2, stream);
+  } else if (dtype == FSR_F16) {
     if (best_mb == 4) T3_GO(f16_t, 4);
-    if (best_mb == 3) T3_GO(f16_t, 3);
-    T3_GO(f16_t, 2);
+    else if (best_mb == 3) T3_GO(f16_t, 3);
+    else T3_GO(f16_t, 2);
+  } else {
+    if (best_mb == 4) T3_GO(bf16_t, 4);
+    else if (best_mb == 3) T3_GO(bf16_t, 3);
+    else T3_GO(bf16_t, 2);
   }
-  if (best_mb == 4) T3_GO(bf16_t, 4);
-  if (best_mb == 3) T3_GO(bf16_t, 3);
-  T3_GO(bf16_t, 2);
 #undef T3_GO
+  if (rc == 1) a = b;
+  return rc;
 }

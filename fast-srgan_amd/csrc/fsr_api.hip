@@ -85,6 +85,7 @@ extern "C" int fsr_conv3x3(const fsr_conv_desc* d, const void* in, const void* p
   a.dmask_add = (dact_mask && d->mask_is_addend) ? 1 : 0;
   if (d->mask_is_addend && !dact_mask) return fsr_fail(-1, "fsr_conv3x3: mask_is_addend needs the dact_mask tensor");
   a.stats = stats ? (float*)scratch : nullptr;   // the kernels write per-workgroup partials; finished below
+  a.stats_P_max = stats ? (int)stats_slots_bound(d) : 0;   // launchers compare their slot count with this BEFORE launching
   a.N = d->n;
   a.IH = d->ih;
   a.IW = d->iw;
@@ -117,7 +118,6 @@ extern "C" int fsr_conv3x3(const fsr_conv_desc* d, const void* in, const void* p
   if (int rc = conv3x3_enqueue(d, a, stream)) return rc;
   if (stats) {
     // second level: the image's slots added in a fixed order into stats[n][cout][2]
-    if ((size_t)a.stats_P > stats_slots_bound(d)) return fsr_fail(-3, "fsr_conv3x3: internal error (partial slots %d)", a.stats_P);
     return fsr_launch_reduce_partials((const float*)scratch, stats, d->n, a.stats_P, d->cout * 2, d->cout * 2, a.stats_tpi, a.stats_per, 1.f, 0, stream);
   }
   return 0;

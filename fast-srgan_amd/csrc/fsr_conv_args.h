@@ -22,6 +22,7 @@ struct ConvKArgs {
   int dmask_add;        // the dmask tensor is an addend (result += dmask) instead of a gate
   float* stats;         // optional per-workgroup partials [N][stats_P][Cout][2] (sum, sum of squares of the pre-activation)
   int stats_P;          // partial slots per image (set by the launcher: tiles per image, or tile ranges per image)
+  int stats_P_max;      // slots per image the caller's scratch buffer holds (fsr_conv3x3_scratch): checked BEFORE a launch
   int stats_tpi, stats_per;   // persistent kernels: tiles per image / tiles per workgroup (0 for one-tile workgroups)
   int N, IH, IW, Cin;
   int GH, GW;
@@ -45,7 +46,6 @@ struct ConvKArgs {
   // conv_tall3.hip: byte offset of the filter slice that serves canonical tap ky*3+kx, and the launch's tile count
   unsigned t3_woff[9];
   int t3_ntiles;
-  int t3_dbg;           // FSR_T3_DBG (debug builds of the bench only): 1 no stores, 2 no DMA, 4 no main loop
 };
 
 // A launch may cover up to four "classes" that differ only in their output grid, tap table and output offset (the

@@ -753,7 +753,6 @@ def test_conv_tall3(dev, cdn, cin, cout, variant, rows, monkeypatch):
     and with more tiles than workgroups (FSR_PERSIST_CUS: every workgroup walks several tiles -- the DMA stream runs on across
     tile boundaries -- borders included), for the three tile heights."""
     monkeypatch.setenv("FSR_PERSIST_CUS", "3" if _big(dev) else "1")
-    monkeypatch.setenv("FSR_TALL3", "3" if cout == 256 else "1")   # 256 channels: the 8-wave form; 128: the 4-wave form
     monkeypatch.setenv("FSR_T3_ROWS", str(rows))                    # tile height (the dispatch picks it by tile rounds otherwise)
     cd = ops.Compute(cdn)
     torch.manual_seed(11)
@@ -784,7 +783,6 @@ def test_conv_tall3(dev, cdn, cin, cout, variant, rows, monkeypatch):
     assert relerr(_nchw(dx), want) < tol(cdn, 1e-5, 1e-2)
     # forward with InstanceNorm statistics of the pre-activation (the discriminator's stride-1 blocks): the 4-wave form's
     # statistics epilogue, one partial slot per tile and wave row group, ragged tiles excluded pixel by pixel
-    monkeypatch.setenv("FSR_TALL3", "1")
     y2, _, stats = ops.conv3x3_raw(cd, xd, wpk, cout, bias=bias.to(dev), act=L.ACT_LEAKY, slope=0.2, want_stats=True)
     if cout % 128 == 0:             # (64-channel blocks have no statistics instantiation: those launches stay on conv_igemm.hip)
         assert L.lib().fsr_last_kernel().decode().startswith("conv_tall3_kernel") and b"stats" in L.lib().fsr_last_kernel()
@@ -795,6 +793,47 @@ def test_conv_tall3(dev, cdn, cin, cout, variant, rows, monkeypatch):
     assert relerr(st[..., 1], (pre * pre).sum((2, 3))) < tol(cdn, 1e-4, 1e-3)
     _, _, stats2 = ops.conv3x3_raw(cd, xd, wpk, cout, bias=bias.to(dev), act=L.ACT_LEAKY, slope=0.2, want_stats=True)
     assert torch.equal(stats2.cpu(), st)                        # no atomics: bit-reproducible
+
+
+@pytest.mark.parametrize("cdn", ["bf16", "f16"])
+@pytest.mark.parametrize("cin,cout,hw,variant", [(128, 128, (19, 22), "stats"), (160, 256, (32, 47), "plain"), (128, 128, (48, 32), "stats"),
+                                                 (128, 256, (17, 33), "mask")])
+def test_conv_tall3_stride2_forward(dev, cdn, cin, cout, hw, variant, monkeypatch):
+    """conv_tall3.hip, S = 2 (the discriminator's stride-2 forwards, model.py:160-183): the four parity planes of a tile's
+    17 x 33 input window gathered by LDS-DMA into their own buffers, the 44 pieces of a chunk dealt over the four waves on
+    the fixed issue schedule, counted vmcnt waits -- odd and even extents (ragged tiles, the last input row / column present or
+    absent), more tiles than workgroups (the DMA stream runs on across tile and channel-block boundaries), InstanceNorm
+    statistics, a fused activation-gradient-style mask, bias + LeakyReLU."""
+    monkeypatch.setenv("FSR_PERSIST_CUS", "3" if _big(dev) else "1")
+    cd = ops.Compute(cdn)
+    torch.manual_seed(12)
+    h, w = hw if _big(dev) else (min(hw[0], 19), min(hw[1], 22))
+    n = 3 if _big(dev) else 1
+    x = _q(torch.randn(n, cin, h, w), cd)
+    wt = _q(torch.randn(cout, cin, 3, 3) * 0.05, cd)
+    xd = _nhwc(x, cd, dev)
+    wpk = ops.packed_filter(cd, wt.to(dev), L.PACK_FWD, cin)
+    oh, ow = (h - 1) // 2 + 1, (w - 1) // 2 + 1
+    if variant == "stats":
+        y, _, stats = ops.conv3x3_raw(cd, xd, wpk, cout, stride=2, want_stats=True)
+        assert L.lib().fsr_last_kernel().decode().startswith("conv_tall3_kernel") and b"stats,s2" in L.lib().fsr_last_kernel()
+        ref = F.conv2d(x, wt, None, 2, 1)
+        assert relerr(_nchw(y), ref) < tol(cdn, 1e-5, 1e-2)
+        st = stats.cpu()
+        assert relerr(st[..., 0], ref.sum((2, 3))) < tol(cdn, 1e-4, 1e-3)
+        assert relerr(st[..., 1], (ref * ref).sum((2, 3))) < tol(cdn, 1e-4, 1e-3)
+        _, _, stats2 = ops.conv3x3_raw(cd, xd, wpk, cout, stride=2, want_stats=True)
+        assert torch.equal(stats2.cpu(), st)                    # order-fixed partial slots: bit-reproducible
+        return
+    bias = torch.randn(cout) * 0.1
+    mask = _q(torch.randn(n, cout, oh, ow), cd) if variant == "mask" else None
+    y, _, _ = ops.conv3x3_raw(cd, xd, wpk, cout, stride=2, bias=bias.to(dev), act=L.ACT_LEAKY, slope=0.2,
+                              dact_mask=None if mask is None else _nhwc(mask, cd, dev), dact_slope=0.5)
+    assert L.lib().fsr_last_kernel().decode().startswith("conv_tall3_kernel") and b",s2>" in L.lib().fsr_last_kernel()
+    pre = F.conv2d(x, wt, bias, 2, 1)
+    if mask is not None:
+        pre = pre * torch.where(mask > 0, torch.ones_like(mask), torch.full_like(mask, 0.5))
+    assert relerr(_nchw(y), F.leaky_relu(pre, 0.2)) < tol(cdn, 1e-5, 1e-2)
 
 
 # (name, cin, cout, h, w, stride, batch, variant): the launches of the timed iteration whose PERSISTENT WALKS only exist at the

@@ -32,8 +32,12 @@ F32_VGG_DX = 2e-2
 # HIP-f32 gradients and the oracle's own float32 gradients are compared with the oracle evaluated in FLOAT64; the HIP error may
 # be at most F64_NET x the oracle's float32 error over a whole network (all tensors concatenated) and F64_TENSOR x per tensor
 # (+ F64_FLOOR of the tensor's norm: tensors the oracle reproduces to 1e-6 would otherwise gate at 1e-6).  A kernel bug shows
-# as a ratio of tens to thousands; summation order shows as ~1.
-F64_NET, F64_TENSOR, F64_FLOOR = 1.5, 2.5, 2e-4
+# as a ratio of tens to thousands; summation order shows as ~1.  Measured on the MI355X (profiles/r04_parity_errors.log):
+# networks 1.10 (D: 2.3e-3 against the oracle's own 2.1e-3) and 1.05 (G: 9.1e-2 against 8.7e-2), every filter tensor
+# 1.02 .. 1.17.  Tensors of fewer than 64 elements (the head's 3 biases, single PReLU slopes) are cancelling sums over a whole
+# layer: 0.14 .. 4.7 x either way, so they are held to F64_SMALL of their norm instead (slopes, as everywhere: unbounded, the
+# float32 oracle itself misses some by 60 .. 180 %).
+F64_NET, F64_TENSOR, F64_FLOOR, F64_SMALL = 1.5, 2.0, 2e-4, 0.05
 VGGQ_OUT, VGGQ_DX, VGG_BF16_OUT, VGG_BF16_DX = 1.2e-2, 0.45, 2e-2, 0.7
 #    Measured at cfg #1 (bf16 kernels vs the bf16-storage oracle): the four losses 3e-5, 3e-5, 1.7e-4, 3e-6; gradient tensors
 #    0.15-0.5 relative L2 with norm ratios 0.94-1.01 and cosines 0.995 (D) / 0.90 (G): the forward pass is reproduced to 1e-3,
@@ -140,8 +144,10 @@ def test_train_step_at_baseline_cfg1_size(pkg, cdn):
                 num_h, num_o, den = num_h + eh * eh, num_o + eo * eo, den + nr * nr
                 report("cfg1.f32.vs_f64.hip.%s" % n, eh / max(nr, 1e-300))
                 report("cfg1.f32.vs_f64.oracle32.%s" % n, eo / max(nr, 1e-300))
-                if g.numel() > 1 and not eh <= F64_TENSOR * eo + F64_FLOOR * nr:
+                if g.numel() >= 64 and not eh <= F64_TENSOR * eo + F64_FLOOR * nr:
                     bad.append((n, eh / max(nr, 1e-300), eo / max(nr, 1e-300)))
+                if 1 < g.numel() < 64 and not eh <= max(F64_TENSOR * eo, F64_SMALL * nr):
+                    bad.append((n, "small tensor", eh / max(nr, 1e-300), eo / max(nr, 1e-300)))
             eh, eo = (num_h / den) ** 0.5, (num_o / den) ** 0.5
             report("cfg1.f32.vs_f64.hip.%s_network" % tag, eh)
             report("cfg1.f32.vs_f64.oracle32.%s_network" % tag, eo)
