@@ -169,6 +169,10 @@ static int conv3x3_enqueue(const fsr_conv_desc* d, ConvKArgs& a, hipStream_t str
     ConvKArgs p = a;
     if (const int rc = fsr_conv64_s2dgrad_try(d->dtype, p, stream)) return rc < 0 ? rc : 0;
   }
+  {   // 128..512 channels: persistent kernel, all four classes per tile, dy read once (conv_s2d3.hip)
+    ConvKArgs p = a;
+    if (const int rc = fsr_conv_s2d3_try(d->dtype, p, stream)) return rc < 0 ? rc : 0;
+  }
   // The four classes go out as ONE launch, the 4-tap class first (longest workgroups first).
   ConvKArgs cls[4];
   int ncls = 0;

@@ -796,6 +796,33 @@ def test_conv_tall3(dev, cdn, cin, cout, variant, rows, monkeypatch):
 
 
 @pytest.mark.parametrize("cdn", ["bf16", "f16"])
+@pytest.mark.parametrize("cin,cout,hw,masked", [(128, 128, (19, 22), True), (128, 160, (32, 47), False), (192, 128, (48, 32), True),
+                                                (128, 128, (17, 33), False)])
+def test_conv_s2d3_stride2_data_gradient(dev, cdn, cin, cout, hw, masked, monkeypatch):
+    """conv_s2d3.hip (the discriminator's stride-2 data gradients, model.py:160-183): all four parity classes of a tile from
+    ONE dy halo, 128 / 192 input channels (two 64-channel blocks and three), dy maps with partial tiles, odd input extents
+    (partial parity classes), more tiles than workgroups (the DMA stream runs on across tile boundaries), with and without
+    the fused activation mask -- against autograd."""
+    monkeypatch.setenv("FSR_PERSIST_CUS", "3" if _big(dev) else "1")
+    cd = ops.Compute(cdn)
+    torch.manual_seed(13)
+    h, w = hw if _big(dev) else (min(hw[0], 19), min(hw[1], 22))
+    n = 3 if _big(dev) else 1
+    x = _q(torch.randn(n, cin, h, w), cd)                 # forward input = output of the producing activation (the mask)
+    wt = _q(torch.randn(cout, cin, 3, 3) * 0.05, cd)
+    xr = x.clone().requires_grad_(True)
+    y = F.conv2d(xr, wt, None, 2, 1)
+    g = _q(torch.randn_like(y), cd)
+    y.backward(g)
+    want = xr.grad * torch.where(x > 0, torch.ones(()), torch.tensor(0.2)) if masked else xr.grad
+    wpk = ops.packed_filter(cd, wt.to(dev), L.PACK_DGRAD, cout)
+    dx, _, _ = ops.conv3x3_raw(cd, _nhwc(g, cd, dev), wpk, cin, mode=L.CONV_DGRAD, out_hw=(h, w), stride=2,
+                               dact_mask=_nhwc(x, cd, dev) if masked else None, dact_slope=0.2)
+    assert L.lib().fsr_last_kernel().decode().startswith("conv_s2d3_kernel<%s>" % cdn), L.lib().fsr_last_kernel()
+    assert relerr(_nchw(dx), want) < tol(cdn, 1e-5, 1e-2)
+
+
+@pytest.mark.parametrize("cdn", ["bf16", "f16"])
 @pytest.mark.parametrize("cin,cout,hw,variant", [(128, 128, (19, 22), "stats"), (160, 256, (32, 47), "plain"), (128, 128, (48, 32), "stats"),
                                                  (128, 256, (17, 33), "mask")])
 def test_conv_tall3_stride2_forward(dev, cdn, cin, cout, hw, variant, monkeypatch):
