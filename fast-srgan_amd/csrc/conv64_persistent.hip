@@ -398,8 +398,8 @@ __global__ __launch_bounds__(NTHR64) void conv64_v2_kernel(const ConvKArgs a) {
       });
       if (col_ok && gyb < a.GH && !(l15 & 1)) {
         const unsigned off = (unsigned)((img * (a.FOH >> 1) + (gyb >> 1)) * (a.FOW >> 1) + (gx >> 1)) * (unsigned)a.Cout + (unsigned)(nb * 64 + lg * 16);
-        *(u32x4*)(outp + off) = pk[0];
-        *(u32x4*)(outp + off + 8) = pk[1];
+        fsr_st<2>((u32x4*)(outp + off), (u32x4)(pk[0]));
+        fsr_st<2>((u32x4*)(outp + off + 8), (u32x4)(pk[1]));
       }
       return;
     }
@@ -433,15 +433,15 @@ __global__ __launch_bounds__(NTHR64) void conv64_v2_kernel(const ConvKArgs a) {
           pk[n >> 1][(n & 1) * 2 + 1] = pack2<T>(v[2], v[3]);
         });
         if (prep) {
-          *(u32x4*)(prep + off) = pp[0];
-          *(u32x4*)(prep + off + 8) = pp[1];
+          fsr_st<2>((u32x4*)(prep + off), (u32x4)(pp[0]));
+          fsr_st<2>((u32x4*)(prep + off + 8), (u32x4)(pp[1]));
         }
 #if FSR_ABL64 == 1 || FSR_ABL64 == 3
         if (a.GW < 0)
 #endif
         {
-          *(u32x4*)(outp + off) = pk[0];
-          *(u32x4*)(outp + off + 8) = pk[1];
+          fsr_st<2>((u32x4*)(outp + off), (u32x4)(pk[0]));
+          fsr_st<2>((u32x4*)(outp + off + 8), (u32x4)(pk[1]));
         }
       }
     });
@@ -682,11 +682,11 @@ __global__ __launch_bounds__(NTHR64) void conv64_s2fwd_kernel(const ConvKArgs a)
             pk[n >> 1][(n & 1) * 2 + 1] = pack2<T>(v[2], v[3]);
           });
           if (prep) {
-            *(u32x4*)(prep + off) = pp[0];
-            *(u32x4*)(prep + off + 8) = pp[1];
+            fsr_st<2>((u32x4*)(prep + off), (u32x4)(pp[0]));
+            fsr_st<2>((u32x4*)(prep + off + 8), (u32x4)(pp[1]));
           }
-          *(u32x4*)(outp + off) = pk[0];
-          *(u32x4*)(outp + off + 8) = pk[1];
+          fsr_st<2>((u32x4*)(outp + off), (u32x4)(pk[0]));
+          fsr_st<2>((u32x4*)(outp + off + 8), (u32x4)(pk[1]));
         }
         if constexpr (STATS) {
           if (flush) {
@@ -864,7 +864,7 @@ __global__ __launch_bounds__(NTHR64, 2) void conv64_s2dgrad_kernel(const ConvKAr
             u32x2 pk;
             pk.x = pack2<T>(v[0], v[1]);
             pk.y = pack2<T>(v[2], v[3]);
-            *(u32x2*)(outp + off) = pk;
+            fsr_st<2>((u32x2*)(outp + off), (u32x2)(pk));
           });
         }
       });

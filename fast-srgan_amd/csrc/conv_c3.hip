@@ -180,15 +180,15 @@ __global__ __launch_bounds__(256) void conv_c3_fwd_kernel(const C3Args a) {
             lo += bv[2 * p];
             hi += bv[2 * p + 1];
             if (prep)
-              *(u32x4*)(prep + off + p * 32) = (u32x4){pack2<T>(lo[0], lo[1]), pack2<T>(lo[2], lo[3]),
-                                                       pack2<T>(hi[0], hi[1]), pack2<T>(hi[2], hi[3])};
+              fsr_st<4>((u32x4*)(prep + off + p * 32), (u32x4)((u32x4){pack2<T>(lo[0], lo[1]), pack2<T>(lo[2], lo[3]),
+                                                       pack2<T>(hi[0], hi[1]), pack2<T>(hi[2], hi[3])}));
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
               lo[q] = fmaxf(lo[q], 0.f) + slope * fminf(lo[q], 0.f);
               hi[q] = fmaxf(hi[q], 0.f) + slope * fminf(hi[q], 0.f);
             }
-            *(u32x4*)(outp + off + p * 32) = (u32x4){pack2<T>(lo[0], lo[1]), pack2<T>(lo[2], lo[3]),
-                                                     pack2<T>(hi[0], hi[1]), pack2<T>(hi[2], hi[3])};
+            fsr_st<4>((u32x4*)(outp + off + p * 32), (u32x4)((u32x4){pack2<T>(lo[0], lo[1]), pack2<T>(lo[2], lo[3]),
+                                                     pack2<T>(hi[0], hi[1]), pack2<T>(hi[2], hi[3])}));
           }
         }
         continue;
@@ -213,7 +213,7 @@ __global__ __launch_bounds__(256) void conv_c3_fwd_kernel(const C3Args a) {
               u32x2 pk;
               pk.x = pack2<T>(acc[0], acc[1]);
               pk.y = pack2<T>(acc[2], acc[3]);
-              *(u32x2*)(prep + off) = pk;
+              fsr_st<4>((u32x2*)(prep + off), (u32x2)(pk));
             }
           } else {
             if (prep) *(f32x4*)(prep + off) = acc;
@@ -224,7 +224,7 @@ __global__ __launch_bounds__(256) void conv_c3_fwd_kernel(const C3Args a) {
             u32x2 pk;
             pk.x = pack2<T>(acc[0], acc[1]);
             pk.y = pack2<T>(acc[2], acc[3]);
-            *(u32x2*)(outp + off) = pk;
+            fsr_st<4>((u32x2*)(outp + off), (u32x2)(pk));
           } else {
             *(f32x4*)(outp + off) = acc;
           }

@@ -27,20 +27,28 @@
 //             a substep = one k half (16 channels) of a stage: 6 MFMAs fed by 3 filter + 2 or 4 pixel fragment reads (38 reads
 //             per 36 MFMAs; conv_tall3's 64-channel-block form runs 45 per 36).  Reads run one substep ahead.
 // LDS (bytes)  halo[2][12 KB]  9 x 18 pixels (17 used) x 32 channels of chunk c / c+1, 64 B per pixel, swizzled like conv_tall3's
-//              ring[4][3 taps][64 rows][64 B] = 48 KB    -> 72 KB: two workgroups per CU
+//              ring[4][3 taps][64 rows][64 B] = 48 KB, stage[4 waves][2 KB] (epilogue)    -> 80 KB: two workgroups per CU
 //   The DMA runs ONE CHUNK ahead: stage (c, s) issues the filter pieces of stage (c+1, s) into the slot stage (c, s-1) just left,
 //   stage (c, 0) also the three halo pieces of chunk c+1.  One s_barrier per stage (before its second substep) with a counted
 //   vmcnt in front of it, as in conv_tall3.hip.
-// Epilogue: a lane holds 16 consecutive channels of one dy pixel per class and fragment -> two 16-byte stores into dx pixel
-//   (2a + py, 2b + px); the optional mask (the saved forward input of the producing layer: LeakyReLU / ReLU backward) is read
-//   at the same offsets.
+// Epilogue: a lane holds 16 consecutive channels of one dy pixel per class and fragment; each fragment is transposed through a
+//   wave-private LDS buffer so that a store instruction writes 16 dx pixels (2a + py, 2b + px) x 64 contiguous bytes; the
+//   optional mask (the saved forward input of the producing layer: LeakyReLU / ReLU backward) is loaded the same way.
 #include "fsr_common.h"
 #include "fsr_conv_args.h"
 #include "fsr_host.h"
 
 #include <stdlib.h>
 
+// Ablation builds (tools/build_variant1.sh -DFSR_ABLS=<mask>; results WRONG on purpose, the product library is built with 0):
+//   1 no stores   2 no DMA after the prologue   8 no fragment reads   32 no barriers   64 no DMA waits   128 no MFMAs
+#ifndef FSR_ABLS
+#define FSR_ABLS 0
+#endif
+
 namespace {
+
+constexpr int S2D_ABL = FSR_ABLS;
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
@@ -80,7 +88,8 @@ constexpr int S2D_HPW = 3;                                     // halo pieces pe
 constexpr int S2D_HALO_BYTES = S2D_HPW * S2D_NW * 1024;
 constexpr int S2D_SLOT_BYTES = 3 * S2D_BN * 64;                // three taps x 64 rows x 64 B
 constexpr int S2D_NSLOT = 4;
-constexpr int S2D_LDS = 2 * S2D_HALO_BYTES + S2D_NSLOT * S2D_SLOT_BYTES;
+constexpr int S2D_STAGE_OFF = 2 * S2D_HALO_BYTES + S2D_NSLOT * S2D_SLOT_BYTES;   // the epilogue's transposing buffers: 2 KB per wave
+constexpr int S2D_LDS = S2D_STAGE_OFF + S2D_NW * 2048;
 static_assert(S2D_HUNITS <= S2D_HPW * S2D_NW * 64, "the halo fits its pieces");
 
 __device__ __forceinline__ int s2d_swz_row(int R) { return (R >> 2) & 3; }
@@ -159,10 +168,12 @@ __global__ __launch_bounds__(S2D_NW * 64, 2) void conv_s2d3_kernel(const ConvKAr
     }
   };
   auto dma_halo = [&](const unsigned (&hv)[HPW], int c, int k, unsigned hb) {
+    if constexpr (!(S2D_ABL & 2))
     FSR_BLDS16(in_buf, hv[k], (unsigned)(c * 64), halo_addr + (fsr_lds_addr_t)(hb + (wave + k * NW) * 1024));
   };
   // this wave's piece of the tap at position `pos` of chunk c's nine (slice a.t3_woff[forward tap]) into slot offset `dst`
   auto dma_filter = [&](unsigned ws, int c, unsigned woff_tap, unsigned dst) {
+    if constexpr (!(S2D_ABL & 2))
     FSR_BLDS16(w_buf, wvoff, woff_tap + ws + (unsigned)(c * 64), ring_addr + (fsr_lds_addr_t)(dst + wave * 1024));
   };
   auto slot_of = [&](int gs) { return (unsigned)((gs & (S2D_NSLOT - 1)) * S2D_SLOT_BYTES); };
@@ -175,7 +186,7 @@ __global__ __launch_bounds__(S2D_NW * 64, 2) void conv_s2d3_kernel(const ConvKAr
     constexpr int r = decltype(rc)::value, buf = decltype(bufc)::value, si = decltype(sic)::value, j = decltype(jc)::value;
     constexpr bool two = s2d_two_sets(si);
     constexpr int NRD = two ? 7 : 5;
-    if constexpr (r < NRD) {
+    if constexpr (r < NRD && !(S2D_ABL & 8)) {
       // decode r -> (kind, index)
       constexpr int seq1[7] = {0, 10, 11, 1, 20, 21, 2};      // stage 1 order: a = 0..2, b set 0 = 10 + m, b set 1 = 20 + m
       constexpr int seq2[7] = {0, 10, 11, 1, 2, 20, 21};      // stage 2 order
@@ -253,15 +264,17 @@ __global__ __launch_bounds__(S2D_NW * 64, 2) void conv_s2d3_kernel(const ConvKAr
             // order, stores in the queue only lengthen the wait.  A stage that issued nothing (the end of the last tile)
             // makes the count meaningless: wait for everything.
             constexpr int n_this = si == 0 ? 6 : 3, n_prev = si == 1 ? 6 : 3;
-            if (full_prev && issue) FSR_WAIT_VM(n_this + n_prev);
-            else FSR_WAIT_VM(0);
-            FSR_BARRIER();
+            if constexpr (!(S2D_ABL & 64)) {
+              if (full_prev && issue) FSR_WAIT_VM(n_this + n_prev);
+              else FSR_WAIT_VM(0);
+            }
+            if constexpr (!(S2D_ABL & 32)) FSR_BARRIER();
           }
           static_for<0, 6>([&](auto ic) {
             constexpr int i = decltype(ic)::value;
             constexpr int g = i / MB, m = i % MB;
             constexpr int pos = si * 3 + g, t = S2D_TAP[pos];
-            acc[s2d_cls(t)][m] = Mfma32<T>::run(fa[buf][g], fb[buf][s2d_set(pos)][m], acc[s2d_cls(t)][m]);
+            if constexpr (!(S2D_ABL & 128)) acc[s2d_cls(t)][m] = Mfma32<T>::run(fa[buf][g], fb[buf][s2d_set(pos)][m], acc[s2d_cls(t)][m]);
             auto next_frag = [&](auto rc) {
               if constexpr (q == 0) {
                 read_frag(rc, std::integral_constant<int, buf ^ 1>{}, sic, std::integral_constant<int, 1>{}, sl, hb);
@@ -288,41 +301,68 @@ __global__ __launch_bounds__(S2D_NW * 64, 2) void conv_s2d3_kernel(const ConvKAr
       });
     }
 
-    // ---- epilogue: dx pixel (2a + py, 2b + px) of every class, 16 consecutive channels per lane --------------------------
+    // ---- epilogue: dx pixel (2a + py, 2b + px) of every class ------------------------------------------------------------
+    // After the MFMAs a lane holds 16 consecutive channels (32 B) of ONE dy pixel per class and fragment; stored from there a
+    // wave instruction is 64 separate 16-byte pieces 512+ B apart, and the CU's vector-memory path -- shared with the other
+    // workgroup's DMA pieces -- takes them one segment at a time (ablation, profiles/r04_s2d3_ablation.txt: without stores the
+    // kernel ran 2.0..2.5x faster).  Each fragment (32 pixels x 32 channels = 2 KB) is therefore TRANSPOSED through a wave-private
+    // 2 KB LDS buffer: written in accumulator layout, read back as four lanes per pixel, so a store instruction covers 16
+    // pixels x 64 contiguous bytes (16 segments instead of 64).  The mask travels the other way (coalesced load, transposed
+    // into accumulator layout) so that the gate is applied to the f32 accumulators exactly as before.
     T* outp = (T*)a.out;
     const T* maskp = (const T*)a.dmask;
-    const int co = cur.nb * BN + wco * 32 + hi * 16;
-    const int gb = cur.gx0 + l15;
+    char* stg = smem + S2D_STAGE_OFF + wave * 2048;
+    const int ct = lane >> 2, qt = lane & 3;                               // store layout: pixel column, 16-byte piece
+    const unsigned sa0 = (unsigned)(l31 * 64 + (((2 * hi) ^ ((l31 >> 2) & 3)) << 4));         // accumulator layout: pieces 2 hi, 2 hi + 1 of pixel l31
+    const unsigned sa1 = (unsigned)(l31 * 64 + (((2 * hi + 1) ^ ((l31 >> 2) & 3)) << 4));
+    const unsigned sb0 = (unsigned)(ct * 64 + ((qt ^ ((ct >> 2) & 3)) << 4)), sb1 = sb0 + 16 * 64;   // store layout: row 0 / row 1 of the fragment
+    const int gb = cur.gx0 + ct;
+    const int cob = cur.nb * BN + wco * 32 + qt * 8;
     static_for<0, 4>([&](auto kc) {
       constexpr int k = decltype(kc)::value, py = k >> 1, px = k & 1;
       static_for<0, MB>([&](auto mc) {
         constexpr int m = decltype(mc)::value;
-        const int ga = cur.gy0 + wpx * 2 * MB + 2 * m + lrow;
-        const int oy = 2 * ga + py, ox = 2 * gb + px;
-        if (ga < a.IH && gb < a.IW && oy < a.FOH && ox < a.FOW) {
-          const unsigned off = (unsigned)((cur.img * a.FOH + oy) * a.FOW + ox) * (unsigned)a.Cout + (unsigned)co;
-          float v[16];
+        const int ga0 = cur.gy0 + wpx * 2 * MB + 2 * m;
+        const int ox = 2 * gb + px;
+        const bool okx = gb < a.IW && ox < a.FOW;
+        const bool ok0 = okx && ga0 < a.IH && 2 * ga0 + py < a.FOH, ok1 = okx && ga0 + 1 < a.IH && 2 * ga0 + 2 + py < a.FOH;
+        const unsigned off0 = (unsigned)((cur.img * a.FOH + 2 * ga0 + py) * a.FOW + ox) * (unsigned)a.Cout + (unsigned)cob;
+        const unsigned off1 = off0 + 2u * (unsigned)a.FOW * (unsigned)a.Cout;
+        float v[16];
 #pragma unroll
-          for (int e = 0; e < 16; ++e) v[e] = acc[k][m][e];
-          if (maskp) {   // fused activation backward of the producing layer: dz = dx * act'(y), y = its saved output
-            const u32x4 k0 = *(const u32x4*)(maskp + off), k1 = *(const u32x4*)(maskp + off + 8);
-            const float ms = a.dmask_slope;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-              v[2 * e] = (int)(k0[e] << 16) > 0 ? v[2 * e] : v[2 * e] * ms;
-              v[2 * e + 1] = (int)(k0[e] & 0xffff0000u) > 0 ? v[2 * e + 1] : v[2 * e + 1] * ms;
-              v[8 + 2 * e] = (int)(k1[e] << 16) > 0 ? v[8 + 2 * e] : v[8 + 2 * e] * ms;
-              v[8 + 2 * e + 1] = (int)(k1[e] & 0xffff0000u) > 0 ? v[8 + 2 * e + 1] : v[8 + 2 * e + 1] * ms;
-            }
-          }
-          u32x4 p0, p1;
+        for (int e = 0; e < 16; ++e) v[e] = acc[k][m][e];
+        if (maskp) {   // fused activation backward of the producing layer: dz = dx * act'(y), y = its saved output
+          u32x4 m0 = {0u, 0u, 0u, 0u}, m1 = {0u, 0u, 0u, 0u};
+          if (ok0) m0 = *(const u32x4*)(maskp + off0);
+          if (ok1) m1 = *(const u32x4*)(maskp + off1);
+          *FSR_LDS_PTR(u32x4, stg + sb0) = m0;
+          *FSR_LDS_PTR(u32x4, stg + sb1) = m1;
+          FSR_WAVE_SYNC();
+          const u32x4 k0 = *FSR_LDS_PTR(const u32x4, stg + sa0), k1 = *FSR_LDS_PTR(const u32x4, stg + sa1);
+          FSR_WAVE_SYNC();
+          const float ms = a.dmask_slope;
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
-            p0[e] = pack2<T>(v[2 * e], v[2 * e + 1]);
-            p1[e] = pack2<T>(v[8 + 2 * e], v[8 + 2 * e + 1]);
+            v[2 * e] = (int)(k0[e] << 16) > 0 ? v[2 * e] : v[2 * e] * ms;
+            v[2 * e + 1] = (int)(k0[e] & 0xffff0000u) > 0 ? v[2 * e + 1] : v[2 * e + 1] * ms;
+            v[8 + 2 * e] = (int)(k1[e] << 16) > 0 ? v[8 + 2 * e] : v[8 + 2 * e] * ms;
+            v[8 + 2 * e + 1] = (int)(k1[e] & 0xffff0000u) > 0 ? v[8 + 2 * e + 1] : v[8 + 2 * e + 1] * ms;
           }
-          *(u32x4*)(outp + off) = p0;
-          *(u32x4*)(outp + off + 8) = p1;
+        }
+        u32x4 p0, p1;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          p0[e] = pack2<T>(v[2 * e], v[2 * e + 1]);
+          p1[e] = pack2<T>(v[8 + 2 * e], v[8 + 2 * e + 1]);
+        }
+        *FSR_LDS_PTR(u32x4, stg + sa0) = p0;
+        *FSR_LDS_PTR(u32x4, stg + sa1) = p1;
+        FSR_WAVE_SYNC();
+        const u32x4 o0 = *FSR_LDS_PTR(const u32x4, stg + sb0), o1 = *FSR_LDS_PTR(const u32x4, stg + sb1);
+        FSR_WAVE_SYNC();
+        if (!(S2D_ABL & 1)) {
+          if (ok0) fsr_st<16>((u32x4*)(outp + off0), o0);
+          if (ok1) fsr_st<16>((u32x4*)(outp + off1), o1);
         }
       });
     });

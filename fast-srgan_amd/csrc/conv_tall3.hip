@@ -473,8 +473,8 @@ __global__ __launch_bounds__(NW * 64, 2) void conv_tall3_kernel(const ConvKArgs 
                 p0[e] = pack2<T>(v[2 * e], v[2 * e + 1]);
                 p1[e] = pack2<T>(v[8 + 2 * e], v[8 + 2 * e + 1]);
               }
-              *(u32x4*)(outp + off) = p0;
-              *(u32x4*)(outp + off + 8) = p1;
+              fsr_st<1>((u32x4*)(outp + off), (u32x4)(p0));
+              fsr_st<1>((u32x4*)(outp + off + 8), (u32x4)(p1));
             }
           } else if (!(T3_ABL & 1) && ok) {
             const unsigned off = (unsigned)((oimg * a.FOH + gy) * a.FOW + gx) * (unsigned)a.Cout + (unsigned)co;
@@ -507,8 +507,8 @@ __global__ __launch_bounds__(NW * 64, 2) void conv_tall3_kernel(const ConvKArgs 
               p0[e] = pack2<T>(activate(v[2 * e]), activate(v[2 * e + 1]));
               p1[e] = pack2<T>(activate(v[8 + 2 * e]), activate(v[8 + 2 * e + 1]));
             }
-            *(u32x4*)(outp + off) = p0;
-            *(u32x4*)(outp + off + 8) = p1;
+            fsr_st<1>((u32x4*)(outp + off), (u32x4)(p0));
+            fsr_st<1>((u32x4*)(outp + off + 8), (u32x4)(p1));
           }
         });
       });

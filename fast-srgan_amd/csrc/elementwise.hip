@@ -31,7 +31,7 @@ template <typename T> struct V16 {   // the 16-bit storage types (bf16_t, f16_t)
     u32x4 t;
 #pragma unroll
     for (int i = 0; i < 4; ++i) t[i] = pack2<T>(v[2 * i], v[2 * i + 1]);
-    *(u32x4*)p = t;
+    fsr_st<8>((u32x4*)p, t);
   }
 };
 

@@ -87,6 +87,23 @@ __device__ __forceinline__ void fsr_blds16(fsr_buf_t b, unsigned voff, unsigned 
 #define FSR_WAIT_LGKM0() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
 #define FSR_BARRIER() __builtin_amdgcn_s_barrier()
 #endif
+// Orders the LDS traffic of ONE wave around a wave-private exchange (write in one lane mapping, read back in another): the
+// hardware runs a wave's LDS instructions in order, so this only has to stop the compiler from moving them across it.
+#ifndef FSR_WAVE_SYNC
+#define FSR_WAVE_SYNC() __builtin_amdgcn_wave_barrier()
+#endif
+// Bulk output stores.  FSR_NT (compile-time bit mask, one bit per kernel family) puts the non-temporal hint on them: a conv
+// epilogue streams hundreds of MB through 4 MB L2s whose hot content is the filter and halo lines the LDS-DMA keeps re-reading
+// (measured on conv_s2d3.hip's 128-channel layer: +8..10 % with `nt` stores, profiles/r04_nt_stores.txt).
+//   1 conv_tall3   2 conv64 family   4 first-layer kernels   8 elementwise   16 conv_s2d3   32 conv_igemm
+#ifndef FSR_NT
+#define FSR_NT 20
+#endif
+template <int BIT, typename V>
+__device__ __forceinline__ void fsr_st(V* p, V v) {
+  if constexpr ((FSR_NT & BIT) != 0) __builtin_nontemporal_store(v, p);
+  else *p = v;
+}
 // A register "use" with no instruction: pins where the compiler places its s_waitcnt for a load's result.
 #ifndef FSR_TOUCH
 #define FSR_TOUCH(v) asm volatile("" : "+v"(v))

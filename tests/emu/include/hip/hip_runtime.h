@@ -42,6 +42,7 @@ struct fsr_buf_t { const char* p; unsigned bytes; };
 #define FSR_WAIT_VM(n) ((void)0)
 #define FSR_WAIT_LGKM0() ((void)0)
 #define FSR_BARRIER() emu::block_sync()
+#define FSR_WAVE_SYNC() emu::wave_sync()
 
 struct dim3 {
   unsigned x, y, z;
