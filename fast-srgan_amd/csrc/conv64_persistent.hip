@@ -719,162 +719,6 @@ __global__ __launch_bounds__(NTHR64) void conv64_s2fwd_kernel(const ConvKArgs a)
   if (pend_img >= 0) stats_store();
 }
 
-// ---------------------------------------------------------------------------------------------------------------
-// Data gradient of the 64 -> 64 STRIDE-2 convolution (Discriminator block 0, /root/reference/model.py:148-152), all four
-// output-parity classes in one pass.  As four class launches of the generic kernel the layer is latency-bound (K is only
-// 64..256 per class, a workgroup lives for a prologue and an epilogue) at ~2 TB/s.  Here a persistent workgroup keeps
-// the whole transposed filter in LDS, walks 16x16 tiles of dz with the next halo prefetched, and computes for every
-// tile the 32x32 block of dx: tap (ky, kx) feeds class (py, px) = (1 - (ky & 1), 1 - (kx & 1)) from dz[i + (ky == 0),
-// j + (kx == 0)], 144 MFMAs per wave and tile into 32 accumulator tiles (4 classes x 2 rows x 4 channel tiles).  dz is
-// read once, dx (and the fused activation mask) as whole rows.
-template <typename T>
-__global__ __launch_bounds__(NTHR64, 2) void conv64_s2dgrad_kernel(const ConvKArgs a) {
-  constexpr int HUNITS = HT * HT * 8;
-  constexpr int HPT = (HUNITS + NTHR64 - 1) / NTHR64;
-  HIP_DYNAMIC_SHARED(char, smem)
-  T* wl = (T*)smem;
-  T* halo = (T*)(smem + W_BYTES);
-
-  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int l15 = lane & 15, lg = lane >> 4;
-  const T* in = (const T*)a.in;
-  const int tiles_per_img = a.tiles_x * a.tiles_y;
-  const int ntiles = tiles_per_img * a.N;
-  {
-    const T* wpk = (const T*)a.wpk;
-#pragma unroll
-    for (int i = 0; i < 9; ++i) {
-      const int u = tid + i * NTHR64;
-      const u32x4 v = *(const u32x4*)(wpk + (size_t)u * 8);
-      *(u32x4*)(wl + (u >> 3) * P64 + (u & 7) * 8) = v;
-    }
-  }
-  u32x4 hreg[HPT];
-  auto halo_issue = [&](int tile) {
-    const int img = tile / tiles_per_img;
-    const int rem = tile - img * tiles_per_img;
-    const int ty = rem / a.tiles_x, tx = rem - ty * a.tiles_x;
-    const int iy0 = ty * 16, ix0 = tx * 16;
-#pragma unroll
-    for (int i = 0; i < HPT; ++i) {
-      const int u = tid + i * NTHR64;
-      u32x4 v = (u32x4){0u, 0u, 0u, 0u};
-      if (u < HUNITS) {
-        const int unit = u & 7, p = u >> 3;
-        const int hy = p / HT, hx = p - hy * HT;
-        const int iy = iy0 + hy, ix = ix0 + hx;
-        if (iy < a.IH && ix < a.IW) v = *(const u32x4*)(in + ((unsigned)((img * a.IH + iy) * a.IW + ix) * 64u + (unsigned)(unit * 8)));
-      }
-      hreg[i] = v;
-    }
-  };
-  auto halo_commit = [&]() {
-#pragma unroll
-    for (int i = 0; i < HPT; ++i) {
-      const int u = tid + i * NTHR64;
-      if (u < HUNITS) *(u32x4*)(halo + (u >> 3) * P64 + (u & 7) * 8) = hreg[i];
-    }
-  };
-  T* outp = (T*)a.out;
-  const T* maskp = (const T*)a.dmask;
-  int pixbase[2], wbase[4];
-#pragma unroll
-  for (int m = 0; m < 2; ++m) pixbase[m] = ((wave * 2 + m) * HT + l15) * P64 + lg * 8;
-#pragma unroll
-  for (int n = 0; n < 4; ++n) wbase[n] = (n * 16 + l15) * P64 + lg * 8;
-
-  const int tile_begin = (int)blockIdx.x * a.nblk_n;
-  const int tile_end = (tile_begin + a.nblk_n < ntiles) ? tile_begin + a.nblk_n : ntiles;
-  int tile = tile_begin;
-  if (tile < tile_end) halo_issue(tile);
-  __syncthreads();
-  if (tile < tile_end) halo_commit();
-  __syncthreads();
-
-  for (; tile < tile_end; ++tile) {
-    const int next = tile + 1;
-    if (next < tile_end) halo_issue(next);
-
-    f32x4 acc[4][2][4];   // [class 2*py + px][row][channel tile]
-#pragma unroll
-    for (int q = 0; q < 4; ++q)
-#pragma unroll
-      for (int m = 0; m < 2; ++m)
-#pragma unroll
-        for (int n = 0; n < 4; ++n) acc[q][m][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    static_for<0, 9>([&](auto tcn) {
-      constexpr int t = decltype(tcn)::value;
-      constexpr int ky = t / 3, kx = t % 3;
-      constexpr int q = 2 * (1 - (ky & 1)) + (1 - (kx & 1));
-      constexpr int toff = ((ky == 0 ? 1 : 0) * HT + (kx == 0 ? 1 : 0)) * P64;
-      const T* wsl = wl + t * 64 * P64;
-#pragma unroll
-      for (int ks = 0; ks < 2; ++ks) {
-        s16x8 wf[4], xf[2];
-#pragma unroll
-        for (int n = 0; n < 4; ++n) wf[n] = *(const s16x8*)(wsl + wbase[n] + ks * 32);
-#pragma unroll
-        for (int m = 0; m < 2; ++m) xf[m] = *(const s16x8*)(halo + pixbase[m] + toff + ks * 32);
-#pragma unroll
-        for (int m = 0; m < 2; ++m)
-#pragma unroll
-          for (int n = 0; n < 4; ++n) acc[q][m][n] = mfma16<T>(wf[n], xf[m], acc[q][m][n]);
-      }
-      __builtin_amdgcn_sched_barrier(0);   // 128 accumulators + the prefetched halo: keep fragment live ranges to one tap
-    });
-
-    FSR_WAIT_LOADS();   // (see conv64_thin_kernel)
-    const int img = tile / tiles_per_img;
-    const int rem = tile - img * tiles_per_img;
-    const int ty = rem / a.tiles_x, tx = rem - ty * a.tiles_x;
-    const int gx = tx * 16 + l15, gyb = ty * 16 + wave * 2;
-    static_for<0, 4>([&](auto qc) {
-      constexpr int q = decltype(qc)::value;
-      constexpr int py = q >> 1, px = q & 1;
-      const int ox = 2 * gx + px;
-      // the class's eight mask vectors first, then its stores: a mask load issued after a store would wait for that
-      // store to reach memory (one counter for loads and stores, possible aliasing) -- once per class instead of per row
-      u32x2 mkv[2][4];
-      unsigned base[2];
-      bool ok[2];
-#pragma unroll
-      for (int m = 0; m < 2; ++m) {
-        const int oy = 2 * (gyb + m) + py;
-        ok[m] = ox < a.FOW && oy < a.FOH;
-        base[m] = (unsigned)((img * a.FOH + oy) * a.FOW + ox) * 64u + (unsigned)(lg * 4);
-        if (maskp) {
-#pragma unroll
-          for (int n = 0; n < 4; ++n) mkv[m][n] = ok[m] ? *(const u32x2*)(maskp + base[m] + n * 16) : (u32x2){0u, 0u};
-        }
-      }
-      static_for<0, 2>([&](auto mc) {
-        constexpr int m = decltype(mc)::value;
-        if (ok[m]) {
-          static_for<0, 4>([&](auto nc) {
-            constexpr int n = decltype(nc)::value;
-            const unsigned off = base[m] + n * 16;
-            f32x4 v = acc[q][m][n];
-            if (maskp) {
-              const u32x2 tm = mkv[m][n];
-              const float mk[4] = {cvt_lo<T>(tm.x), cvt_hi<T>(tm.x),
-                                   cvt_lo<T>(tm.y), cvt_hi<T>(tm.y)};
-#pragma unroll
-              for (int r = 0; r < 4; ++r) v[r] = a.dmask_add ? v[r] + mk[r] : (mk[r] > 0.f ? v[r] : v[r] * a.dmask_slope);
-            }
-            u32x2 pk;
-            pk.x = pack2<T>(v[0], v[1]);
-            pk.y = pack2<T>(v[2], v[3]);
-            fsr_st<2>((u32x2*)(outp + off), (u32x2)(pk));
-          });
-        }
-      });
-    });
-    __syncthreads();
-    if (next < tile_end) halo_commit();
-    __syncthreads();
-  }
-}
-
 }  // namespace
 
 // Workgroup slots of the persistent kernels: one per CU.  FSR_PERSIST_CUS overrides the device's CU count (tests: lets a
@@ -892,34 +736,6 @@ static int persistent_slots() {
               ? prop.multiProcessorCount : 256;
   }
   return cus;
-}
-
-// Stride-2 data gradient, 64 -> 64 channels: 1 = launched, 0 = not this kernel's shape, < 0 = error.
-// `a`: in = dz [N, IH, IW, 64], out = dx [N, FOH, FOW, 64], wpk = the [9][64][64] data-gradient pack.
-int fsr_conv64_s2dgrad_try(int dtype, ConvKArgs& a, hipStream_t stream) {
-  if ((dtype != FSR_BF16 && dtype != FSR_F16) || a.Cin != 64 || a.Cout != 64 || a.CoutPad != 64) return 0;
-  if (a.ps || a.in_ps || a.out_f32 || a.preact || a.oscale || a.bias || a.stats || a.act != FSR_ACT_NONE) return 0;
-  if (a.IH != (a.FOH - 1) / 2 + 1 || a.IW != (a.FOW - 1) / 2 + 1) return 0;
-  if ((long long)a.N * a.FOH * a.FOW * 64 >= (1LL << 31)) return 0;
-  a.tiles_x = (a.IW + 15) / 16;
-  a.tiles_y = (a.IH + 15) / 16;
-  const long long ntiles = (long long)a.tiles_x * a.tiles_y * a.N;
-  if (ntiles <= 0 || ntiles > 0x7fffffffLL) return 0;
-  static bool attr_set = false;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute((const void*)conv64_s2dgrad_kernel<bf16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS64);
-    (void)hipFuncSetAttribute((const void*)conv64_s2dgrad_kernel<f16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS64);
-    attr_set = true;
-  }
-  const int cus = persistent_slots();
-  const int per = (int)((ntiles + cus - 1) / cus);
-  a.nblk_n = per;
-  const int grid = (int)((ntiles + per - 1) / per);
-  if (dtype == FSR_F16) hipLaunchKernelGGL(conv64_s2dgrad_kernel<f16_t>, dim3(grid), dim3(NTHR64), LDS64, stream, a);
-  else hipLaunchKernelGGL(conv64_s2dgrad_kernel<bf16_t>, dim3(grid), dim3(NTHR64), LDS64, stream, a);
-  fsr_note_kernel("conv64_s2dgrad_kernel");
-  int rc = fsr_check_launch("conv64_s2dgrad_kernel");
-  return rc ? rc : 1;
 }
 
 // Stride-2 forward, 64 -> 64 channels: 1 = launched, 0 = not this kernel's shape, < 0 = error.

@@ -703,7 +703,6 @@ static int launch_cfg(ConvKArgs& a, hipStream_t stream, ConvKArgs* more = nullpt
 //   256  8x128 configuration with 64-channel chunks: LDS-DMA filter slices (one tap per stage)
 //   1024 stride-2 forward, 64 output channels: LDS-DMA three-tap stages
 //   65536 DISABLE the up-front mask loads of the epilogue
-//   32768 (fsr_api.hip) DISABLE the persistent all-classes kernel of the 64 -> 64 stride-2 data gradient
 static int stage_mode() {
   const char* e = getenv("FSR_CONV_STAGE");
   return e ? atoi(e) : 1374;

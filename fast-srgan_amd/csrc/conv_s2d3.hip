@@ -1,10 +1,12 @@
-// Data gradient of the stride-2 3x3 convolutions with 128..512 channels: ALL FOUR parity classes of a tile in one persistent
+// Data gradient of the stride-2 3x3 convolutions with 64..512 channels: ALL FOUR parity classes of a tile in one persistent
 // workgroup, on v_mfma_f32_32x32x16_{bf16,f16} with both operands arriving by LDS-DMA (the machinery of conv_tall3.hip).
 // (Round 4: replaces the four-class launches of conv_igemm.hip's <16,128,4,1,32,1,2,1> configuration, which re-read the
 // gradient tensor once per class -- 1.96x its algorithmic bytes -- and ran at 0.16..0.24 of the MFMA peak.)
 //
-// Replaces the autograd data gradient of /root/reference/model.py:160-183, strides 2 at :162, :172, :182 (Discriminator
-// 128->128 @192^2, 256->256 @96^2, 512->512 @48^2; trainer.py:181 and :195 run it at batch 2B and B).
+// Replaces the autograd data gradient of /root/reference/model.py:148-183, strides 2 at :150, :162, :172, :182 (Discriminator
+// 64->64 @384^2 -- with the neck's LeakyReLU(0.2) backward as the mask --, 128->128 @192^2, 256->256 @96^2, 512->512 @48^2;
+// trainer.py:181 and :195 run it at batch 2B and B).  The 64->64 layer ran on a filter-resident 8-wave kernel with 8-byte
+// stores before (conv64_s2dgrad_kernel, rounds 1-3: 225 / 429 us at batch 32 / 64 against 164 / 382 here).
 //
 // The arithmetic.  Forward: y[oy, ox] = sum_{ky,kx} x[2 oy + ky - 1, 2 ox + kx - 1] W[ky, kx].  The gradient of input pixel
 // (2a + py, 2b + px) collects the taps whose parity matches -- ky = 1 for py = 0, ky in {0, 2} for py = 1 -- and tap (ky, kx)
@@ -418,7 +420,7 @@ int s2d_launch(ConvKArgs& a, hipStream_t stream) {
 int fsr_conv_s2d3_try(int dtype, ConvKArgs& a, hipStream_t stream) {
   static const bool off = getenv("FSR_S2D3") && atoi(getenv("FSR_S2D3")) == 0;   // A/B switch
   if (off || (dtype != FSR_BF16 && dtype != FSR_F16)) return 0;
-  if (a.Cin < 128 || a.Cin % 32 != 0 || a.Cout % 64 != 0 || a.Cout < 128 || a.CoutPad != a.Cout) return 0;
+  if (a.Cin < 64 || a.Cin % 32 != 0 || a.Cout % 64 != 0 || a.Cout < 64 || a.CoutPad != a.Cout) return 0;
   if (a.ps || a.in_ps || a.out_f32 || a.preact || a.oscale || a.bias || a.stats || a.pool2 || a.act != FSR_ACT_NONE || a.dmask_add) return 0;
   if (a.IH != (a.FOH - 1) / 2 + 1 || a.IW != (a.FOW - 1) / 2 + 1) return 0;
   if ((long long)a.N * a.IH * a.IW * a.Cin >= (1LL << 31) || (long long)a.N * a.FOH * a.FOW * a.Cout >= (1LL << 31)) return 0;

@@ -165,11 +165,7 @@ static int conv3x3_enqueue(const fsr_conv_desc* d, ConvKArgs& a, hipStream_t str
   }
   // stride 2: split dx into its four parity classes.  For dx row y = 2i+py the contributing
   // filter rows are ky = 1 (py = 0; dy row i) or ky in {0, 2} (py = 1; dy rows i+1, i).
-  if (!(fsr_conv_stage_mode() & 32768)) {   // 64 -> 64: persistent kernel, all four classes per tile (conv64_persistent.hip)
-    ConvKArgs p = a;
-    if (const int rc = fsr_conv64_s2dgrad_try(d->dtype, p, stream)) return rc < 0 ? rc : 0;
-  }
-  {   // 128..512 channels: persistent kernel, all four classes per tile, dy read once (conv_s2d3.hip)
+  {   // 64..512 channels: persistent kernel, all four classes per tile, dy read once (conv_s2d3.hip)
     ConvKArgs p = a;
     if (const int rc = fsr_conv_s2d3_try(d->dtype, p, stream)) return rc < 0 ? rc : 0;
   }

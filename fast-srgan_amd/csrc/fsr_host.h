@@ -21,8 +21,7 @@ int fsr_conv_stage_mode();   // FSR_CONV_STAGE tuning / test switch, see conv_ig
 int fsr_conv64_persistent_try(int dtype, ConvKArgs& a, int S, hipStream_t stream);
 int fsr_conv_tall3_try(int dtype, ConvKArgs& a, int S, hipStream_t stream);        // 128..512 channels, stride 1: 32x32x16 MFMA, all-DMA (conv_tall3.hip)
 int fsr_conv64_s2fwd_try(int dtype, ConvKArgs& a, int S, hipStream_t stream);     // stride-2 forward, 64 -> 64, persistent streaming
-int fsr_conv64_s2dgrad_try(int dtype, ConvKArgs& a, hipStream_t stream);   // stride-2 data gradient, 64 -> 64, all parity classes
-int fsr_conv_s2d3_try(int dtype, ConvKArgs& a, hipStream_t stream);        // stride-2 data gradient, 128..512 channels, all parity classes (conv_s2d3.hip)
+int fsr_conv_s2d3_try(int dtype, ConvKArgs& a, hipStream_t stream);        // stride-2 data gradient, 64..512 channels, all parity classes (conv_s2d3.hip)
 // Second level of every cross-workgroup reduction (reduce.hip): out[b][i] (+)= scale * sum_p part[(b*P + p)*stride + i]
 // for i < len, p in a fixed order.  per > 0: batch b owns only the slots of the tile ranges [w*per, (w+1)*per) that
 // intersect its tpi tiles.
