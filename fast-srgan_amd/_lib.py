@@ -17,7 +17,8 @@ ACT_NONE, ACT_RELU, ACT_LEAKY, ACT_PRELU, ACT_TANH = 0, 1, 2, 3, 4
 CONV_FWD, CONV_DGRAD = 0, 1
 PACK_FWD, PACK_FWD_PS, PACK_DGRAD, PACK_DGRAD_PS = 0, 1, 2, 3
 OUT_DTYPE, OUT_F32, OUT_U8 = 0, 1, 2
-ABI_VERSION = 8
+OPT_BIAS, OPT_PRELU, OPT_OSCALE, OPT_MASK, OPT_PREACT, OPT_STATS = 1, 2, 4, 8, 16, 32   # fsr_conv3x3_pack_block
+ABI_VERSION = 9
 
 c_int, c_float, c_void_p, c_size_t, c_ll = ctypes.c_int, ctypes.c_float, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_longlong
 
@@ -29,7 +30,7 @@ class ConvDesc(ctypes.Structure):
         ("n", c_int), ("ih", c_int), ("iw", c_int), ("cin", c_int),
         ("oh", c_int), ("ow", c_int), ("cout", c_int),
         ("stride", c_int), ("act", c_int), ("slope", c_float),
-        ("pixel_shuffle", c_int), ("in_pixel_shuffled", c_int), ("out_f32", c_int), ("pool2", c_int), ("mask_is_addend", c_int),
+        ("pixel_shuffle", c_int), ("in_pixel_shuffled", c_int), ("out_f32", c_int), ("pool2", c_int), ("mask_is_addend", c_int), ("pack_lin", c_int),
     ]
 
 
@@ -51,6 +52,8 @@ SIGNATURES = {
     "fsr_last_kernel": (ctypes.c_char_p, []),
     "fsr_device_info": (c_int, [ctypes.c_char_p, c_size_t]),
     "fsr_pack_conv3x3": (c_int, [c_int, c_int, P, c_int, c_int, c_int, P, P]),
+    "fsr_pack_conv3x3_lin": (c_int, [c_int, c_int, P, c_int, c_int, c_int, P, P]),
+    "fsr_conv3x3_pack_block": (c_int, [ctypes.POINTER(ConvDesc), c_int]),
     "fsr_conv3x3_scratch": (c_size_t, [ctypes.POINTER(ConvDesc)]),
     "fsr_conv3x3": (c_int, [ctypes.POINTER(ConvDesc), P, P, P, P, P, P, c_float, P, P, P, P, P]),
     "fsr_conv3x3_wgrad_workspace": (c_size_t, [ctypes.POINTER(WgradDesc)]),

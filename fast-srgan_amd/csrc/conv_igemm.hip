@@ -777,6 +777,8 @@ static int dispatch_T(ConvKArgs& a, int S, hipStream_t stream, ConvKArgs* more =
 
 int fsr_conv_igemm_dispatch_classes(int dtype, ConvKArgs* cls, int n, hipStream_t stream) {
   if (n < 1 || n > 4) return fsr_fail(-2, "conv3x3: %d classes in one launch", n);
+  if (cls[0].query) return 0;         // (fsr_conv3x3_pack_block: these launches read the standard pack)
+  if (cls[0].wlin) return fsr_fail(-2, "conv3x3: a stage-contiguous filter pack reached a kernel that reads the standard one");
   if (dtype == FSR_BF16) return dispatch_T<bf16_t, 64, 32>(cls[0], 1, stream, cls + 1, n - 1);
   if (dtype == FSR_F16) return dispatch_T<f16_t, 64, 32>(cls[0], 1, stream, cls + 1, n - 1);
   if (dtype == FSR_F32) return dispatch_T<float, 16, 16>(cls[0], 1, stream, cls + 1, n - 1);
@@ -784,12 +786,18 @@ int fsr_conv_igemm_dispatch_classes(int dtype, ConvKArgs* cls, int n, hipStream_
 }
 
 int fsr_conv_igemm_dispatch(int dtype, ConvKArgs& a, int S, hipStream_t stream) {
+  if (a.Cin == 64) {
+    if (a.query) return 0;            // (the 64-input-channel kernels read the standard pack)
+    if (a.wlin) return fsr_fail(-2, "conv3x3: a stage-contiguous filter pack reached a kernel that reads the standard one");
+  }
   // 64 -> 64 channel stride-1 layers: persistent kernel with the whole filter resident in LDS (conv64_persistent.hip)
   if (const int rc = fsr_conv64_persistent_try(dtype, a, S, stream)) return rc < 0 ? rc : 0;
   // 64 -> 64 channel stride-2 forward (Discriminator block 0): persistent streaming kernel (conv64_persistent.hip)
   if (const int rc = fsr_conv64_s2fwd_try(dtype, a, S, stream)) return rc < 0 ? rc : 0;
   // 128..512-channel layers, stride 1 and the stride-2 forward: 32x32x16 MFMA, both operands by LDS-DMA (conv_tall3.hip)
   if (const int rc = fsr_conv_tall3_try(dtype, a, S, stream)) return rc < 0 ? rc : 0;
+  if (a.query) return 0;              // (fsr_conv3x3_pack_block: conv_igemm_kernel reads the standard pack)
+  if (a.wlin) return fsr_fail(-2, "conv3x3: a stage-contiguous filter pack reached a kernel that reads the standard one");
   if (dtype == FSR_BF16) return dispatch_T<bf16_t, 64, 32>(a, S, stream);
   if (dtype == FSR_F16) return dispatch_T<f16_t, 64, 32>(a, S, stream);
   if (dtype == FSR_F32) return dispatch_T<float, 16, 16>(a, S, stream);

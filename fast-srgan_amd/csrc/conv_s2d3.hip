@@ -116,6 +116,7 @@ __global__ __launch_bounds__(S2D_NW * 64, 2) void conv_s2d3_kernel(const ConvKAr
   const fsr_buf_t in_buf = fsr_make_buf(a.in, (unsigned)((size_t)a.N * a.IH * a.IW * a.Cin * sizeof(T)));
   const fsr_buf_t w_buf = fsr_make_buf(a.wpk, (unsigned)((size_t)9 * a.CoutPad * a.Cin * sizeof(T)));
   const int nchunks = a.Cin >> 5;
+  const unsigned wcs = a.wlin ? (unsigned)(9 * BN * 64) : 64u;      // byte step of the filter source from chunk to chunk
 
   // ---- loop-invariant per-lane addresses (the layouts of conv_tall3.hip) ------------------------------------------------
   // filter fragment of the tap at position g of the stage in ring slot `sl`, k half j: ring + sl + g * BN * 64 + aoff[j]
@@ -138,7 +139,8 @@ __global__ __launch_bounds__(S2D_NW * 64, 2) void conv_s2d3_kernel(const ConvKAr
   {
     const int R = wave * 16 + (lane >> 2), ul = lane & 3, i = R & 31;
     const int co = (R & ~31) + 16 * ((i >> 2) & 1) + (i & 3) + 4 * (i >> 3);
-    wvoff = (unsigned)((co * a.Cin + ((ul ^ s2d_swz_row(R)) << 3)) * (int)sizeof(T));
+    wvoff = a.wlin ? (unsigned)(wave * 1024 + lane * 16)       // stage-contiguous pack: a piece = 1 KB of contiguous memory
+                   : (unsigned)((co * a.Cin + ((ul ^ s2d_swz_row(R)) << 3)) * (int)sizeof(T));
   }
 
   f32x16 acc[4][MB];
@@ -156,7 +158,7 @@ __global__ __launch_bounds__(S2D_NW * 64, 2) void conv_s2d3_kernel(const ConvKAr
     tc.img = L / a.tiles_y;
     tc.gy0 = ty * TH;
     tc.gx0 = tx * 16;
-    ws = (unsigned)(tc.nb * BN * a.Cin * (int)sizeof(T));
+    ws = a.wlin ? (unsigned)(tc.nb * nchunks * 9 * BN * 64) : (unsigned)(tc.nb * BN * a.Cin * (int)sizeof(T));
 #pragma unroll
     for (int k = 0; k < HPW; ++k) {
       const int U = (wave + k * NW) * 64 + lane;
@@ -176,7 +178,7 @@ __global__ __launch_bounds__(S2D_NW * 64, 2) void conv_s2d3_kernel(const ConvKAr
   // this wave's piece of the tap at position `pos` of chunk c's nine (slice a.t3_woff[forward tap]) into slot offset `dst`
   auto dma_filter = [&](unsigned ws, int c, unsigned woff_tap, unsigned dst) {
     if constexpr (!(S2D_ABL & 2))
-    FSR_BLDS16(w_buf, wvoff, woff_tap + ws + (unsigned)(c * 64), ring_addr + (fsr_lds_addr_t)(dst + wave * 1024));
+    FSR_BLDS16(w_buf, wvoff, woff_tap + ws + (unsigned)c * wcs, ring_addr + (fsr_lds_addr_t)(dst + wave * 1024));
   };
   auto slot_of = [&](int gs) { return (unsigned)((gs & (S2D_NSLOT - 1)) * S2D_SLOT_BYTES); };
 
@@ -431,7 +433,16 @@ int fsr_conv_s2d3_try(int dtype, ConvKArgs& a, hipStream_t stream) {
   const long long ntiles = (long long)b.tiles_x * b.tiles_y * b.N * b.nblk_n;
   if (ntiles <= 0 || ntiles > 0x7fffffffLL) return 0;
   b.t3_ntiles = (int)ntiles;
-  for (int t = 0; t < 9; ++t) b.t3_woff[t] = (unsigned)((size_t)t * b.CoutPad * b.Cin * 2);
+  // stage-contiguous filter pack (fsr_pack_conv3x3_lin, 64-channel blocks) for 128 and more gradient channels: -2..11 % per layer;
+  // with 64 (a row of the standard pack is one whole line already) it measured +8 %, so that layer keeps the standard pack
+  const int want = b.Cin >= 128 ? S2D_BN : 0;
+  if (b.query) {
+    a.wlin_want = want;
+    return 1;
+  }
+  if (b.wlin != 0 && b.wlin != S2D_BN)
+    return fsr_fail(-2, "conv_s2d3: the filter pack is stage-contiguous in blocks of %d channels, this launch needs %d", b.wlin, S2D_BN);
+  for (int t = 0; t < 9; ++t) b.t3_woff[t] = b.wlin ? (unsigned)(t * S2D_BN * 64) : (unsigned)((size_t)t * b.CoutPad * b.Cin * 2);
   const int rc = dtype == FSR_F16 ? s2d_launch<f16_t>(b, stream) : s2d_launch<bf16_t>(b, stream);
   if (rc == 1) a = b;
   return rc;

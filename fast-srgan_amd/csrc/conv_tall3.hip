@@ -141,6 +141,7 @@ __global__ __launch_bounds__(NW * 64, 2) void conv_tall3_kernel(const ConvKArgs 
   const fsr_buf_t in_buf = fsr_make_buf(a.in, (unsigned)((size_t)a.N * a.IH * a.IW * a.Cin * sizeof(T)));
   const fsr_buf_t w_buf = fsr_make_buf(a.wpk, (unsigned)((size_t)9 * a.CoutPad * a.Cin * sizeof(T)));
   const int nchunks = a.Cin >> 5;
+  const unsigned wcs = a.wlin ? (unsigned)(9 * BN * 64) : 64u;      // byte step of the filter source from chunk to chunk
 
   // ---- loop-invariant per-lane addresses -------------------------------------------------------------------------
   // filter fragment (n, k half j) of tap g of the stage in ring slot `sl`: ring + sl + g*BN*64 + n*2048 + aoff[j]
@@ -164,7 +165,8 @@ __global__ __launch_bounds__(NW * 64, 2) void conv_tall3_kernel(const ConvKArgs 
   for (int k = 0; k < FP; ++k) {
     const int R = (wave + k * NW) * 16 + (lane >> 2), ul = lane & 3, i = R & 31;
     const int co = (R & ~31) + 16 * ((i >> 2) & 1) + (i & 3) + 4 * (i >> 3);
-    wvoff[k] = (unsigned)((co * a.Cin + ((ul ^ t3_swz_row(R)) << 3)) * (int)sizeof(T));
+    wvoff[k] = a.wlin ? (unsigned)((wave + k * NW) * 1024 + lane * 16)      // stage-contiguous pack: a piece = 1 KB of contiguous memory
+                      : (unsigned)((co * a.Cin + ((ul ^ t3_swz_row(R)) << 3)) * (int)sizeof(T));
   }
 
   f32x16 acc[NA][MB];
@@ -185,7 +187,7 @@ __global__ __launch_bounds__(NW * 64, 2) void conv_tall3_kernel(const ConvKArgs 
     tc.img = L / a.tiles_y;
     tc.gy0 = ty * TH;
     tc.gx0 = tx * 16;
-    ws = (unsigned)(tc.nb * BN * a.Cin * (int)sizeof(T));
+    ws = a.wlin ? (unsigned)(tc.nb * nchunks * 9 * BN * 64) : (unsigned)(tc.nb * BN * a.Cin * (int)sizeof(T));
     if constexpr (S == 2) {
       // piece g = wave + 4 k of the chunk's 44: plane g / 11 = (py, px), piece g % 11 of that plane; halo pixel (hy, hx) of the
       // plane is input pixel (2 gy0 - 1 + 2 hy + py, 2 gx0 - 1 + 2 hx + px); rows beyond TH - py / columns beyond 16 - px are
@@ -231,7 +233,7 @@ __global__ __launch_bounds__(NW * 64, 2) void conv_tall3_kernel(const ConvKArgs 
   // filter pieces of the tap at position `pos` of chunk c's stages (stride 1: the tap itself; stride 2: T3_S2_TAP[pos])
   auto dma_filter = [&](unsigned ws, int c, unsigned woff_tap, int k, unsigned slot_tap_off) {
     if constexpr (!(T3_ABL & 2))
-      FSR_BLDS16(w_buf, wvoff[k], woff_tap + ws + (unsigned)(c * 64), ring_addr + (fsr_lds_addr_t)(slot_tap_off + (wave + k * NW) * 1024));
+      FSR_BLDS16(w_buf, wvoff[k], woff_tap + ws + (unsigned)c * wcs, ring_addr + (fsr_lds_addr_t)(slot_tap_off + (wave + k * NW) * 1024));
   };
   // The bias of a tile's channel block comes by DMA as well (one piece of BN floats, wave 0, double buffered by tile parity):
   // an ordinary global load next to the epilogue's stores would make hipcc drain vmcnt -- the whole DMA pipeline -- per tile.
@@ -613,6 +615,10 @@ int t3_launch(ConvKArgs& a, int wg_per_cu, hipStream_t stream) {
   const int nblk_n = a.Cout / BN;
   const long long ntiles = (long long)a.tiles_x * a.tiles_y * a.N * nblk_n;
   if (ntiles <= 0 || ntiles > 0x7fffffffLL) return 0;
+  if (a.query) {            // fsr_conv3x3_pack_block: this kernel would run, and it takes the stage-contiguous pack of its block size
+    a.wlin_want = BN;
+    return 1;
+  }
   if (STATS) {   // one partial slot per tile and pixel-row group of waves; the caller's scratch holds stats_P_max of them
     const long long slots = (long long)a.tiles_x * a.tiles_y * (NW / (BN / (NA * 32)));
     if (slots > a.stats_P_max) return 0;
@@ -663,6 +669,15 @@ int fsr_conv_tall3_try(int dtype, ConvKArgs& a, int S, hipStream_t stream) {
     if (slice[t] < 0) return 0;
     woff[t] = (unsigned)((size_t)slice[t] * a.CoutPad * a.Cin * 2);
   }
+  // Stage-contiguous filter pack (fsr_pack_conv3x3_lin, block = this launch's channel block): the slices of a (block, chunk)
+  // lie back to back, rows already in LDS order and units swizzled, so a DMA piece reads 1 KB of contiguous memory (8 whole
+  // lines) instead of 16 half lines 2 Cin bytes apart.  Measured (profiles/r04_filter_pack.txt): stride 1 -3..5 %, stride-2 forward -9..14 %.
+  const int bn_here = (a.Cout % 128 != 0) ? 64 : 128;
+  if (a.wlin != 0 && a.wlin != bn_here)
+    return fsr_fail(-2, "conv_tall3: the filter pack is stage-contiguous in blocks of %d channels, this launch needs %d", a.wlin, bn_here);
+  const int wlin = a.wlin;
+  if (wlin)
+    for (int t = 0; t < 9; ++t) woff[t] = (unsigned)(slice[t] * bn_here * 64);
   // Tile height (16, 12 or 8 rows): the tallest one that pads the map least -- 16 rows everywhere except the 24-row maps
   // (two 12-row tiles; 16-row tiles would compute 32 rows: measured 906 against 752 TFLOP/s on 512 -> 512 @ 24^2).  Whole
   // tile rounds do NOT decide: 12-row tiles give 512 -> 512 @ 48^2 exactly 3 rounds instead of 2.25 and still measured

@@ -61,10 +61,38 @@ extern "C" size_t fsr_conv3x3_scratch(const fsr_conv_desc* d) {
 
 static int conv3x3_enqueue(const fsr_conv_desc* d, ConvKArgs& a, hipStream_t stream);
 
+static int conv3x3_impl(const fsr_conv_desc* d, const void* in, const void* packed_w, const float* bias,
+                        const float* prelu_weight, const float* oscale, const void* dact_mask, float dact_slope,
+                        void* out, void* preact, float* stats, void* scratch, hipStream_t stream, int* query_block);
+
 extern "C" int fsr_conv3x3(const fsr_conv_desc* d, const void* in, const void* packed_w, const float* bias,
                            const float* prelu_weight, const float* oscale, const void* dact_mask, float dact_slope,
                            void* out, void* preact, float* stats, void* scratch, fsr_stream_t stream_) {
-  hipStream_t stream = (hipStream_t)stream_;
+  return conv3x3_impl(d, in, packed_w, bias, prelu_weight, oscale, dact_mask, dact_slope, out, preact, stats, scratch,
+                      (hipStream_t)stream_, nullptr);
+}
+
+// Which filter pack does the kernel that fsr_conv3x3 would pick for this call read?  Runs the SAME argument checks and
+// dispatch chain with launches suppressed (ConvKArgs.query), so the answer cannot drift from the dispatch.
+extern "C" int fsr_conv3x3_pack_block(const fsr_conv_desc* d, int optional_tensors) {
+  if (!d) return fsr_fail(-1, "fsr_conv3x3_pack_block: null descriptor");
+  static const float dummy_f[4] = {0.f, 0.f, 0.f, 0.f};
+  const void* some = dummy_f;          // stands for "this optional tensor is given"; never dereferenced in query mode
+  fsr_conv_desc q = *d;
+  q.pack_lin = 0;
+  int block = 0;
+  const int rc = conv3x3_impl(&q, some, some, (optional_tensors & FSR_OPT_BIAS) ? dummy_f : nullptr,
+                              (optional_tensors & FSR_OPT_PRELU) ? dummy_f : nullptr, (optional_tensors & FSR_OPT_OSCALE) ? dummy_f : nullptr,
+                              (optional_tensors & FSR_OPT_MASK) ? some : nullptr, 0.f, (void*)some,
+                              (optional_tensors & FSR_OPT_PREACT) ? (void*)some : nullptr,
+                              (optional_tensors & FSR_OPT_STATS) ? (float*)some : nullptr,
+                              (optional_tensors & FSR_OPT_STATS) ? (void*)some : nullptr, nullptr, &block);
+  return rc < 0 ? rc : block;
+}
+
+static int conv3x3_impl(const fsr_conv_desc* d, const void* in, const void* packed_w, const float* bias,
+                        const float* prelu_weight, const float* oscale, const void* dact_mask, float dact_slope,
+                        void* out, void* preact, float* stats, void* scratch, hipStream_t stream, int* query_block) {
   if (!d || !in || !packed_w || !out) return fsr_fail(-1, "fsr_conv3x3: null argument");
   if (stats && !scratch) return fsr_fail(-1, "fsr_conv3x3: statistics need the scratch buffer (fsr_conv3x3_scratch bytes)");
   if (d->stride != 1 && d->stride != 2) return fsr_fail(-2, "fsr_conv3x3: stride must be 1 or 2");
@@ -86,6 +114,9 @@ extern "C" int fsr_conv3x3(const fsr_conv_desc* d, const void* in, const void* p
   if (d->mask_is_addend && !dact_mask) return fsr_fail(-1, "fsr_conv3x3: mask_is_addend needs the dact_mask tensor");
   a.stats = stats ? (float*)scratch : nullptr;   // the kernels write per-workgroup partials; finished below
   a.stats_P_max = stats ? (int)stats_slots_bound(d) : 0;   // launchers compare their slot count with this BEFORE launching
+  a.query = query_block ? 1 : 0;
+  a.wlin = d->pack_lin;
+  if (d->pack_lin != 0 && d->pack_lin != 64 && d->pack_lin != 128) return fsr_fail(-2, "fsr_conv3x3: pack_lin must be 0, 64 or 128");
   a.N = d->n;
   a.IH = d->ih;
   a.IW = d->iw;
@@ -116,6 +147,10 @@ extern "C" int fsr_conv3x3(const fsr_conv_desc* d, const void* in, const void* p
     return fsr_fail(-2, "fsr_conv3x3: statistics are not available for stride-2 data gradients");
 
   if (int rc = conv3x3_enqueue(d, a, stream)) return rc;
+  if (query_block) {
+    *query_block = a.wlin_want;
+    return 0;
+  }
   if (stats) {
     // second level: the image's slots added in a fixed order into stats[n][cout][2]
     return fsr_launch_reduce_partials((const float*)scratch, stats, d->n, a.stats_P, d->cout * 2, d->cout * 2, a.stats_tpi, a.stats_per, 1.f, 0, stream);
@@ -167,7 +202,10 @@ static int conv3x3_enqueue(const fsr_conv_desc* d, ConvKArgs& a, hipStream_t str
   // filter rows are ky = 1 (py = 0; dy row i) or ky in {0, 2} (py = 1; dy rows i+1, i).
   {   // 64..512 channels: persistent kernel, all four classes per tile, dy read once (conv_s2d3.hip)
     ConvKArgs p = a;
-    if (const int rc = fsr_conv_s2d3_try(d->dtype, p, stream)) return rc < 0 ? rc : 0;
+    if (const int rc = fsr_conv_s2d3_try(d->dtype, p, stream)) {
+      a.wlin_want = p.wlin_want;
+      return rc < 0 ? rc : 0;
+    }
   }
   // The four classes go out as ONE launch, the 4-tap class first (longest workgroups first).
   ConvKArgs cls[4];
@@ -196,7 +234,9 @@ static int conv3x3_enqueue(const fsr_conv_desc* d, ConvKArgs& a, hipStream_t str
       cls[ncls++] = b;
     }
   if (fsr_conv_stage_mode() & 16) return fsr_conv_igemm_dispatch_classes(d->dtype, cls, ncls, stream);
-  for (int k = 0; k < ncls; ++k)
+  for (int k = 0; k < ncls; ++k) {
     if (int rc = fsr_conv_igemm_dispatch(d->dtype, cls[k], 1, stream)) return rc;
+    if (a.query) break;
+  }
   return 0;
 }

@@ -55,8 +55,21 @@ PACK_C3 = "c3"   # packed_filter mode of the first-layer (image-input) kernels
 PACK_C3T = "c3t"  # ... of the head conv's data gradient run as a first-layer forward (transposed, tap-flipped filter)
 
 
-def packed_filter(cd, weight, mode, k_pad):
+class FilterSpec:
+    """A filter handed to conv3x3_raw as (weight, pack mode, k_pad) instead of a packed tensor: the launch then asks the
+    library which pack layout the kernel it will dispatch reads (fsr_conv3x3_pack_block: the standard [9][rows][K] image or
+    the stage-contiguous one of the 128..512-channel kernels) and packs -- cached per weight version -- accordingly."""
+
+    __slots__ = ("weight", "mode", "k_pad")
+
+    def __init__(self, weight, mode, k_pad):
+        self.weight, self.mode, self.k_pad = weight, mode, k_pad
+
+
+def packed_filter(cd, weight, mode, k_pad, lin=0):
     """[9][rows_pad][k_pad] image of an OIHW float weight (fsr_pack_conv3x3), cached per weight OBJECT and version.
+    lin = 64 / 128: the stage-contiguous layout of that channel-block size instead (fsr_pack_conv3x3_lin).
+
     Entries die with the weight (weak reference), so a recycled id()/address can never serve a stale filter.
 
     The image of a (weight, mode, dtype, k_pad) lives in ONE buffer for the lifetime of the weight: a newer weight
@@ -69,7 +82,7 @@ def packed_filter(cd, weight, mode, k_pad):
         wid = id(weight)
         slot = (weakref.ref(weight, lambda _r, wid=wid: _pack_cache.pop(wid, None)), {})
         _pack_cache[wid] = slot
-    key = (mode, cd.code, k_pad)
+    key = (mode, cd.code, k_pad, lin)
     hit = slot[1].get(key)
     if hit is not None and hit[0] == ver:
         return hit[1]
@@ -84,11 +97,15 @@ def packed_filter(cd, weight, mode, k_pad):
     if mode == PACK_C3T:
         numel = ((cin + 15) // 16 * 16) * 32
     else:
-        numel = ((cout + 15) // 16 * 16) * 32 if mode == PACK_C3 else 9 * rows_pad * k_pad
+        numel = ((cout + 15) // 16 * 16) * 32 if mode == PACK_C3 else 9 * (rows if lin else rows_pad) * k_pad
     out = hit[1] if (hit is not None and hit[1].device == w.device) else None
     if out is None:
         out = torch.empty(numel, dtype=cd.torch_dtype, device=w.device)
-    if mode == PACK_C3:     # first-layer kernels: [rows_pad][32]
+    if lin:
+        if k_pad != (cin if fwd else cout) or mode in (PACK_C3, PACK_C3T):
+            raise L.FsrError("the stage-contiguous filter pack has no padding")
+        L.check(L.lib().fsr_pack_conv3x3_lin(cd.code, mode, _p(w), cout, cin, lin, _p(out), _stream()), "fsr_pack_conv3x3_lin")
+    elif mode == PACK_C3:     # first-layer kernels: [rows_pad][32]
         L.check(L.lib().fsr_pack_conv3x3_c3(cd.code, _p(w), cout, _p(out), 0, _stream()), "fsr_pack_conv3x3_c3")
     elif mode == PACK_C3T:  # head conv [3][cin][3][3]: rows = its input channels
         L.check(L.lib().fsr_pack_conv3x3_c3(cd.code, _p(w), cin, _p(out), 1, _stream()), "fsr_pack_conv3x3_c3")
@@ -179,6 +196,7 @@ def _const_vec(values, device):
         _const[key] = t
     return t
 
+USE_LIN_PACK = os.environ.get("FSR_PACK_LIN", "1") != "0"   # A/B switch: 0 = every launch reads the standard filter pack
 USE_C3_KERNELS = True   # tests flip this to compare the first-layer kernels with the padded-tensor path
 
 # bench.py sets this to a list to collect (start_event, end_event, algorithmic_flops, algorithmic_bytes, kernel name, kind)
@@ -355,7 +373,15 @@ def conv3x3_raw(cd, x, wpk, cout, *, mode=L.CONV_FWD, out_hw=None, stride=1, bia
     pre = torch.empty(oshape, dtype=odt, device=x.device) if want_preact else None
     stats = _assigned((n, cout, 2), x.device) if want_stats else None
     d = L.ConvDesc(cd.code, mode, n, ih, iw, cin, oh, ow, cout, stride, act, float(slope), int(pixel_shuffle),
-                   int(in_pixel_shuffled), L.OUT_U8 if out_u8 else int(out_f32), int(pool2), int(bool(dact_add)))
+                   int(in_pixel_shuffled), L.OUT_U8 if out_u8 else int(out_f32), int(pool2), int(bool(dact_add)), 0)
+    if isinstance(wpk, FilterSpec):     # pack in the layout the kernel this launch dispatches reads
+        opt = ((L.OPT_BIAS if bias is not None else 0) | (L.OPT_PRELU if prelu is not None else 0) | (L.OPT_OSCALE if oscale is not None else 0)
+               | (L.OPT_MASK if dact_mask is not None else 0) | (L.OPT_PREACT if want_preact else 0) | (L.OPT_STATS if want_stats else 0))
+        blk = L.lib().fsr_conv3x3_pack_block(ctypes.byref(d), opt) if USE_LIN_PACK else 0
+        if blk < 0:
+            L.check(blk, "fsr_conv3x3_pack_block")
+        d.pack_lin = blk
+        wpk = packed_filter(cd, wpk.weight, wpk.mode, wpk.k_pad, lin=blk)
     scratch = _workspace(L.lib().fsr_conv3x3_scratch(ctypes.byref(d)), x.device) if want_stats else None
     prof = PROFILE_CONV
     if prof is not None:
@@ -474,7 +500,7 @@ class Conv3x3Fn(torch.autograd.Function):
             if xin.dtype != cd.torch_dtype:
                 raise L.FsrError("activation dtype %s does not match the module's compute dtype %s" % (xin.dtype, cd.name))
         cin_pad = xin.shape[3]
-        wpk = packed_filter(cd, weight, L.PACK_FWD_PS if cfg.pixel_shuffle else L.PACK_FWD, cin_pad)
+        wpk = FilterSpec(weight, L.PACK_FWD_PS if cfg.pixel_shuffle else L.PACK_FWD, cin_pad)
         training = ctx.grad_on and any(ctx.needs_input_grad)
         if (cfg.u8_head or cfg.pool_after) and training:
             raise L.FsrError("the uint8 head / fused max-pool epilogues are inference-only: they have no gradient")
@@ -608,7 +634,7 @@ class Conv3x3Fn(torch.autograd.Function):
                 dx = dx.permute(0, 3, 1, 2)
             else:
                 kpad = dz.shape[3] * (4 if cfg.pixel_shuffle else 1)
-                wpk = packed_filter(cd, weight, L.PACK_DGRAD_PS if cfg.pixel_shuffle else L.PACK_DGRAD, kpad)
+                wpk = FilterSpec(weight, L.PACK_DGRAD_PS if cfg.pixel_shuffle else L.PACK_DGRAD, kpad)
                 mask = xin if cfg.input_act_bwd is not None else None
                 addend = None
                 if skips:       # dL/dx = conv_dgrad(dz) + dL/d(skip): the first skip gradient rides in the launch's epilogue

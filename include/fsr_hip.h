@@ -38,7 +38,7 @@
 extern "C" {
 #endif
 
-#define FSR_ABI_VERSION 8
+#define FSR_ABI_VERSION 9
 
 enum { FSR_F32 = 0, FSR_BF16 = 1, FSR_F16 = 2 };
 enum { FSR_ACT_NONE = 0, FSR_ACT_RELU = 1, FSR_ACT_LEAKY = 2, FSR_ACT_PRELU = 3, FSR_ACT_TANH = 4 };
@@ -68,6 +68,13 @@ int fsr_device_info(char* buf, size_t buflen);
  * filled.  `packed` holds 9*rows_pad*k_pad elements. */
 int fsr_pack_conv3x3(int dtype, int mode, const float* w_oihw, int cout, int cin, int k_pad, void* packed,
                      fsr_stream_t stream);
+/* The same four layouts, STAGE-CONTIGUOUS for the 128..512-channel kernels (16-bit dtypes; rows a multiple of `block` = 64 or
+ * 128, K a multiple of 32, no padding): [rows / block][K / 32][9 slices][block rows][32 channels], the rows of a block in the
+ * kernels' LDS order and the 16-byte units of a 32-channel chunk XOR-swizzled as they lie in LDS, so the LDS-DMA of one
+ * (block, chunk, slice) reads block * 64 contiguous bytes (whole 128-byte lines) instead of half lines 2 K bytes apart.
+ * Which launches take it: fsr_conv3x3_pack_block().  `packed` holds 9 * rows * K elements. */
+int fsr_pack_conv3x3_lin(int dtype, int mode, const float* w_oihw, int cout, int cin, int block, void* packed,
+                         fsr_stream_t stream);
 
 /* ------------------------------------------------------------------ 3x3 convolution, pad 1
  * Forward:  torch.nn.Conv2d(k=3, p=1, stride 1|2) at model.py:47-64, 86-93, 30-35, 103-108,
@@ -116,7 +123,14 @@ typedef struct fsr_conv_desc {
   int out_f32;
   int pool2; /* FWD, 16-bit dtypes, no pixel shuffle: out is the MaxPool2d(2,2) of the activated result, [n,oh/2,ow/2,cout] */
   int mask_is_addend; /* dact_mask is ADDED to the result instead of gating it (see below) */
+  int pack_lin; /* 0: packed_w is fsr_pack_conv3x3's layout; 64 / 128: fsr_pack_conv3x3_lin's with that block (must equal fsr_conv3x3_pack_block) */
 } fsr_conv_desc;
+
+/* Block size of the stage-contiguous filter pack (fsr_pack_conv3x3_lin) that the kernel fsr_conv3x3 would dispatch for `desc`
+ * reads, or 0 if it reads the standard pack (always a valid choice: every kernel also accepts pack_lin = 0).  The optional
+ * tensors of the call take part in the dispatch: say which ones will be given.  Nothing is launched.  < 0: error. */
+enum { FSR_OPT_BIAS = 1, FSR_OPT_PRELU = 2, FSR_OPT_OSCALE = 4, FSR_OPT_MASK = 8, FSR_OPT_PREACT = 16, FSR_OPT_STATS = 32 };
+int fsr_conv3x3_pack_block(const fsr_conv_desc* desc, int optional_tensors);
 
 size_t fsr_conv3x3_scratch(const fsr_conv_desc* desc);
 int fsr_conv3x3(const fsr_conv_desc* desc, const void* in, const void* packed_w, const float* bias,

@@ -1,5 +1,7 @@
 """Operator-level parity: every kernel of libfsr_hip.so against the plain PyTorch fp32 op it replaces
 (torch CPU), through the same C ABI on both backends (see tests/backend.py)."""
+import ctypes
+
 import pytest
 import torch
 import torch.nn.functional as F
@@ -793,6 +795,45 @@ def test_conv_tall3(dev, cdn, cin, cout, variant, rows, monkeypatch):
     assert relerr(st[..., 1], (pre * pre).sum((2, 3))) < tol(cdn, 1e-4, 1e-3)
     _, _, stats2 = ops.conv3x3_raw(cd, xd, wpk, cout, bias=bias.to(dev), act=L.ACT_LEAKY, slope=0.2, want_stats=True)
     assert torch.equal(stats2.cpu(), st)                        # no atomics: bit-reproducible
+
+
+@pytest.mark.parametrize("case", ["fwd128", "fwd_s2_stats", "dgrad_narrow", "dgrad_s2", "dgrad_s2_64", "fwd64", "fwd_f32"])
+def test_stage_contiguous_filter_pack(dev, case, monkeypatch):
+    """fsr_pack_conv3x3_lin + fsr_conv3x3_pack_block: a launch that is given the WEIGHT (ops.FilterSpec) asks the library which
+    pack its kernel reads; conv_tall3 (128- and 64-channel blocks, stride 1 and 2) and conv_s2d3 (>= 128 gradient channels) answer
+    with their block size and then produce BIT-IDENTICAL results from the stage-contiguous pack; every other kernel answers 0."""
+    monkeypatch.setenv("FSR_PERSIST_CUS", "2" if _big(dev) else "1")
+    cdn = "f32" if case == "fwd_f32" else "bf16"
+    cd = ops.Compute(cdn)
+    torch.manual_seed(21)
+    cin, cout, stride, mode, want_blk = {"fwd128": (160, 256, 1, L.CONV_FWD, 128), "fwd_s2_stats": (128, 128, 2, L.CONV_FWD, 128),
+                                         "dgrad_narrow": (64, 128, 1, L.CONV_DGRAD, 64), "dgrad_s2": (128, 160, 2, L.CONV_DGRAD, 64),
+                                         "dgrad_s2_64": (64, 64, 2, L.CONV_DGRAD, 0), "fwd64": (64, 128, 1, L.CONV_FWD, 0),
+                                         "fwd_f32": (128, 128, 1, L.CONV_FWD, 0)}[case]
+    n, h, w = (2, 34, 40) if _big(dev) else (1, 18, 20)
+    wt = (_q(torch.randn(cout, cin, 3, 3) * 0.05, cd)).to(dev)
+    if mode == L.CONV_FWD:
+        x = _nhwc(_q(torch.randn(n, cin, h, w), cd), cd, dev)
+        kw = dict(stride=stride, act=L.ACT_LEAKY, slope=0.2, want_stats=(case == "fwd_s2_stats"))
+        pmode, kpad, co = L.PACK_FWD, cin, cout
+    else:
+        oh, ow = (h - 1) // stride + 1, (w - 1) // stride + 1
+        x = _nhwc(_q(torch.randn(n, cout, oh, ow), cd), cd, dev)            # dy
+        mask = _nhwc(_q(torch.randn(n, cin, h, w), cd), cd, dev)
+        kw = dict(mode=L.CONV_DGRAD, out_hw=(h, w), stride=stride, dact_mask=mask, dact_slope=0.2)
+        pmode, kpad, co = L.PACK_DGRAD, cout, cin
+    y0, _, s0 = ops.conv3x3_raw(cd, x, ops.packed_filter(cd, wt, pmode, kpad), co, **kw)
+    k0 = L.lib().fsr_last_kernel()
+    y1, _, s1 = ops.conv3x3_raw(cd, x, ops.FilterSpec(wt, pmode, kpad), co, **kw)
+    assert L.lib().fsr_last_kernel() == k0
+    key = [k for k in ops._pack_cache[id(wt)][1] if k[0] == pmode]
+    assert sorted(k[3] for k in key) == sorted({0, want_blk}), (k0, key)
+    assert torch.equal(y0.float().cpu(), y1.float().cpu())
+    if s0 is not None:
+        assert torch.equal(s0.cpu(), s1.cpu())
+    if want_blk:        # a pack of the wrong block size is refused, not misread
+        d = L.ConvDesc(cd.code, mode, n, x.shape[1], x.shape[2], x.shape[3], *( (y0.shape[1], y0.shape[2]) ), co, stride, 0, 0.0, 0, 0, 0, 0, 0, 192 - want_blk)
+        assert L.lib().fsr_conv3x3(ctypes.byref(d), x.data_ptr(), y0.data_ptr(), None, None, None, None, 0.0, y1.data_ptr(), None, None, None, ops._stream()) == -2
 
 
 @pytest.mark.parametrize("cdn", ["bf16", "f16"])
