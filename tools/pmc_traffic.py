@@ -13,7 +13,7 @@ import sys
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
-KERNELS = ("conv_igemm_kernel", "conv_tall3_kernel", "conv64_", "conv_c3_fwd_kernel")      # every forward / data-gradient convolution kernel (conv64_*: all persistent forms)
+KERNELS = ("conv_igemm_kernel", "conv_tall3_kernel", "conv_s2d3_kernel", "conv64_", "conv_c3_fwd_kernel")      # every forward / data-gradient convolution kernel (conv64_*: all persistent forms)
 
 
 def total_kb(path, counter):
@@ -29,7 +29,8 @@ def norm(name):
     """rocprofv3's demangled kernel name -> the spelling bench.py / fsr_last_kernel use."""
     n = name.replace("void ", "").replace("(anonymous namespace)::", "").split("(")[0]
     n = n.replace("unsigned short", "bf16").replace("_Float16", "f16").replace("float", "f32").replace(" ", "")
-    if n.startswith("conv_tall3_kernel<"):     # its trailing STATS flag: the library's note prints "<...>" / "<...,stats>"
+    if n.startswith("conv_tall3_kernel<"):     # its trailing STATS flag and stride: the library's note prints "<...>" / "<...,stats>" / "<...,s2>" / "<...,stats,s2>"
+        n = n.replace(",false,1>", ">").replace(",true,1>", ",stats>").replace(",false,2>", ",s2>").replace(",true,2>", ",stats,s2>")
         n = n.replace(",false>", ">").replace(",true>", ",stats>")
     return n
 
