@@ -72,7 +72,7 @@ SIGNATURES = {
     "fsr_pack_conv3x3_c3": (c_int, [c_int, P, c_int, P, c_int, P]),
     "fsr_tanh_bwd_image": (c_int, [P, c_ll, c_ll, c_ll, c_ll, P, c_int, c_int, c_int, P, P, P, P]),
     "fsr_conv3x3_c3_fwd": (c_int, [c_int, P, c_ll, c_ll, c_ll, c_ll, c_int, c_int, c_int, c_float, c_float, c_float, c_float,
-                                   c_float, c_float, P, P, c_int, c_float, P, c_int, P, P, P]),
+                                   c_float, c_float, P, P, c_int, c_float, P, c_int, P, P, P, P]),
     "fsr_conv3x3_c3_wgrad_workspace": (ctypes.c_size_t, [c_int, c_int, c_int, c_int]),
     "fsr_conv3x3_c3_wgrad": (c_int, [c_int, P, c_ll, c_ll, c_ll, c_ll, c_int, c_int, c_int, c_float, c_float, c_float,
                                      c_float, c_float, c_float, P, c_int, P, P, P, c_int, P]),

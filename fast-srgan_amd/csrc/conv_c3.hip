@@ -34,6 +34,7 @@ struct C3Args {
   int cout;             // multiple of 16
   void* out;            // forward: [N,H,W,cout] T
   void* preact;
+  unsigned char* signs; // forward, optional: [N,H,W,cout/8] -- bit (c & 7) of byte c >> 3 = (out[c] > 0), read by conv_s2d3.hip as the activation-gradient mask
   const void* dz;       // wgrad: [N,H,W,cout] T
   float* ws;            // wgrad partials [slab][cout][32]
   int tiles_x, tiles_y, tiles_per_slab, ntiles;
@@ -187,8 +188,14 @@ __global__ __launch_bounds__(256) void conv_c3_fwd_kernel(const C3Args a) {
               lo[q] = fmaxf(lo[q], 0.f) + slope * fminf(lo[q], 0.f);
               hi[q] = fmaxf(hi[q], 0.f) + slope * fminf(hi[q], 0.f);
             }
-            fsr_st<4>((u32x4*)(outp + off + p * 32), (u32x4)((u32x4){pack2<T>(lo[0], lo[1]), pack2<T>(lo[2], lo[3]),
-                                                     pack2<T>(hi[0], hi[1]), pack2<T>(hi[2], hi[3])}));
+            const u32x4 pk = (u32x4){pack2<T>(lo[0], lo[1]), pack2<T>(lo[2], lo[3]), pack2<T>(hi[0], hi[1]), pack2<T>(hi[2], hi[3])};
+            fsr_st<4>((u32x4*)(outp + off + p * 32), pk);
+            if (a.signs) {      // the lane's eight channels nb * 64 + p * 32 + lg * 8 .. + 7 as one byte of sign bits of the STORED values
+              unsigned b = 0u;
+#pragma unroll
+              for (int q = 0; q < 4; ++q) b |= ((int)(pk[q] << 16) > 0 ? 1u << (2 * q) : 0u) | ((int)(pk[q] & 0xffff0000u) > 0 ? 2u << (2 * q) : 0u);
+              a.signs[(((size_t)n * a.H + gy) * a.W + gx) * (a.cout >> 3) + nb * 8 + p * 4 + lg] = (unsigned char)b;
+            }
           }
         }
         continue;
@@ -423,7 +430,7 @@ extern "C" int fsr_pack_conv3x3_c3(int dtype, const float* w_oihw, int cout, voi
 extern "C" int fsr_conv3x3_c3_fwd(int dtype, const float* img, long long sn, long long sc, long long sh, long long sw, int n,
                                   int h, int w, float scale0, float scale1, float scale2, float shift0, float shift1,
                                   float shift2, const void* packed_w, const float* bias, int act, float slope, const float* prelu_weight, int cout, void* out,
-                                  void* preact, fsr_stream_t stream_) {
+                                  void* preact, void* signs, fsr_stream_t stream_) {
   C3Args a = {};
   const float scale3[3] = {scale0, scale1, scale2}, shift3[3] = {shift0, shift1, shift2};
   if (int rc = fill_args(a, "fsr_conv3x3_c3_fwd", dtype, img, sn, sc, sh, sw, n, h, w, scale3, shift3, cout)) return rc;
@@ -437,6 +444,8 @@ extern "C" int fsr_conv3x3_c3_fwd(int dtype, const float* img, long long sn, lon
   a.slope = slope;
   a.out = out;
   a.preact = preact;
+  if (signs && (dtype == FSR_F32 || cout % 64 != 0)) return fsr_fail(-2, "fsr_conv3x3_c3_fwd: sign bits are written by the 16-bit kernels for cout %% 64 == 0");
+  a.signs = (unsigned char*)signs;
   a.tiles_x = (w + 15) / 16;
   a.tiles_y = (h + 15) / 16;
   const long long nwg = (long long)a.tiles_x * a.tiles_y * n;

@@ -330,6 +330,22 @@ __global__ __launch_bounds__(S2D_NW * 64, 2) void conv_s2d3_kernel(const ConvKAr
     const unsigned mb0 = (unsigned)(ct * 64 + ((qt ^ frt) << 4)), mb1 = mb0 + 16 * 64;       // mask, load layout
     const int gb = cur.gx0 + ct;
     const int cob = cur.nb * BN + wco * 32 + qt * 8;
+    // sign-bit mask: all eight words of the lane (class x fragment) are requested BEFORE the first store -- a load issued after a
+    // store waits for that store (one counter), and loaded one by one inside the loop each would be a serial memory round trip
+    unsigned sbits[4][MB];
+    if (maskp && a.dmask_bits) {
+      static_for<0, 4>([&](auto kc) {
+        constexpr int k = decltype(kc)::value, py = k >> 1, px = k & 1;
+        static_for<0, MB>([&](auto mc) {
+          constexpr int m = decltype(mc)::value;
+          const int ga = cur.gy0 + wpx * 2 * MB + 2 * m + lrow, gba = cur.gx0 + l15;
+          const int oya = 2 * ga + py, oxa = 2 * gba + px;
+          const bool oka = ga < a.IH && gba < a.IW && oya < a.FOH && oxa < a.FOW;
+          const size_t bo = oka ? ((size_t)((cur.img * a.FOH + oya) * a.FOW + oxa) * (unsigned)(a.Cout >> 3) + (unsigned)((cur.nb * BN + wco * 32 + hi * 16) >> 3)) : 0;
+          sbits[k][m] = *(const unsigned short*)((const unsigned char*)a.dmask + bo);     // (an out-of-range lane reads word 0: its result is never stored)
+        });
+      });
+    }
     static_for<0, 4>([&](auto kc) {
       constexpr int k = decltype(kc)::value, py = k >> 1, px = k & 1;
       static_for<0, MB>([&](auto mc) {
@@ -343,7 +359,15 @@ __global__ __launch_bounds__(S2D_NW * 64, 2) void conv_s2d3_kernel(const ConvKAr
         float v[16];
 #pragma unroll
         for (int e = 0; e < 16; ++e) v[e] = acc[k][m][e];
-        if (maskp) {   // fused activation backward of the producing layer: dz = dx * act'(y), y = its saved output
+        if (maskp && a.dmask_bits) {
+          // the producing layer's activation backward from its SIGN BITS ([N][FOH][FOW][Cout / 8], written by conv_c3_fwd_kernel): two
+          // bytes per lane in accumulator layout instead of 32 -- the 64-channel 384^2 tensor of the discriminator's neck is 1.2 GB at
+          // batch 64, its sign bits 75 MB
+          const unsigned bits = sbits[k][m];
+          const float ms = a.dmask_slope;
+#pragma unroll
+          for (int e = 0; e < 16; ++e) v[e] = ((bits >> e) & 1u) ? v[e] : v[e] * ms;
+        } else if (maskp) {   // fused activation backward of the producing layer: dz = dx * act'(y), y = its saved output
           u32x4 m0 = {0u, 0u, 0u, 0u}, m1 = {0u, 0u, 0u, 0u};
           if (ok0) m0 = *(const u32x4*)(maskp + off0);
           if (ok1) m1 = *(const u32x4*)(maskp + off1);

@@ -110,8 +110,12 @@ static int conv3x3_impl(const fsr_conv_desc* d, const void* in, const void* pack
   a.oscale = oscale;
   a.dmask = dact_mask;
   a.dmask_slope = dact_slope;
-  a.dmask_add = (dact_mask && d->mask_is_addend) ? 1 : 0;
+  a.dmask_add = (dact_mask && d->mask_is_addend == 1) ? 1 : 0;
+  a.dmask_bits = (dact_mask && d->mask_is_addend == 2) ? 1 : 0;
   if (d->mask_is_addend && !dact_mask) return fsr_fail(-1, "fsr_conv3x3: mask_is_addend needs the dact_mask tensor");
+  if (d->mask_is_addend < 0 || d->mask_is_addend > 2) return fsr_fail(-2, "fsr_conv3x3: mask_is_addend must be 0, 1 or 2");
+  if (a.dmask_bits && (d->mode != FSR_CONV_DGRAD || d->stride != 2 || d->dtype == FSR_F32 || d->cout % 64 != 0))
+    return fsr_fail(-2, "fsr_conv3x3: a sign-bit mask (mask_is_addend = 2) is read by the stride-2 data gradients of the 16-bit modes, cout %% 64 == 0");
   a.stats = stats ? (float*)scratch : nullptr;   // the kernels write per-workgroup partials; finished below
   a.stats_P_max = stats ? (int)stats_slots_bound(d) : 0;   // launchers compare their slot count with this BEFORE launching
   a.query = query_block ? 1 : 0;
@@ -207,6 +211,7 @@ static int conv3x3_enqueue(const fsr_conv_desc* d, ConvKArgs& a, hipStream_t str
       return rc < 0 ? rc : 0;
     }
   }
+  if (a.dmask_bits) return fsr_fail(-2, "fsr_conv3x3: no kernel with a sign-bit mask takes this launch");
   // The four classes go out as ONE launch, the 4-tap class first (longest workgroups first).
   ConvKArgs cls[4];
   int ncls = 0;

@@ -20,6 +20,7 @@ struct ConvKArgs {
   const void* dmask;    // optional tensor like `out`: result *= (dmask > 0 ? 1 : dmask_slope) (fused activation backward)
   float dmask_slope;
   int dmask_add;        // the dmask tensor is an addend (result += dmask) instead of a gate
+  int dmask_bits;       // dmask is a packed sign-bit tensor [N][FOH][FOW][Cout / 8] (bit = the producing layer's output > 0): conv_s2d3.hip
   float* stats;         // optional per-workgroup partials [N][stats_P][Cout][2] (sum, sum of squares of the pre-activation)
   int stats_P;          // partial slots per image (set by the launcher: tiles per image, or tile ranges per image)
   int stats_P_max;      // slots per image the caller's scratch buffer holds (fsr_conv3x3_scratch): checked BEFORE a launch

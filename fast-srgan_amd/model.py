@@ -163,7 +163,7 @@ class Discriminator(torch.nn.Module):
         cd = self.compute
         # the neck's LeakyReLU(0.2) backward is applied by stem.0's data-gradient epilogue (mask = the neck output it
         # saved as its input); the neck then only needs the column sums of that gradient for its bias
-        self._cfg_neck = ops.ConvCfg(cd, act=L.ACT_LEAKY, slope=0.2, image_in=True, act_bwd_by_consumer=True)
+        self._cfg_neck = ops.ConvCfg(cd, act=L.ACT_LEAKY, slope=0.2, image_in=True, act_bwd_by_consumer=True, emit_signs=True)
         self._cfg_s = {1: ops.ConvCfg(cd, stride=1, stats=True), 2: ops.ConvCfg(cd, stride=2, stats=True)}
         self._cfg_s0 = ops.ConvCfg(cd, stride=2, stats=True, input_act_bwd=0.2)
 

@@ -197,6 +197,7 @@ def _const_vec(values, device):
     return t
 
 USE_LIN_PACK = os.environ.get("FSR_PACK_LIN", "1") != "0"   # A/B switch: 0 = every launch reads the standard filter pack
+USE_SIGN_BITS = os.environ.get("FSR_SIGN_BITS", "1") != "0"   # A/B switch: 0 = activation-gradient masks are always the saved tensors
 USE_C3_KERNELS = True   # tests flip this to compare the first-layer kernels with the padded-tensor path
 
 # bench.py sets this to a list to collect (start_event, end_event, algorithmic_flops, algorithmic_bytes, kernel name, kind)
@@ -352,11 +353,12 @@ class _on_wgrad_stream:
 # ---------------------------------------------------------------------------------- raw launches
 def conv3x3_raw(cd, x, wpk, cout, *, mode=L.CONV_FWD, out_hw=None, stride=1, bias=None, act=L.ACT_NONE, slope=0.0,
                 prelu=None, oscale=None, pixel_shuffle=False, in_pixel_shuffled=False, out_f32=False, want_stats=False,
-                want_preact=False, alg_k=None, dact_mask=None, dact_slope=0.0, out_u8=False, pool2=False, dact_add=False):
+                want_preact=False, alg_k=None, dact_mask=None, dact_slope=0.0, out_u8=False, pool2=False, dact_add=False, dact_bits=False):
     """One fsr_conv3x3 launch.  x: (N,IH,IW,Cin) [or its depth-to-space form when in_pixel_shuffled].
     out_u8 (tanh heads): the output is the finished uint8 HWC image of inference.py:53-56.
     pool2 (no-grad passes): the output is MaxPool2d(2,2) of the activated result; the full-resolution tensor is never written.
-    dact_add: `dact_mask` is ADDED to the result (the gradient of a skip connection) instead of gating it."""
+    dact_add: `dact_mask` is ADDED to the result (the gradient of a skip connection) instead of gating it.
+    dact_bits: `dact_mask` is the packed sign-bit tensor (N,OH,OW,Cout/8) uint8 of the producing layer's output (stride-2 data gradients)."""
     _check_dev(x)
     n = x.shape[0]
     if in_pixel_shuffled:
@@ -373,7 +375,7 @@ def conv3x3_raw(cd, x, wpk, cout, *, mode=L.CONV_FWD, out_hw=None, stride=1, bia
     pre = torch.empty(oshape, dtype=odt, device=x.device) if want_preact else None
     stats = _assigned((n, cout, 2), x.device) if want_stats else None
     d = L.ConvDesc(cd.code, mode, n, ih, iw, cin, oh, ow, cout, stride, act, float(slope), int(pixel_shuffle),
-                   int(in_pixel_shuffled), L.OUT_U8 if out_u8 else int(out_f32), int(pool2), int(bool(dact_add)), 0)
+                   int(in_pixel_shuffled), L.OUT_U8 if out_u8 else int(out_f32), int(pool2), 2 if dact_bits else int(bool(dact_add)), 0)
     if isinstance(wpk, FilterSpec):     # pack in the layout the kernel this launch dispatches reads
         opt = ((L.OPT_BIAS if bias is not None else 0) | (L.OPT_PRELU if prelu is not None else 0) | (L.OPT_OSCALE if oscale is not None else 0)
                | (L.OPT_MASK if dact_mask is not None else 0) | (L.OPT_PREACT if want_preact else 0) | (L.OPT_STATS if want_stats else 0))
@@ -450,7 +452,7 @@ class ConvCfg:
 
     def __init__(self, cd, *, stride=1, act=L.ACT_NONE, slope=0.0, pixel_shuffle=False, stats=False, image_in=False,
                  in_scale=(1.0, 1.0, 1.0), in_shift=(0.0, 0.0, 0.0), tanh_head=False, input_act_bwd=None,
-                 act_bwd_by_consumer=False, u8_head=False, pool_after=False, n_alias=0):
+                 act_bwd_by_consumer=False, u8_head=False, pool_after=False, n_alias=0, emit_signs=False):
         # u8_head (inference only, with tanh_head): the head stores the finished uint8 HWC frame instead of float
         # input_act_bwd = slope: the data-gradient launch also applies the backward of the ReLU (0.0) / LeakyReLU
         #   that produced this conv's input (the mask is the saved input itself), so the tensor it returns is
@@ -470,6 +472,10 @@ class ConvCfg:
         # (model.py:69, :115).  Their gradients come back to THIS function's backward, whose data-gradient launch adds the
         # first one in its epilogue (fsr_conv_desc.mask_is_addend): autograd has nothing left to accumulate on the block input.
         self.n_alias = n_alias
+        # emit_signs (first-layer kernels, training, 16-bit): the forward also writes the SIGN BITS of its output (N,H,W,Cout/8 uint8)
+        # and hangs them on the output tensor (`_fsr_signs`); a stride-2 consumer with input_act_bwd then reads those -- a sixteenth
+        # of the bytes -- as its activation-gradient mask instead of the tensor itself
+        self.emit_signs = emit_signs
 
 
 class Conv3x3Fn(torch.autograd.Function):
@@ -493,6 +499,8 @@ class Conv3x3Fn(torch.autograd.Function):
                 and USE_C3_KERNELS):
             return Conv3x3Fn._forward_c3(ctx, x, weight, bias, prelu, cfg)
         ctx.c3 = False
+        # sign bits of the input (hung on it by the first-layer kernel that produced it): the stride-2 data gradient's mask
+        ctx.in_signs = getattr(x, "_fsr_signs", None) if (cfg.input_act_bwd is not None and cfg.stride == 2 and cd.name != "f32") else None
         if cfg.image_in:
             xin = image_to_nhwc(cd, x, cfg.in_scale, cfg.in_shift)
         else:
@@ -548,14 +556,18 @@ class Conv3x3Fn(torch.autograd.Function):
         b32 = bias if bias is None or bias.dtype == torch.float32 else bias.float()
         out = torch.empty((n, h, w, cout), dtype=cd.torch_dtype, device=x.device)
         pre = torch.empty_like(out) if want_pre else None
+        signs = (torch.empty((n, h, w, cout // 8), dtype=torch.uint8, device=x.device)
+                 if (cfg.emit_signs and USE_SIGN_BITS and training and cd.name != "f32" and cout % 64 == 0) else None)
         sn, sc, sh, sw = x.stride()
         prof = PROFILE_CONV
         if prof is not None:
             ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             ev0.record()
         L.check(L.lib().fsr_conv3x3_c3_fwd(cd.code, _p(x), sn, sc, sh, sw, n, h, w, *cfg.in_scale, *cfg.in_shift, _p(wpk),
-                                           _p(b32), cfg.act, float(cfg.slope), _p(prelu), cout, _p(out), _p(pre), _stream()),
+                                           _p(b32), cfg.act, float(cfg.slope), _p(prelu), cout, _p(out), _p(pre), _p(signs), _stream()),
                 "fsr_conv3x3_c3_fwd")
+        if signs is not None:
+            out._fsr_signs = signs
         if prof is not None:
             ev1.record()
             nbytes = x.numel() * 4 + out.numel() * out.element_size() * (2 if want_pre else 1) + wpk.numel() * wpk.element_size()
@@ -636,12 +648,16 @@ class Conv3x3Fn(torch.autograd.Function):
                 kpad = dz.shape[3] * (4 if cfg.pixel_shuffle else 1)
                 wpk = FilterSpec(weight, L.PACK_DGRAD_PS if cfg.pixel_shuffle else L.PACK_DGRAD, kpad)
                 mask = xin if cfg.input_act_bwd is not None else None
+                bits = getattr(ctx, "in_signs", None) if (mask is not None and cin_pad % 64 == 0) else None
+                if bits is not None:
+                    mask = bits
                 addend = None
                 if skips:       # dL/dx = conv_dgrad(dz) + dL/d(skip): the first skip gradient rides in the launch's epilogue
                     addend = skips[0] if skips[0].is_contiguous() else skips[0].contiguous()
                 dx, _, _ = conv3x3_raw(cd, dz, wpk, cin_pad, mode=L.CONV_DGRAD, out_hw=(ih, iw), stride=cfg.stride,
                                        in_pixel_shuffled=cfg.pixel_shuffle, alg_k=cout, dact_mask=addend if addend is not None else mask,
-                                       dact_slope=cfg.input_act_bwd or 0.0, dact_add=addend is not None)
+                                       dact_slope=cfg.input_act_bwd or 0.0, dact_add=addend is not None,
+                                       dact_bits=(bits is not None and addend is None))
                 for t in skips[1:]:
                     dx += t
         dw = None
@@ -703,7 +719,7 @@ def _head_backward_c3(ctx, g):
             ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             ev0.record()
         L.check(lib.fsr_conv3x3_c3_fwd(cd.code, _p(dz_img), *img_strides, n, ih, iw, *one, *zero, _p(wpk), None, L.ACT_NONE, 0.0, None,
-                                       cin_pad, _p(dx), None, st), "fsr_conv3x3_c3_fwd")
+                                       cin_pad, _p(dx), None, None, st), "fsr_conv3x3_c3_fwd")
         if prof is not None:
             ev1.record()
             prof.append((ev0, ev1, 2.0 * n * ih * iw * cin * 27, dz_img.numel() * 4 + dx.numel() * dx.element_size(), "conv_c3_fwd_kernel", "dgrad"))

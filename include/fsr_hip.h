@@ -122,7 +122,9 @@ typedef struct fsr_conv_desc {
   int in_pixel_shuffled;
   int out_f32;
   int pool2; /* FWD, 16-bit dtypes, no pixel shuffle: out is the MaxPool2d(2,2) of the activated result, [n,oh/2,ow/2,cout] */
-  int mask_is_addend; /* dact_mask is ADDED to the result instead of gating it (see below) */
+  int mask_is_addend; /* 0: dact_mask gates the result by its sign; 1: it is ADDED to the result instead (see below); 2 (stride-2 data
+                         gradients, 16-bit dtypes): it is the PACKED SIGN-BIT tensor [n][oh][ow][cout / 8] of the producing layer's output
+                         (bit c & 7 of byte c >> 3 = output > 0: fsr_conv3x3_c3_fwd's `signs`), gating like 0 at a sixteenth of the bytes */
   int pack_lin; /* 0: packed_w is fsr_pack_conv3x3's layout; 64 / 128: fsr_pack_conv3x3_lin's with that block (must equal fsr_conv3x3_pack_block) */
 } fsr_conv_desc;
 
@@ -222,7 +224,9 @@ int fsr_u8_to_image(const uint8_t* frames, float* img, long long count, fsr_stre
  * round_dtype(img*scale[c] + shift[c]) -- the value fsr_image_to_nhwc would have stored -- as the conv input.
  * cout must be a multiple of 16.
  *   fsr_pack_conv3x3_c3 : OIHW float [cout][3][3][3] -> `dtype` [round_up(cout,16)][32], k = (ky*3+kx)*3 + ci.
- *   fsr_conv3x3_c3_fwd  : out[n,h,w,cout] = act(conv + bias); act NONE/RELU/LEAKY/PRELU; preact optional.
+ *   fsr_conv3x3_c3_fwd  : out[n,h,w,cout] = act(conv + bias); act NONE/RELU/LEAKY/PRELU; preact optional; signs optional (16-bit
+ *                         dtypes, cout % 64 == 0): uint8 [n,h,w,cout/8], bit c & 7 of byte c >> 3 = (out[..., c] > 0) -- the activation-gradient
+ *                         mask of the layer as fsr_conv3x3's mask_is_addend = 2 reads it.
  *   fsr_conv3x3_c3_wgrad: dw_oihw (float [cout][3][3][3]) += d loss / d weight for dz [n,h,w,cout] `dtype`;
  *                         dbias (optional, float [cout]) += per-channel sums of dz (the bias gradient: a column of
  *                         ones in the padded K dimension of the same MFMAs);
@@ -236,7 +240,7 @@ int fsr_pack_conv3x3_c3(int dtype, const float* w_oihw, int cout, void* packed, 
 int fsr_conv3x3_c3_fwd(int dtype, const float* img, long long sn, long long sc, long long sh, long long sw, int n, int h,
                        int w, float scale0, float scale1, float scale2, float shift0, float shift1, float shift2,
                        const void* packed_w, const float* bias, int act, float slope, const float* prelu_weight, int cout,
-                       void* out, void* preact, fsr_stream_t stream);
+                       void* out, void* preact, void* signs, fsr_stream_t stream);
 size_t fsr_conv3x3_c3_wgrad_workspace(int n, int h, int w, int cout);
 int fsr_conv3x3_c3_wgrad(int dtype, const float* img, long long sn, long long sc, long long sh, long long sw, int n, int h,
                          int w, float scale0, float scale1, float scale2, float shift0, float shift1, float shift2,

@@ -392,9 +392,9 @@ def test_first_layer_kernels_reject_bad_arguments(dev):
     out = torch.zeros(1, 8, 8, 24).to(dev)
     wpk = torch.zeros(32 * 32).to(dev)
     args = (img.data_ptr(), 192, 64, 8, 1, 1, 8, 8, 1.0, 1.0, 1.0, 0.0, 0.0, 0.0)
-    assert lib.fsr_conv3x3_c3_fwd(cd.code, *args, wpk.data_ptr(), None, L.ACT_NONE, 0.0, None, 24, out.data_ptr(), None, None) < 0
+    assert lib.fsr_conv3x3_c3_fwd(cd.code, *args, wpk.data_ptr(), None, L.ACT_NONE, 0.0, None, 24, out.data_ptr(), None, None, None) < 0
     assert b"multiple of 16" in lib.fsr_last_error()
-    assert lib.fsr_conv3x3_c3_fwd(cd.code, *args, wpk.data_ptr(), None, L.ACT_PRELU, 0.0, None, 16, out.data_ptr(), None, None) < 0
+    assert lib.fsr_conv3x3_c3_fwd(cd.code, *args, wpk.data_ptr(), None, L.ACT_PRELU, 0.0, None, 16, out.data_ptr(), None, None, None) < 0
     assert lib.fsr_conv3x3_c3_wgrad(cd.code, *args, None, 16, out.data_ptr(), None, out.data_ptr(), 0, None) < 0
     assert lib.fsr_conv3x3_c3_wgrad_workspace(0, 8, 8, 16) == 0
 
@@ -795,6 +795,42 @@ def test_conv_tall3(dev, cdn, cin, cout, variant, rows, monkeypatch):
     assert relerr(st[..., 1], (pre * pre).sum((2, 3))) < tol(cdn, 1e-4, 1e-3)
     _, _, stats2 = ops.conv3x3_raw(cd, xd, wpk, cout, bias=bias.to(dev), act=L.ACT_LEAKY, slope=0.2, want_stats=True)
     assert torch.equal(stats2.cpu(), st)                        # no atomics: bit-reproducible
+
+
+@pytest.mark.parametrize("cdn", ["bf16", "f16"])
+def test_sign_bit_mask_first_layer_to_stride2_data_gradient(dev, cdn, monkeypatch):
+    """The discriminator's neck -> block 0 (model.py:143-152): fsr_conv3x3_c3_fwd also writes the SIGN BITS of its LeakyReLU output
+    ((N,H,W,8) bytes for 64 channels) and conv_s2d3 reads them (mask_is_addend = 2) as the activation-gradient mask instead of the
+    64-channel tensor: the bits equal (out > 0), and the masked data gradient is BIT-IDENTICAL to the one gated by the tensor."""
+    monkeypatch.setenv("FSR_PERSIST_CUS", "2" if _big(dev) else "1")
+    cd = ops.Compute(cdn)
+    torch.manual_seed(17)
+    n, h, w = (3, 37, 46) if _big(dev) else (1, 19, 22)
+    img = (torch.rand(n, 3, h, w) * 2 - 1).to(dev)
+    wn = (torch.randn(64, 3, 3, 3) * 0.3).to(dev)
+    bn = (torch.randn(64) * 0.1).to(dev)
+    out = torch.empty((n, h, w, 64), dtype=cd.torch_dtype, device=dev)
+    signs = torch.zeros((n, h, w, 8), dtype=torch.uint8, device=dev)
+    wpk = ops.packed_filter(cd, wn, ops.PACK_C3, 32)
+    L.check(L.lib().fsr_conv3x3_c3_fwd(cd.code, img.data_ptr(), *img.stride(), n, h, w, 1.0, 1.0, 1.0, 0.0, 0.0, 0.0, wpk.data_ptr(), bn.data_ptr(),
+                                       L.ACT_LEAKY, 0.2, None, 64, out.data_ptr(), None, signs.data_ptr(), ops._stream()), "fsr_conv3x3_c3_fwd")
+    o = out.float().cpu()
+    bits = signs.cpu()
+    want = torch.zeros_like(bits)
+    for c in range(64):
+        want[..., c >> 3] |= ((o[..., c] > 0).to(torch.uint8) << (c & 7))
+    assert torch.equal(bits, want)
+    assert 0.2 < float((o > 0).float().mean()) < 0.8
+    # block 0: 64 -> 64, stride 2; its data gradient gated by the neck's output vs by the neck's sign bits
+    wt = _q(torch.randn(64, 64, 3, 3) * 0.05, cd).to(dev)
+    oh, ow = (h - 1) // 2 + 1, (w - 1) // 2 + 1
+    dy = _nhwc(_q(torch.randn(n, 64, oh, ow), cd), cd, dev)
+    wpd = ops.packed_filter(cd, wt, L.PACK_DGRAD, 64)
+    d0, _, _ = ops.conv3x3_raw(cd, dy, wpd, 64, mode=L.CONV_DGRAD, out_hw=(h, w), stride=2, dact_mask=out, dact_slope=0.2)
+    assert L.lib().fsr_last_kernel().decode().startswith("conv_s2d3_kernel")
+    d1, _, _ = ops.conv3x3_raw(cd, dy, wpd, 64, mode=L.CONV_DGRAD, out_hw=(h, w), stride=2, dact_mask=signs, dact_slope=0.2, dact_bits=True)
+    assert torch.equal(d0.float().cpu(), d1.float().cpu())
+    assert float(d0.float().abs().max()) > 0
 
 
 @pytest.mark.parametrize("case", ["fwd128", "fwd_s2_stats", "dgrad_narrow", "dgrad_s2", "dgrad_s2_64", "fwd64", "fwd_f32"])

@@ -72,6 +72,7 @@ def main():
     ap.add_argument("--miopen", action="store_true")
     ap.add_argument("--dtype", default="bf16")
     ap.add_argument("--filter", default="")
+    ap.add_argument("--mask", action="store_true", help="data gradients with the fused activation-gradient mask (the saved forward input)")
     args = ap.parse_args()
     cd = ops.Compute(args.dtype)
     dev = torch.device("cuda:0")
@@ -98,8 +99,9 @@ def main():
             res += [0, 0]
         if "dgrad" in only:
             wpd = ops.packed_filter(cd, wt, L.PACK_DGRAD_PS if ps else L.PACK_DGRAD, cout_pad)
+            mask = x if (args.mask and cin > 3) else None      # the fused activation gradient: mask = the saved forward input
             t = timeit(lambda: ops.conv3x3_raw(cd, dy, wpd, cin_pad if cin > 3 else 3, mode=L.CONV_DGRAD, out_hw=(h, w),
-                                               stride=stride, in_pixel_shuffled=ps, out_f32=(cin == 3)))
+                                               stride=stride, in_pixel_shuffled=ps, out_f32=(cin == 3), dact_mask=mask, dact_slope=0.2))
             res += [t * 1e3, gflop / t]
         else:
             res += [0, 0]
