@@ -78,7 +78,8 @@ SIGNATURES = {
                                      c_float, c_float, c_float, P, c_int, P, P, P, c_int, P]),
     "fsr_tanh_bwd_scratch": (c_size_t, []),
     "fsr_tanh_bwd_to_nhwc": (c_int, [c_int, P, c_ll, c_ll, c_ll, c_ll, P, c_int, c_int, c_int, P, c_int, P, P, P]),
-    "fsr_maxpool2_fwd": (c_int, [c_int, P, P, c_int, c_int, c_int, c_int, P]),
+    "fsr_maxpool2_fwd": (c_int, [c_int, P, P, P, c_int, c_int, c_int, c_int, P]),
+    "fsr_maxpool2_bwd_argmax": (c_int, [c_int, P, P, P, c_int, c_int, c_int, c_int, c_int, P]),
     "fsr_maxpool2_bwd": (c_int, [c_int, P, P, P, P, c_int, c_int, c_int, c_int, c_int, P]),
     "fsr_conv1x1_c1_fwd": (c_int, [c_int, P, P, P, P, c_int, c_int, P]),
     "fsr_conv1x1_c1_bwd_scratch": (c_size_t, [c_int]),

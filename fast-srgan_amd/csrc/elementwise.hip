@@ -444,8 +444,12 @@ __global__ __launch_bounds__(256) void u8_to_image_kernel(const unsigned char* _
 
 // ------------------------------------------------------------------ MaxPool2d(2,2)
 // Grid = (output rows n*oh, column blocks); 32-bit index arithmetic per row.
+// `idx` (optional, training): one byte per pooled element -- bits 0..1 = which of the four inputs (row-major, the FIRST one equal
+// to the maximum) is the arg-max, bit 2 = maximum > 0 -- is all maxpool2_bwd_kernel needs: the backward pass then reads the pooled
+// gradient and these bytes (0.375 tensor-equivalents) instead of the gradient, the pooled output and the full-resolution input (1.5).
 template <typename T>
-__global__ __launch_bounds__(256) void maxpool2_fwd_kernel(const T* __restrict__ x, T* __restrict__ y, int h, int w, int c) {
+__global__ __launch_bounds__(256) void maxpool2_fwd_kernel(const T* __restrict__ x, T* __restrict__ y, unsigned char* __restrict__ idx,
+                                                           int h, int w, int c) {
   constexpr int E = V16<T>::N;
   const int cu = c / E, oh = h / 2, ow = w / 2;
   const int row = blockIdx.x;
@@ -462,9 +466,62 @@ __global__ __launch_bounds__(256) void maxpool2_fwd_kernel(const T* __restrict__
     V16<T>::ld(s + c, b);
     V16<T>::ld(s + rs, d);
     V16<T>::ld(s + rs + c, e);
+    unsigned code[E];
 #pragma unroll
-    for (int i = 0; i < E; ++i) a[i] = fmaxf(fmaxf(a[i], b[i]), fmaxf(d[i], e[i]));
+    for (int i = 0; i < E; ++i) {
+      const float m = fmaxf(fmaxf(a[i], b[i]), fmaxf(d[i], e[i]));
+      code[i] = (a[i] == m ? 0u : (b[i] == m ? 1u : (d[i] == m ? 2u : 3u))) | (m > 0.f ? 4u : 0u);
+      a[i] = m;
+    }
     V16<T>::st(dst + (size_t)u * E, a);
+    if (idx) {
+      unsigned char* ip = idx + (size_t)row * ow * c + (size_t)u * E;
+      if constexpr (E == 8) {
+        *(u32x2*)ip = (u32x2){code[0] | (code[1] << 8) | (code[2] << 16) | (code[3] << 24), code[4] | (code[5] << 8) | (code[6] << 16) | (code[7] << 24)};
+      } else {
+        *(unsigned*)ip = code[0] | (code[1] << 8) | (code[2] << 16) | (code[3] << 24);
+      }
+    }
+  }
+}
+
+// backward from the arg-max bytes of the forward pass: dx[k] = (k == arg-max && (!relu_mask || max > 0)) ? g : 0
+template <typename T>
+__global__ __launch_bounds__(256) void maxpool2_bwd_idx_kernel(const T* __restrict__ g, const unsigned char* __restrict__ idx,
+                                                               T* __restrict__ dx, int h, int w, int c, int relu_mask) {
+  constexpr int E = V16<T>::N;
+  const int cu = c / E, oh = h / 2, ow = w / 2;
+  const int row = blockIdx.x;
+  const int n = row / oh, oy = row - n * oh;
+  const size_t in0 = ((size_t)n * h + 2 * oy) * w * c;
+  const size_t out0 = (size_t)row * ow * c;
+  const unsigned units = (unsigned)ow * cu;
+  const size_t rs = (size_t)w * c;
+  for (unsigned u = blockIdx.y * 256 + threadIdx.x; u < units; u += gridDim.y * 256) {
+    const unsigned ox = u / cu, un = u - ox * cu;
+    const size_t base = in0 + (size_t)(2 * ox) * c + un * E;
+    float gv[E], o[E];
+    unsigned code[E];
+    V16<T>::ld(g + out0 + (size_t)u * E, gv);
+    const unsigned char* ip = idx + out0 + (size_t)u * E;
+    if constexpr (E == 8) {
+      const u32x2 t = *(const u32x2*)ip;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        code[i] = (t.x >> (8 * i)) & 0xffu;
+        code[4 + i] = (t.y >> (8 * i)) & 0xffu;
+      }
+    } else {
+      const unsigned t = *(const unsigned*)ip;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) code[i] = (t >> (8 * i)) & 0xffu;
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+#pragma unroll
+      for (int i = 0; i < E; ++i) o[i] = ((code[i] & 3u) == (unsigned)k && (!relu_mask || (code[i] & 4u))) ? gv[i] : 0.f;
+      V16<T>::st(dx + base + (size_t)(k >> 1) * rs + (k & 1) * c, o);
+    }
   }
 }
 
@@ -722,15 +779,27 @@ extern "C" int fsr_tanh_bwd_image(const float* g, long long sn, long long sc, lo
   return 0;
 }
 
-extern "C" int fsr_maxpool2_fwd(int dtype, const void* x, void* y, int n, int h, int w, int c, fsr_stream_t stream_) {
+extern "C" int fsr_maxpool2_fwd(int dtype, const void* x, void* y, void* argmax, int n, int h, int w, int c, fsr_stream_t stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   if (!x || !y) return fsr_fail(-1, "fsr_maxpool2_fwd: null argument");
   if (int rc = check_c("fsr_maxpool2_fwd", dtype, c)) return rc;
   if ((h | w) & 1) return fsr_fail(-2, "fsr_maxpool2_fwd: odd extent %dx%d", h, w);
   const int rowunits = (w / 2) * (c / (dtype != FSR_F32 ? 8 : 4));
   FSR_DISPATCH_T(dtype, hipLaunchKernelGGL(maxpool2_fwd_kernel<T>, dim3(n * (h / 2), row_blocks(rowunits)), dim3(256), 0,
-                                           stream, P<T>(x), P<T>(y), h, w, c);)
+                                           stream, P<T>(x), P<T>(y), (unsigned char*)argmax, h, w, c);)
   return fsr_check_launch("maxpool2_fwd_kernel");
+}
+
+extern "C" int fsr_maxpool2_bwd_argmax(int dtype, const void* g, const void* argmax, void* dx, int n, int h, int w, int c,
+                                       int relu_mask, fsr_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  if (!g || !argmax || !dx) return fsr_fail(-1, "fsr_maxpool2_bwd_argmax: null argument");
+  if (int rc = check_c("fsr_maxpool2_bwd_argmax", dtype, c)) return rc;
+  if ((h | w) & 1) return fsr_fail(-2, "fsr_maxpool2_bwd_argmax: odd extent %dx%d", h, w);
+  const int rowunits = (w / 2) * (c / (dtype != FSR_F32 ? 8 : 4));
+  FSR_DISPATCH_T(dtype, hipLaunchKernelGGL(maxpool2_bwd_idx_kernel<T>, dim3(n * (h / 2), row_blocks(rowunits)), dim3(256), 0,
+                                           stream, P<T>(g), (const unsigned char*)argmax, P<T>(dx), h, w, c, relu_mask);)
+  return fsr_check_launch("maxpool2_bwd_idx_kernel");
 }
 
 extern "C" int fsr_maxpool2_bwd(int dtype, const void* g, const void* x, const void* y, void* dx, int n, int h, int w,

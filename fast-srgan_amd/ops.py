@@ -198,6 +198,7 @@ def _const_vec(values, device):
 
 USE_LIN_PACK = os.environ.get("FSR_PACK_LIN", "1") != "0"   # A/B switch: 0 = every launch reads the standard filter pack
 USE_SIGN_BITS = os.environ.get("FSR_SIGN_BITS", "1") != "0"   # A/B switch: 0 = activation-gradient masks are always the saved tensors
+USE_POOL_ARGMAX = os.environ.get("FSR_POOL_ARGMAX", "1") != "0"   # A/B switch: 0 = the pool backward re-reads its input and output
 USE_C3_KERNELS = True   # tests flip this to compare the first-layer kernels with the padded-tensor path
 
 # bench.py sets this to a list to collect (start_event, end_event, algorithmic_flops, algorithmic_bytes, kernel name, kind)
@@ -790,31 +791,43 @@ def instnorm_act(x, stats, res, prelu, cd, act=L.ACT_NONE, slope=0.0):
 
 # ---------------------------------------------------------------------------------- autograd: MaxPool2d(2,2)
 class MaxPool2Fn(torch.autograd.Function):
-    """relu_mask: backward also applies the backward of the ReLU that produced x (see ConvCfg.act_bwd_by_consumer)."""
+    """relu_mask: backward also applies the backward of the ReLU that produced x (see ConvCfg.act_bwd_by_consumer).
+    With gradients enabled the forward also writes one arg-max byte per pooled element (position of the maximum + its sign);
+    the backward pass reads the pooled gradient and those bytes -- not the full-resolution input and the pooled output."""
 
     @staticmethod
-    def forward(ctx, x, cd, relu_mask=False):
+    def forward(ctx, x, cd, relu_mask=False, grad_on=True):
         _check_dev(x)
         n, h, w, c = x.shape
         y = torch.empty((n, h // 2, w // 2, c), dtype=x.dtype, device=x.device)
-        L.check(L.lib().fsr_maxpool2_fwd(cd.code, _p(x), _p(y), n, h, w, c, _stream()), "fsr_maxpool2_fwd")
-        ctx.cd, ctx.relu_mask = cd, relu_mask
-        ctx.save_for_backward(x, y)
+        idx = torch.empty((n, h // 2, w // 2, c), dtype=torch.uint8, device=x.device) if (grad_on and USE_POOL_ARGMAX) else None
+        L.check(L.lib().fsr_maxpool2_fwd(cd.code, _p(x), _p(y), _p(idx), n, h, w, c, _stream()), "fsr_maxpool2_fwd")
+        ctx.cd, ctx.relu_mask, ctx.xshape = cd, relu_mask, tuple(x.shape)
+        ctx.by_idx = idx is not None
+        if idx is not None:
+            ctx.save_for_backward(idx)
+        else:
+            ctx.save_for_backward(x, y)
         return y
 
     @staticmethod
     def backward(ctx, g):
-        x, y = ctx.saved_tensors
-        n, h, w, c = x.shape
+        n, h, w, c = ctx.xshape
         g = g if g.is_contiguous() else g.contiguous()
-        dx = torch.empty_like(x)
-        L.check(L.lib().fsr_maxpool2_bwd(ctx.cd.code, _p(g), _p(x), _p(y), _p(dx), n, h, w, c, int(ctx.relu_mask), _stream()),
-                "fsr_maxpool2_bwd")
-        return dx, None, None
+        dx = torch.empty((n, h, w, c), dtype=g.dtype, device=g.device)
+        if ctx.by_idx:
+            (idx,) = ctx.saved_tensors
+            L.check(L.lib().fsr_maxpool2_bwd_argmax(ctx.cd.code, _p(g), _p(idx), _p(dx), n, h, w, c, int(ctx.relu_mask), _stream()),
+                    "fsr_maxpool2_bwd_argmax")
+        else:
+            x, y = ctx.saved_tensors
+            L.check(L.lib().fsr_maxpool2_bwd(ctx.cd.code, _p(g), _p(x), _p(y), _p(dx), n, h, w, c, int(ctx.relu_mask), _stream()),
+                    "fsr_maxpool2_bwd")
+        return dx, None, None, None
 
 
 def maxpool2(x, cd, relu_mask=False):
-    return MaxPool2Fn.apply(x, cd, relu_mask)
+    return MaxPool2Fn.apply(x, cd, relu_mask, torch.is_grad_enabled())
 
 
 # ---------------------------------------------------------------------------------- autograd: Conv2d(C -> 1, k=1)

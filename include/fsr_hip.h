@@ -250,7 +250,11 @@ int fsr_conv3x3_c3_wgrad(int dtype, const float* img, long long sn, long long sc
 /* ------------------------------------------------------------------ MaxPool2d(2,2) of vgg19.features (model.py:8)
  * x [n,h,w,c] -> y [n,h/2,w/2,c].  Backward routes g to the first maximum in window scan order; with
  * relu_mask != 0 it also applies the backward of the ReLU that produced x (dx = 0 where x <= 0). */
-int fsr_maxpool2_fwd(int dtype, const void* x, void* y, int n, int h, int w, int c, fsr_stream_t stream);
+/* argmax (optional, uint8 [n,h/2,w/2,c]): bits 0..1 = which of the four inputs of the window (row-major, the first one equal to the
+ * maximum) was taken, bit 2 = maximum > 0; fsr_maxpool2_bwd_argmax needs nothing else of the forward pass. */
+int fsr_maxpool2_fwd(int dtype, const void* x, void* y, void* argmax, int n, int h, int w, int c, fsr_stream_t stream);
+int fsr_maxpool2_bwd_argmax(int dtype, const void* g, const void* argmax, void* dx, int n, int h, int w, int c, int relu_mask,
+                            fsr_stream_t stream);
 int fsr_maxpool2_bwd(int dtype, const void* g, const void* x, const void* y, void* dx, int n, int h, int w, int c,
                      int relu_mask, fsr_stream_t stream);
 

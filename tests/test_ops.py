@@ -380,7 +380,7 @@ def test_c_abi_rejects_malformed_calls(dev):
     assert lib.fsr_act_bwd(L.FSR_F32, p, p, L.ACT_RELU, 0.0, None, p, p, None, None, 1, 8, 8, 16, 0, None) < 0   # dbias without scratch
     assert lib.fsr_bce_logits_fwd(p, p, p, None, 64, None) < 0 and lib.fsr_smooth_l1_fwd(L.FSR_F32, p, p, p, None, 64, None) < 0
     assert lib.fsr_instnorm_act_bwd_reduce(L.FSR_F32, p, p, p, L.ACT_NONE, 0.0, None, p, None, None, 1, 64, 16, None) < 0
-    assert lib.fsr_maxpool2_fwd(L.FSR_F32, p, p, 1, 7, 8, 16, None) < 0
+    assert lib.fsr_maxpool2_fwd(L.FSR_F32, p, p, None, 1, 7, 8, 16, None) < 0
     assert lib.fsr_adamw_step(p, p, p, p, 0, 1e-3, 0.9, 0.999, 1e-8, 0.0, p, 1.0, None) < 0
     assert lib.fsr_pack_conv3x3(L.FSR_F32, 9, p, 16, 16, 16, p, None) < 0
 
@@ -470,6 +470,17 @@ def test_maxpool_relu_conv1x1(dev, cdn):
     yr.backward(g)
     nz = (x > 0)  # ties only happen at ReLU zeros, where the ReLU behind the pool kills the gradient anyway
     assert torch.equal(_nchw(xd.grad)[nz], xr.grad[nz])
+    # the backward from the forward's arg-max bytes (the default) equals the one that re-reads input and output, with and
+    # without the fused ReLU backward, bit for bit
+    for relu_mask in (False, True):
+        grads = []
+        for by_idx in (True, False):
+            ops.USE_POOL_ARGMAX = by_idx
+            xa = leaf(_nhwc(x, cd, dev))
+            ops.maxpool2(xa, cd, relu_mask).backward(_nhwc(g, cd, dev))
+            grads.append(xa.grad.float().cpu())
+        ops.USE_POOL_ARGMAX = True
+        assert torch.equal(grads[0], grads[1]), relu_mask
     # 1x1 conv to one logit
     wt, b = torch.randn(1, c, 1, 1) * 0.1, torch.randn(1)
     xd2 = leaf(_nhwc(x, cd, dev))
