@@ -79,6 +79,8 @@ SIGNATURES = {
     "fsr_tanh_bwd_scratch": (c_size_t, []),
     "fsr_tanh_bwd_to_nhwc": (c_int, [c_int, P, c_ll, c_ll, c_ll, c_ll, P, c_int, c_int, c_int, P, c_int, P, P, P]),
     "fsr_maxpool2_fwd": (c_int, [c_int, P, P, P, c_int, c_int, c_int, c_int, P]),
+    "fsr_png_to_npy": (c_int, [P, P, c_int, c_int, P]),
+    "fsr_png_decode_chw": (c_int, [ctypes.c_char_p, P, c_size_t, P, P]),
     "fsr_maxpool2_bwd_argmax": (c_int, [c_int, P, P, P, c_int, c_int, c_int, c_int, c_int, P]),
     "fsr_maxpool2_bwd": (c_int, [c_int, P, P, P, P, c_int, c_int, c_int, c_int, c_int, P]),
     "fsr_conv1x1_c1_fwd": (c_int, [c_int, P, P, P, P, c_int, c_int, P]),

@@ -63,7 +63,7 @@ def build_hip(force=False, verbose=True):
                     print("[fsr build] compiled", os.path.basename(done), flush=True)
     objs = [os.path.join(OBJ, s[:-4] + ".o") for s in srcs]
     if todo or not os.path.exists(LIB):
-        cmd = [hipcc, "--offload-arch=" + ARCH, "-shared", "-fPIC", "-o", LIB] + objs
+        cmd = [hipcc, "--offload-arch=" + ARCH, "-shared", "-fPIC", "-o", LIB] + objs + ["-lz"]      # zlib: csrc/ingest.hip (PNG inflate)
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError("link failed:\n" + r.stderr[-8000:])

@@ -24,17 +24,38 @@ def seed(seed_value):
     random.seed(seed_value)
 
 
-def write_images_to_numpy_arrays(image_list, output_dir):
-    from PIL import Image
+def write_images_to_numpy_arrays(image_list, output_dir, threads=16):
+    """train.py:22-37 of the reference (PIL decode -> RGB -> uint8 CHW -> np.save on a 16-thread pool), done natively:
+    fsr_png_to_npy (csrc/ingest.hip) inflates, unfilters and converts on `threads` worker threads without the GIL and writes the
+    same (3, H, W) uint8 .npy files.  PNG kinds that decoder does not take (interlaced, 16-bit, grey below 8 bits: status -4) --
+    and only those -- go through PIL as in the reference; any other failure is an error."""
+    import ctypes
+
+    from . import _lib as L
     os.makedirs(output_dir, exist_ok=True)
+    image_list = list(image_list)
+    outs = [os.path.join(output_dir, os.path.basename(p).replace(".png", "")) + ".npy" for p in image_list]
+    n = len(image_list)
+    if n == 0:
+        return
+    arr = ctypes.c_char_p * n
+    status = (ctypes.c_int * n)()
+    left = L.lib().fsr_png_to_npy(arr(*[os.fsencode(p) for p in image_list]), arr(*[os.fsencode(p) for p in outs]), n, int(threads), status)
+    if left < 0:
+        L.check(left, "fsr_png_to_npy")
+    todo = [(p, o) for p, o, st in zip(image_list, outs, status) if st != 0]
+    bad = [(p, st) for p, st in zip(image_list, status) if st not in (0, -4)]
+    if bad:
+        raise L.FsrError("fsr_png_to_npy: %d file(s) could not be converted, e.g. %s (status %d)" % (len(bad), bad[0][0], bad[0][1]))
+    if todo:
+        from PIL import Image
 
-    def _write(image_path, numpy_path):
-        image = np.array(Image.open(image_path).convert("RGB")).astype(np.uint8)
-        np.save(numpy_path, np.transpose(image, (2, 0, 1)))
+        def _write(image_path, numpy_path):
+            image = np.array(Image.open(image_path).convert("RGB")).astype(np.uint8)
+            np.save(numpy_path, np.transpose(image, (2, 0, 1)))
 
-    with ThreadPoolExecutor(max_workers=16) as executor:
-        for image_path in image_list:
-            executor.submit(_write, image_path, os.path.join(output_dir, os.path.basename(image_path).replace(".png", "")))
+        with ThreadPoolExecutor(max_workers=threads) as executor:
+            list(executor.map(lambda t: _write(*t), todo))
 
 
 def main(argv=None, config_dir="configs"):

@@ -331,6 +331,16 @@ int fsr_crop_resize(const uint8_t* const* images, const int* img_h, const int* i
                     const int* crop_x, int n, int hr_size, int scale, const float* wtab, const int* xmin,
                     const int* xsize, int kmax, float* hr_out, float* lr_out, float* tmp, fsr_stream_t stream);
 
+/* ------------------------------------------------------------------ PNG -> .npy ingest (host code, no device work)
+ * train.py:22-37 of the reference converts the data set once: PIL decode -> RGB -> uint8 CHW -> np.save, on 16 Python threads.
+ * fsr_png_to_npy does the same natively on `threads` threads (zlib inflate, the five PNG row filters, grey / palette / alpha
+ * handled as PIL's convert("RGB") does: replicated / looked up / dropped), writing .npy format 1.0 ('|u1', C order, (3, H, W)).
+ * status[i] (optional): 0 converted; -1 not a PNG; -2 corrupt; -3 I/O error; -4 a PNG this decoder does not take (interlaced,
+ * 16-bit, grey below 8 bits) -- the caller decodes exactly those files its own way.  Returns the number of files NOT converted.
+ * fsr_png_decode_chw decodes one file into `out_chw` (3 * H * W bytes; null: only report the size). */
+int fsr_png_to_npy(const char* const* png_paths, const char* const* npy_paths, int count, int threads, int* status);
+int fsr_png_decode_chw(const char* png_path, unsigned char* out_chw, size_t capacity, int* height, int* width);
+
 #ifdef __cplusplus
 }
 #endif

@@ -43,7 +43,7 @@ def build_emu(force=False):
             list(ex.map(cc, todo))
     objs = [os.path.join(OUT, s[:-4] + ".o") for s in srcs] + [runtime_obj]
     if todo or not os.path.exists(LIB):
-        r = subprocess.run([CLANG, "-shared", "-fPIC", "-pthread", "-o", LIB] + objs, capture_output=True, text=True)
+        r = subprocess.run([CLANG, "-shared", "-fPIC", "-pthread", "-o", LIB] + objs + ["-lz"], capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError("emu link failed:\n" + r.stderr[-8000:])
     return LIB

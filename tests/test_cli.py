@@ -129,3 +129,49 @@ def test_bench_self_spawns_ranks_and_runs_the_rccl_path():
     assert d["n_gpus"] == 1 and d["steps"] == 2 and d["unit"] == "images/s" and d["value"] > 0
     assert d["config"]["collectives"] == "rccl world 1" and d["config"]["launch"].startswith("3 phase hipGraphs")
     assert d["roofline"]["bound"] == "mfma" and 0 < d["roofline"]["frac"] < 1
+
+
+def test_native_png_ingest_matches_pil(tmp_path):
+    """train.write_images_to_numpy_arrays (reference train.py:22-37) through fsr_png_to_npy: RGB, RGBA, grey, grey + alpha and palette
+    (8, 4, 2, 1 bits) PNGs written by PIL with several compression / filter settings decode to EXACTLY np.array(Image.open(p).convert("RGB")),
+    land as (3, H, W) uint8 .npy files np.load reads, and the kinds the native decoder leaves out (interlaced, 16-bit) go through
+    PIL, per file.  Host code only: runs against the emulation build too (the entry point does no device work)."""
+    import numpy as np
+    from PIL import Image
+    from backend import select
+    select("emu")
+    train = importlib.import_module("fast-srgan_amd.train")
+    rng = np.random.default_rng(5)
+    src = tmp_path / "png"
+    src.mkdir()
+    h, w = 37, 53
+    rgb = rng.integers(0, 256, (h, w, 3), dtype=np.uint8)
+    rgb[5:20, 7:30] = rgb[5, 7]                     # flat areas: the Sub / Up / Paeth filters get picked by the encoder
+    grad = (np.add.outer(np.arange(h), np.arange(w)) % 256).astype(np.uint8)
+    Image.fromarray(rgb, "RGB").save(src / "rgb.png")
+    Image.fromarray(rgb, "RGB").save(src / "rgb_opt.png", optimize=True, compress_level=9)
+    Image.fromarray(np.dstack([rgb, grad]), "RGBA").save(src / "rgba.png")
+    Image.fromarray(grad, "L").save(src / "grey.png")
+    Image.fromarray(np.dstack([grad, 255 - grad]), "LA").save(src / "grey_alpha.png")
+    Image.fromarray(np.stack([grad] * 3, axis=2), "RGB").save(src / "smooth.png", compress_level=1)
+    pal = Image.fromarray(rgb, "RGB").quantize(200)
+    pal.save(src / "pal8.png")
+    Image.fromarray(rgb, "RGB").quantize(16).save(src / "pal4.png", bits=4)
+    Image.fromarray(rgb, "RGB").quantize(4).save(src / "pal2.png", bits=2)
+    Image.fromarray(rgb, "RGB").quantize(2).save(src / "pal1.png", bits=1)
+    Image.fromarray((rng.integers(0, 65536, (h, w))).astype(np.uint16)).save(src / "grey16.png")          # left to PIL
+    names = sorted(os.listdir(src))
+    out = tmp_path / "npy"
+    train.write_images_to_numpy_arrays([str(src / n) for n in names], str(out), threads=3)
+    for n in names:
+        want = np.transpose(np.array(Image.open(src / n).convert("RGB")).astype(np.uint8), (2, 0, 1))
+        got = np.load(out / n.replace(".png", ".npy"))
+        assert got.dtype == np.uint8 and got.shape == want.shape, n
+        assert np.array_equal(got, want), n
+    # the per-file status: the 16-bit file is the only one the native decoder declined
+    import ctypes
+    L = importlib.import_module("fast-srgan_amd._lib")
+    hh, ww = ctypes.c_int(0), ctypes.c_int(0)
+    assert L.lib().fsr_png_decode_chw(os.fsencode(str(src / "grey16.png")), None, 0, ctypes.byref(hh), ctypes.byref(ww)) == -4
+    assert L.lib().fsr_png_decode_chw(os.fsencode(str(src / "rgb.png")), None, 0, ctypes.byref(hh), ctypes.byref(ww)) == 0 and (hh.value, ww.value) == (h, w)
+    assert L.lib().fsr_png_decode_chw(os.fsencode(str(out / "rgb.npy")), None, 0, ctypes.byref(hh), ctypes.byref(ww)) == -1

@@ -8,5 +8,5 @@ O=/tmp/fsr_var1_$SUF; mkdir -p $O
 b=$(basename $F .hip)
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=fast -I $R/include -I $R/fast-srgan_amd/csrc "$@" -c $R/fast-srgan_amd/csrc/$b.hip -o $O/$b.o
 OBJS=$(ls $R/fast-srgan_amd/_obj/*.o | grep -v "/$b.o")
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $R/fast-srgan_amd/libfsr_hip_$SUF.so $OBJS $O/$b.o
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $R/fast-srgan_amd/libfsr_hip_$SUF.so $OBJS $O/$b.o -lz
 echo built $R/fast-srgan_amd/libfsr_hip_$SUF.so
