@@ -36,21 +36,21 @@ def _newest_header():
 
 def build_hip(force=False, verbose=True):
     os.makedirs(OBJ, exist_ok=True)
-    srcs = sorted(f for f in os.listdir(CSRC) if f.endswith(".hip"))
+    srcs = sorted(f for f in os.listdir(CSRC) if f.endswith((".hip", ".cpp")))     # .cpp: host-only code (ingest.cpp), same compiler driver
     hdr_t = _newest_header()
     flags = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-ffp-contract=fast",
              "-I", os.path.join(ROOT, "include"), "-I", CSRC]
     todo = []
     for s in srcs:
         src = os.path.join(CSRC, s)
-        obj = os.path.join(OBJ, s[:-4] + ".o")
+        obj = os.path.join(OBJ, os.path.splitext(s)[0] + ".o")
         if force or not os.path.exists(obj) or os.path.getmtime(obj) < max(os.path.getmtime(src), hdr_t):
             todo.append((src, obj))
     hipcc = _hipcc()
 
     def cc(job):
         src, obj = job
-        cmd = [hipcc] + flags + ["-c", src, "-o", obj]
+        cmd = [hipcc] + (flags if src.endswith(".hip") else ["-x", "hip"] + flags) + ["-c", src, "-o", obj]
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError("hipcc failed for %s:\n%s" % (src, r.stderr[-8000:]))
@@ -61,9 +61,9 @@ def build_hip(force=False, verbose=True):
             for done in ex.map(cc, todo):
                 if verbose:
                     print("[fsr build] compiled", os.path.basename(done), flush=True)
-    objs = [os.path.join(OBJ, s[:-4] + ".o") for s in srcs]
+    objs = [os.path.join(OBJ, os.path.splitext(s)[0] + ".o") for s in srcs]
     if todo or not os.path.exists(LIB):
-        cmd = [hipcc, "--offload-arch=" + ARCH, "-shared", "-fPIC", "-o", LIB] + objs + ["-lz"]      # zlib: csrc/ingest.hip (PNG inflate)
+        cmd = [hipcc, "--offload-arch=" + ARCH, "-shared", "-fPIC", "-o", LIB] + objs + ["-lz"]      # zlib: csrc/ingest.cpp (PNG inflate)
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError("link failed:\n" + r.stderr[-8000:])

@@ -26,7 +26,7 @@ def seed(seed_value):
 
 def write_images_to_numpy_arrays(image_list, output_dir, threads=16):
     """train.py:22-37 of the reference (PIL decode -> RGB -> uint8 CHW -> np.save on a 16-thread pool), done natively:
-    fsr_png_to_npy (csrc/ingest.hip) inflates, unfilters and converts on `threads` worker threads without the GIL and writes the
+    fsr_png_to_npy (csrc/ingest.cpp) inflates, unfilters and converts on `threads` worker threads without the GIL and writes the
     same (3, H, W) uint8 .npy files.  PNG kinds that decoder does not take (interlaced, 16-bit, grey below 8 bits: status -4) --
     and only those -- go through PIL as in the reference; any other failure is an error."""
     import ctypes

@@ -16,7 +16,7 @@ CLANG = "/opt/rocm/lib/llvm/bin/clang++"
 
 def build_emu(force=False):
     os.makedirs(OUT, exist_ok=True)
-    srcs = sorted(f for f in os.listdir(CSRC) if f.endswith(".hip"))
+    srcs = sorted(f for f in os.listdir(CSRC) if f.endswith((".hip", ".cpp")))
     runtime_src, runtime_obj = os.path.join(HERE, "emu_runtime.cpp"), os.path.join(OUT, "emu_runtime.o")
     hdrs = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
     hdrs += [os.path.join(ROOT, "include", "fsr_hip.h"), os.path.join(HERE, "include", "hip", "hip_runtime.h")]
@@ -28,7 +28,7 @@ def build_emu(force=False):
         todo.append((runtime_src, runtime_obj))
     for s in srcs:
         src = os.path.join(CSRC, s)
-        obj = os.path.join(OUT, s[:-4] + ".o")
+        obj = os.path.join(OUT, os.path.splitext(s)[0] + ".o")
         if force or not os.path.exists(obj) or os.path.getmtime(obj) < max(os.path.getmtime(src), hdr_t):
             todo.append((src, obj))
 
@@ -41,7 +41,7 @@ def build_emu(force=False):
     if todo:
         with concurrent.futures.ThreadPoolExecutor(max_workers=8) as ex:
             list(ex.map(cc, todo))
-    objs = [os.path.join(OUT, s[:-4] + ".o") for s in srcs] + [runtime_obj]
+    objs = [os.path.join(OUT, os.path.splitext(s)[0] + ".o") for s in srcs] + [runtime_obj]
     if todo or not os.path.exists(LIB):
         r = subprocess.run([CLANG, "-shared", "-fPIC", "-pthread", "-o", LIB] + objs + ["-lz"], capture_output=True, text=True)
         if r.returncode != 0:
