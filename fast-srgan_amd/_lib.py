@@ -12,13 +12,13 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # FSR_HIP_LIB: another build of the same sources (kernel A/B experiments, tools/ab.py); the default is the in-tree library
 LIB_PATH = os.environ.get("FSR_HIP_LIB") or os.path.join(_HERE, "libfsr_hip.so")
 
-FSR_F32, FSR_BF16, FSR_F16 = 0, 1, 2
+FSR_F32, FSR_BF16, FSR_F16, FSR_X3 = 0, 1, 2, 3
 ACT_NONE, ACT_RELU, ACT_LEAKY, ACT_PRELU, ACT_TANH = 0, 1, 2, 3, 4
 CONV_FWD, CONV_DGRAD = 0, 1
 PACK_FWD, PACK_FWD_PS, PACK_DGRAD, PACK_DGRAD_PS = 0, 1, 2, 3
 OUT_DTYPE, OUT_F32, OUT_U8 = 0, 1, 2
 OPT_BIAS, OPT_PRELU, OPT_OSCALE, OPT_MASK, OPT_PREACT, OPT_STATS = 1, 2, 4, 8, 16, 32   # fsr_conv3x3_pack_block
-ABI_VERSION = 9
+ABI_VERSION = 10
 
 c_int, c_float, c_void_p, c_size_t, c_ll = ctypes.c_int, ctypes.c_float, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_longlong
 
@@ -66,6 +66,7 @@ SIGNATURES = {
     "fsr_instnorm_act_bwd_apply": (c_int, [c_int, P, P, P, P, c_int, c_float, P, P, c_int, c_int, c_int, P]),
     "fsr_act_bwd_scratch": (c_size_t, [c_int, c_int, c_int, c_int, c_int]),
     "fsr_act_bwd": (c_int, [c_int, P, P, c_int, c_float, P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, P]),
+    "fsr_add": (c_int, [c_int, P, P, P, c_ll, P]),
     "fsr_image_to_nhwc": (c_int, [c_int, P, c_ll, c_ll, c_ll, c_ll, c_int, c_int, c_int, c_float, c_float, c_float,
                                   c_float, c_float, c_float, P, c_int, P]),
     "fsr_u8_to_image": (c_int, [P, P, c_ll, P]),

@@ -68,7 +68,9 @@ __device__ __forceinline__ unsigned tap_code(const ConvKArgs& a, int t) {
 // ReLU / LeakyReLU / PReLU / identity are ONE formula: v > 0 ? v : v * slope with slope 0 / s / a / 1.
 template <typename T>
 __device__ __forceinline__ void store_vec4(T* p, f32x4 v) {
-  if constexpr (sizeof(T) == 4) {
+  if constexpr (std::is_same<T, x3_t>::value) {
+    x3_st4(p, v);
+  } else if constexpr (sizeof(T) == 4) {
     *(f32x4*)p = v;
   } else {
     u32x2 pk;
@@ -78,9 +80,16 @@ __device__ __forceinline__ void store_vec4(T* p, f32x4 v) {
   }
 }
 
-template <typename T, int TH, int BN, int WM, int WN, int KC, int S, int G = 1, int DMA = 0>
+// X3 = 1 (FSR_X3, T = bf16_t, KC = 64): the input is an x3 tensor seen as a bf16 tensor of a.Cin = 2 x logical channels whose
+// 32-channel chunks alternate hi / lo, the filter pack has the same K order ([w_hi | w_lo] per 64), so staging, LDS images and
+// addressing are exactly the bf16 kernel's at twice the channels.  Only two things differ: a 64-channel chunk of a tap is
+// THREE MFMAs per fragment pair -- w_hi x_hi + w_hi x_lo + w_lo x_hi (4 fragment reads per 3 MFMAs; the bf16 form reads 4 per 2)
+// -- and the epilogue stores / reads x3 elements (hi and lo 64 bytes apart, fsr_common.h).
+template <typename T, int TH, int BN, int WM, int WN, int KC, int S, int G = 1, int DMA = 0, int X3 = 0>
 __global__ __launch_bounds__(WM * WN * 64, 2) void conv_igemm_kernel(const ConvKArgs a_in, const ConvKClasses cls) {
   static_assert(WM * WN == 4 || WM * WN == 8, "4 or 8 waves per workgroup");
+  static_assert(!X3 || (std::is_same<T, bf16_t>::value && KC == 64 && G == 1 && DMA == 0), "x3: bf16 planes, 64-channel (hi | lo) chunks");
+  typedef typename std::conditional<X3 != 0, x3_t, T>::type ST;   // storage type of the output-side tensors
   constexpr int NTHR = WM * WN * 64;
   constexpr int MT = TH / WM;
   constexpr int NT = BN / 16 / WN;
@@ -241,6 +250,34 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv_igemm_kernel(const ConvK
   auto tap_mfma = [&](const T* wcur, int t) {
     const unsigned tc = tap_code(a, t);
     const int toff = ((int)(tc & 3u) * HW + (int)((tc >> 2) & 3u)) * PITCHX;
+    if constexpr (X3) {
+      frag_t xh[MT], xl[MT];
+#pragma unroll
+      for (int m = 0; m < MT; ++m) {
+        xh[m] = *(const frag_t*)(halo + pixbase[m] + toff);
+        xl[m] = *(const frag_t*)(halo + pixbase[m] + toff + KSTEP);
+      }
+      constexpr int NH = NT > 4 ? 4 : NT;
+#pragma unroll
+      for (int n0 = 0; n0 < NT; n0 += NH) {
+        frag_t wh[NH], wlo[NH];
+#pragma unroll
+        for (int n = 0; n < NH; ++n) {
+          wh[n] = *(const frag_t*)(wcur + wbase[n0 + n] + wsw[0]);
+          wlo[n] = *(const frag_t*)(wcur + wbase[n0 + n] + wsw[1]);
+        }
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+#pragma unroll
+          for (int n = 0; n < NH; ++n) {
+            acc[m][n0 + n] = mfma16<T>(wh[n], xh[m], acc[m][n0 + n]);
+            acc[m][n0 + n] = mfma16<T>(wh[n], xl[m], acc[m][n0 + n]);
+            acc[m][n0 + n] = mfma16<T>(wlo[n], xh[m], acc[m][n0 + n]);
+          }
+        if constexpr (NH < NT) __builtin_amdgcn_sched_barrier(0);
+      }
+      return;
+    }
 #pragma unroll
     for (int ks = 0; ks < KC / KSTEP; ++ks) {
       // filter fragments in groups of NH tiles: with multi-tap stages the 8-tile waves would otherwise hold 12
@@ -495,22 +532,22 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv_igemm_kernel(const ConvK
               v = (a.act == FSR_ACT_TANH) ? tanhf(v) : (v > 0.f ? v : v * slope);
               if (a.out_f32 == FSR_OUT_U8) ((unsigned char*)a.out)[off + r] = image_u8(v);
               else if (a.out_f32 || sizeof(T) == 4) ((float*)a.out)[off + r] = v;
-              else ElemIO<T>::st((T*)a.out + (off + r), v);
+              else ElemIO<ST>::st((ST*)a.out + (off + r), v);
             }
         }
       });
     });
     return;
   }
-  T* outp = (T*)a.out;
-  T* prep = (T*)a.preact;
-  const T* maskp = (const T*)a.dmask;
+  ST* outp = (ST*)a.out;
+  ST* prep = (ST*)a.preact;
+  const ST* maskp = (const ST*)a.dmask;
   const bool want_stats = a.stats != nullptr;
   // Masks (fused activation backward) are loaded for ALL tiles of the wave before the first store: a load issued after
   // a store may alias it as far as the compiler knows, and gfx9 counts loads and stores on one counter, so every
   // (tile row) mask load would otherwise wait for the previous row's store to reach memory -- MT x NT serialised
   // round trips per workgroup.
-  constexpr bool PREMASK = sizeof(T) == 2;
+  constexpr bool PREMASK = sizeof(T) == 2 && !X3;
   u32x2 mkreg[PREMASK ? NT : 1][PREMASK ? MT : 1];
   const bool premask = PREMASK && maskp && !a.ps && a.premask;
   if (premask) {
@@ -521,8 +558,10 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv_igemm_kernel(const ConvK
       static_for<0, MT>([&](auto mc) {
         constexpr int m = decltype(mc)::value;
         u32x2 t = (u32x2){0u, 0u};
-        if (col_ok && gyb + m < a.GH) t = *(const u32x2*)(maskp + (base0 + n * 16 + m * rs));
-        if constexpr (PREMASK) mkreg[n][m] = t;
+        if constexpr (PREMASK) {
+          if (col_ok && gyb + m < a.GH) t = *(const u32x2*)(maskp + (base0 + n * 16 + m * rs));
+          mkreg[n][m] = t;
+        }
       });
     });
   }
@@ -563,7 +602,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv_igemm_kernel(const ConvK
           }
           if (col_ok && gyb + m < a.GH && !(l15 & 1)) {
             const unsigned off = (unsigned)((img * (a.FOH >> 1) + ((gyb + m) >> 1)) * (a.FOW >> 1) + (gx >> 1)) * (unsigned)a.Cout + (unsigned)co;
-            store_vec4<T>(outp + off, v);
+            store_vec4<ST>(outp + off, v);
           }
         });
         return;
@@ -575,7 +614,10 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv_igemm_kernel(const ConvK
         f32x4 v = acc[m][n] + bv;
         if (maskp) {   // data-gradient launch fused with the producer's activation backward: dz = dx * act'(y)
           float mk[4];
-          if constexpr (sizeof(T) == 4) {
+          if constexpr (X3) {
+            const f32x4 t = x3_ld4(maskp + (base + m * rstride));
+            mk[0] = t[0]; mk[1] = t[1]; mk[2] = t[2]; mk[3] = t[3];
+          } else if constexpr (sizeof(T) == 4) {
             const f32x4 t = *(const f32x4*)(maskp + (base + m * rstride));
             mk[0] = t[0]; mk[1] = t[1]; mk[2] = t[2]; mk[3] = t[3];
           } else {
@@ -592,10 +634,10 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv_igemm_kernel(const ConvK
           s1 += v;
           s2 += v * v;
         }
-        if (prep) store_vec4<T>(prep + (base + m * rstride), v);
+        if (prep) store_vec4<ST>(prep + (base + m * rstride), v);
 #pragma unroll
         for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f) + slope * fminf(v[r], 0.f);
-        store_vec4<T>(outp + (base + m * rstride), v);
+        store_vec4<ST>(outp + (base + m * rstride), v);
       }
     });
     if (want_stats) {
@@ -648,7 +690,7 @@ static int pack_taps(ConvKArgs& a) {
 
 // `more` (optional): further classes of the same launch (see ConvKClasses); they share everything with `a` except
 // the output grid, the tap table and the output offset.
-template <typename T, int TH, int BN, int WM, int WN, int KC, int S, int G = 1, int DMA = 0>
+template <typename T, int TH, int BN, int WM, int WN, int KC, int S, int G = 1, int DMA = 0, int X3 = 0>
 static int launch_cfg(ConvKArgs& a, hipStream_t stream, ConvKArgs* more = nullptr, int nmore = 0) {
   constexpr int EPB = 16 / (int)sizeof(T);
   constexpr int PITCHW = KC + 2 * EPB, PITCHX = KC + (S == 2 ? 1 : 2) * EPB;
@@ -660,7 +702,7 @@ static int launch_cfg(ConvKArgs& a, hipStream_t stream, ConvKArgs* more = nullpt
   a.premask = (stage_mode() & 65536) ? 0 : 1;
   a.HH = (TH - 1) * S + 3;
   a.HW = 15 * S + 3;
-  if ((long long)a.N * a.IH * a.IW * a.Cin >= (1LL << 31) || (long long)a.N * a.FOH * a.FOW * a.Cout >= (1LL << 31))
+  if ((long long)a.N * a.IH * a.IW * a.Cin >= (1LL << 31) || (long long)a.N * a.FOH * a.FOW * a.Cout * (X3 ? 2 : 1) >= (1LL << 31))
     return fsr_fail(-2, "conv3x3: tensors with 2^31 or more elements are not supported");
   if (G == 3 && (a.ntaps % 3 != 0 || nmore > 0)) return fsr_fail(-2, "conv3x3: three-tap stages need a multiple of 3 taps");
   if (a.stats && nmore > 0) return fsr_fail(-2, "conv3x3: statistics are not available for multi-class launches");
@@ -684,14 +726,14 @@ static int launch_cfg(ConvKArgs& a, hipStream_t stream, ConvKArgs* more = nullpt
   if (a.stats && a.stats_P > a.stats_P_max) return fsr_fail(-3, "conv3x3: %d partial slots per image exceed the scratch buffer's %d", a.stats_P, a.stats_P_max);
   a.stats_tpi = a.stats_per = 0;
   const size_t lds = ((size_t)a.HH * a.HW * PITCHX + (DMA ? 2 * G * (size_t)BN * KC : (G == 1 ? 2 : G) * (size_t)BN * PITCHW)) * sizeof(T);
-  auto kern = conv_igemm_kernel<T, TH, BN, WM, WN, KC, S, G, DMA>;
+  auto kern = conv_igemm_kernel<T, TH, BN, WM, WN, KC, S, G, DMA, X3>;
   static bool attr_set = false;
   if (!attr_set) {
     (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
     attr_set = true;
   }
   hipLaunchKernelGGL(kern, dim3((unsigned)nwg), dim3(WM * WN * 64), lds, stream, a, cls);
-  fsr_note_kernel("conv_igemm_kernel<%s,%d,%d,%d,%d,%d,%d,%d,%d>", sizeof(T) == 4 ? "f32" : (std::is_same<T, f16_t>::value ? "f16" : "bf16"), TH, BN, WM, WN, KC, S, G, DMA);
+  fsr_note_kernel("conv_igemm_kernel<%s,%d,%d,%d,%d,%d,%d,%d,%d>", X3 ? "x3" : (sizeof(T) == 4 ? "f32" : (std::is_same<T, f16_t>::value ? "f16" : "bf16")), TH, BN, WM, WN, KC, S, G, DMA);
   return fsr_check_launch("conv_igemm_kernel");
 }
 
@@ -775,6 +817,31 @@ static int dispatch_T(ConvKArgs& a, int S, hipStream_t stream, ConvKArgs* more =
   return fsr_fail(-2, "conv3x3: unsupported padded Cout=%d (need a multiple of 16)", a.CoutPad);
 }
 
+// FSR_X3 on this kernel: a.Cin counts PHYSICAL bf16 channels (2 x logical, set by the caller), 64-channel (hi | lo) chunks,
+// one tap per step (G = 1, register-staged filter slices).
+#define FSR_GO3(...) return launch_cfg<bf16_t, __VA_ARGS__, 1, 0, 1>(a, stream, more, nmore)
+static int dispatch_X3(ConvKArgs& a, int S, hipStream_t stream, ConvKArgs* more = nullptr, int nmore = 0) {
+  const int w16 = ((a.GH + 15) / 16) * 16 - a.GH, w8 = ((a.GH + 7) / 8) * 8 - a.GH;
+  const long long tiles16 = (long long)a.N * ((a.GH + 15) / 16) * ((a.GW + 15) / 16) * (a.CoutPad / 64 > 0 ? a.CoutPad / 64 : 1) * (nmore + 1);
+  const bool th8 = !(stage_mode() & 32) && ((w16 - w8 >= 8) || tiles16 < 1024);
+  if (nmore > 0 && S != 1) return fsr_fail(-2, "conv3x3: multi-class launches are stride-1 launches");
+  if (a.CoutPad % 128 == 0) {
+    if (S == 2) FSR_GO3(8, 128, 2, 2, 64, 2);
+    FSR_GO3(8, 128, 2, 2, 64, 1);
+  }
+  if (a.CoutPad % 64 == 0) {
+    if (S == 2) FSR_GO3(8, 64, 2, 2, 64, 2);
+    if (th8) FSR_GO3(8, 64, 2, 2, 64, 1);
+    FSR_GO3(16, 64, 4, 1, 64, 1);
+  }
+  if (a.CoutPad % 16 == 0) {
+    if (S == 2) FSR_GO3(8, 16, 4, 1, 64, 2);
+    FSR_GO3(8, 16, 4, 1, 64, 1);
+  }
+  return fsr_fail(-2, "conv3x3: unsupported padded Cout=%d (need a multiple of 16)", a.CoutPad);
+}
+#undef FSR_GO3
+
 int fsr_conv_igemm_dispatch_classes(int dtype, ConvKArgs* cls, int n, hipStream_t stream) {
   if (n < 1 || n > 4) return fsr_fail(-2, "conv3x3: %d classes in one launch", n);
   if (cls[0].query) return 0;         // (fsr_conv3x3_pack_block: these launches read the standard pack)
@@ -782,10 +849,16 @@ int fsr_conv_igemm_dispatch_classes(int dtype, ConvKArgs* cls, int n, hipStream_
   if (dtype == FSR_BF16) return dispatch_T<bf16_t, 64, 32>(cls[0], 1, stream, cls + 1, n - 1);
   if (dtype == FSR_F16) return dispatch_T<f16_t, 64, 32>(cls[0], 1, stream, cls + 1, n - 1);
   if (dtype == FSR_F32) return dispatch_T<float, 16, 16>(cls[0], 1, stream, cls + 1, n - 1);
+  if (dtype == FSR_X3) return dispatch_X3(cls[0], 1, stream, cls + 1, n - 1);
   return fsr_fail(-2, "conv3x3: unknown dtype %d", dtype);
 }
 
 int fsr_conv_igemm_dispatch(int dtype, ConvKArgs& a, int S, hipStream_t stream) {
+  if (dtype == FSR_X3) {
+    if (a.query) return 0;            // (the standard x3 pack)
+    if (a.wlin) return fsr_fail(-2, "conv3x3: a stage-contiguous filter pack reached a kernel that reads the standard one");
+    return dispatch_X3(a, S, stream);
+  }
   if (a.Cin == 64) {
     if (a.query) return 0;            // (the 64-input-channel kernels read the standard pack)
     if (a.wlin) return fsr_fail(-2, "conv3x3: a stage-contiguous filter pack reached a kernel that reads the standard one");

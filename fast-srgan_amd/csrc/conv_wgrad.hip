@@ -479,7 +479,64 @@ __global__ __launch_bounds__(256) void conv_wgrad_reduce_kernel(const float* __r
   }
 }
 
+// FSR_X3: the weight-gradient kernel ran on the bf16 views of x and dy (2 x the channels, hi / lo chunks of 32), so the workspace
+// holds every (dy part, x part) product block: dW[co][ci] = P[hi(co)][hi(ci)] + P[hi(co)][lo(ci)] + P[lo(co)][hi(ci)], with
+// hi(c) = (c >> 5) * 64 + (c & 31) and lo(c) = hi(c) + 32 (the lo x lo block, <= 2^-16 of the result, is computed and dropped:
+// the blocks of a workgroup share its staging, skipping its MFMAs would only unbalance the waves).  Slab order and the order of
+// the three terms are fixed: bit-reproducible.  cout_pad / cin_pad are the PHYSICAL workspace dims, cout / cin logical.
+__global__ __launch_bounds__(256) void conv_wgrad_reduce_x3_kernel(const float* __restrict__ ws, float* __restrict__ dw, int nslab,
+                                                                   int cout, int cin, int cout_pad, int cin_pad, int ps) {
+  __shared__ float red[8][32];
+  const int total = 9 * cout * cin;
+  const size_t sstride = (size_t)9 * cout_pad * cin_pad;
+  const int oi = threadIdx.x & 31, pl = threadIdx.x >> 5;
+  for (int i0 = blockIdx.x * 32; i0 < total; i0 += gridDim.x * 32) {
+    const int i = i0 + oi;
+    float s = 0.f;
+    int co = 0, ci = 0, t = 0;
+    if (i < total) {
+      ci = i % cin;
+      co = (i / cin) % cout;
+      t = i / (cin * cout);
+      const int row = ps ? (co & 3) * (cout_pad >> 3) + (co >> 2) : co;     // logical row (cout_pad / 2 logical rows, a quarter per quadrant)
+      const int rh = (row >> 5) * 64 + (row & 31), ch = (ci >> 5) * 64 + (ci & 31);
+      const float* p = ws + ((size_t)t * cout_pad + rh) * cin_pad + ch;
+      const size_t rlo = (size_t)32 * cin_pad;
+      float hh = 0.f, hl = 0.f, lh = 0.f;
+      for (int k = pl; k < nslab; k += 8) {
+        const float* q = p + (size_t)k * sstride;
+        hh += q[0];
+        hl += q[32];
+        lh += q[rlo];
+      }
+      s = hh + (hl + lh);
+    }
+    red[pl][oi] = s;
+    __syncthreads();
+    if (pl == 0 && i < total) {
+      float r = red[0][oi];
+#pragma unroll
+      for (int j = 1; j < 8; ++j) r += red[j][oi];
+      dw[((size_t)co * cin + ci) * 9 + t] += r;
+    }
+    __syncthreads();
+  }
+}
+
 namespace {
+
+// FSR_X3 -> the bf16 launch on the physical views (see conv_wgrad_reduce_x3_kernel)
+inline fsr_wgrad_desc physical_desc(const fsr_wgrad_desc* d) {
+  fsr_wgrad_desc q = *d;
+  if (d->dtype == FSR_X3) {
+    q.dtype = FSR_BF16;
+    q.cin_pad = 2 * d->cin_pad;
+    q.cout_pad = 2 * d->cout_pad;
+    q.cin = q.cin_pad;
+    q.cout = q.cout_pad;
+  }
+  return q;
+}
 
 struct WgradPlan {
   int BM, BN, TPH, S;
@@ -487,8 +544,13 @@ struct WgradPlan {
   size_t lds;
 };
 
-int make_plan(const fsr_wgrad_desc* d, WgradPlan& p) {
-  if (!d) return fsr_fail(-1, "conv3x3_wgrad: null descriptor");
+int make_plan(const fsr_wgrad_desc* d_in, WgradPlan& p) {
+  if (!d_in) return fsr_fail(-1, "conv3x3_wgrad: null descriptor");
+  if (d_in->dtype == FSR_X3 && (d_in->cin_pad % 32 || d_in->cout_pad % 32 || d_in->cin > d_in->cin_pad || d_in->cout > d_in->cout_pad ||
+                                (d_in->dy_pixel_shuffled && (d_in->cout_pad / 4) % 32)))
+    return fsr_fail(-2, "conv3x3_wgrad: x3 tensors have a multiple of 32 channels");
+  const fsr_wgrad_desc dphys = physical_desc(d_in);
+  const fsr_wgrad_desc* d = &dphys;
   if (d->dtype != FSR_F32 && d->dtype != FSR_BF16 && d->dtype != FSR_F16) return fsr_fail(-2, "conv3x3_wgrad: unknown dtype %d", d->dtype);
   const int cpad = d->dtype != FSR_F32 ? 32 : 16;
   if (d->stride != 1 && d->stride != 2) return fsr_fail(-2, "conv3x3_wgrad: stride must be 1 or 2");
@@ -641,6 +703,7 @@ extern "C" int fsr_conv3x3_wgrad_grouped(const fsr_wgrad_desc* d, int nlayers, c
   if (int rc = make_plan(d, p)) return rc;
   if (nlayers < 1 || nlayers > WGRAD_GROUP_MAX) return fsr_fail(-2, "fsr_conv3x3_wgrad_grouped: 1..%d layers per launch", WGRAD_GROUP_MAX);
   if (!x || !dy || !dw_oihw || !workspace) return fsr_fail(-1, "fsr_conv3x3_wgrad_grouped: null argument");
+  if (d->dtype == FSR_X3) return fsr_fail(-2, "fsr_conv3x3_wgrad_grouped: not available for x3 tensors (launch the layers one by one)");
   if (p.nbm * p.nbn != 1 || d->dy_pixel_shuffled || d->cout != d->cout_pad || d->cin != d->cin_pad)
     return fsr_fail(-2, "fsr_conv3x3_wgrad_grouped: layers of one 64 x 64 block (cout = cin = 64, unpadded, no pixel shuffle)");
   WgradKArgs a = {};
@@ -675,15 +738,20 @@ extern "C" int fsr_conv3x3_wgrad_grouped(const fsr_wgrad_desc* d, int nlayers, c
 extern "C" size_t fsr_conv3x3_wgrad_workspace(const fsr_wgrad_desc* d) {
   WgradPlan p;
   if (make_plan(d, p) != 0) return 0;
-  return (size_t)p.nslab * 9 * d->cout_pad * d->cin_pad * sizeof(float);
+  const int f = d->dtype == FSR_X3 ? 4 : 1;     // x3: all four (dy part, x part) product blocks
+  return (size_t)p.nslab * 9 * d->cout_pad * d->cin_pad * f * sizeof(float);
 }
 
-extern "C" int fsr_conv3x3_wgrad(const fsr_wgrad_desc* d, const void* x, const void* dy, float* dw_oihw, void* workspace,
+extern "C" int fsr_conv3x3_wgrad(const fsr_wgrad_desc* d_in, const void* x, const void* dy, float* dw_oihw, void* workspace,
                                  fsr_stream_t stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   WgradPlan p;
-  if (int rc = make_plan(d, p)) return rc;
+  if (int rc = make_plan(d_in, p)) return rc;
   if (!x || !dy || !dw_oihw || !workspace) return fsr_fail(-1, "fsr_conv3x3_wgrad: null argument");
+  const bool x3 = d_in->dtype == FSR_X3;
+  if (x3 && ((((size_t)x | (size_t)dy) & 127) != 0)) return fsr_fail(-2, "fsr_conv3x3_wgrad: x3 tensors must be 128-byte aligned");
+  const fsr_wgrad_desc dphys = physical_desc(d_in);
+  const fsr_wgrad_desc* d = &dphys;
   WgradKArgs a = {};
   a.x = x;
   a.dy = dy;
@@ -709,6 +777,14 @@ extern "C" int fsr_conv3x3_wgrad(const fsr_wgrad_desc* d, const void* x, const v
   const int total = 9 * d->cout * d->cin;
   int blocks = (total + 31) / 32;
   if (blocks > 8192) blocks = 8192;
+  if (x3) {
+    const int total3 = 9 * d_in->cout * d_in->cin;
+    int blocks3 = (total3 + 31) / 32;
+    if (blocks3 > 8192) blocks3 = 8192;
+    hipLaunchKernelGGL(conv_wgrad_reduce_x3_kernel, dim3(blocks3), dim3(256), 0, stream, (const float*)workspace, dw_oihw,
+                       p.nslab, d_in->cout, d_in->cin, d->cout_pad, d->cin_pad, d->dy_pixel_shuffled);
+    return fsr_check_launch("conv_wgrad_reduce_x3_kernel");
+  }
   hipLaunchKernelGGL(conv_wgrad_reduce_kernel, dim3(blocks), dim3(256), 0, stream, (const float*)workspace, dw_oihw,
                      p.nslab, d->cout, d->cin, d->cout_pad, d->cin_pad, d->dy_pixel_shuffled);
   return fsr_check_launch("conv_wgrad_reduce_kernel");

@@ -16,35 +16,8 @@ namespace {
 
 constexpr float kEps = 1e-5f;  // torch.nn.InstanceNorm2d default eps
 
-// one 16-byte unit of T viewed as floats
-template <typename T> struct V16 {   // the 16-bit storage types (bf16_t, f16_t): 8 elements per 16-byte unit
-  static constexpr int N = 8;
-  static __device__ __forceinline__ void ld(const T* p, float (&v)[8]) {
-    const u32x4 t = *(const u32x4*)p;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      v[2 * i] = cvt_lo<T>(t[i]);
-      v[2 * i + 1] = cvt_hi<T>(t[i]);
-    }
-  }
-  static __device__ __forceinline__ void st(T* p, const float (&v)[8]) {
-    u32x4 t;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) t[i] = pack2<T>(v[2 * i], v[2 * i + 1]);
-    fsr_st<8>((u32x4*)p, t);
-  }
-};
-
-template <> struct V16<float> {
-  static constexpr int N = 4;
-  static __device__ __forceinline__ void ld(const float* p, float (&v)[4]) {
-    const f32x4 t = *(const f32x4*)p;
-    v[0] = t[0]; v[1] = t[1]; v[2] = t[2]; v[3] = t[3];
-  }
-  static __device__ __forceinline__ void st(float* p, const float (&v)[4]) {
-    *(f32x4*)p = (f32x4){v[0], v[1], v[2], v[3]};
-  }
-};
+// one 16-byte unit of T viewed as floats (fsr_common.h), stored with this family's non-temporal setting
+template <typename T> struct EV : V16<T, 8> {};
 // derivative with respect to the pre-activation, evaluated from the pre-activation
 __device__ __forceinline__ float act_dz(float z, int act, float slope) {
   if (act == FSR_ACT_NONE) return 1.f;
@@ -87,7 +60,7 @@ __global__ __launch_bounds__(256) void instnorm_act_fwd_kernel(const T* __restri
                                                                const T* __restrict__ res, int act, float slope_in,
                                                                const float* __restrict__ prelu, T* __restrict__ out,
                                                                int hw, int c) {
-  constexpr int E = V16<T>::N;
+  constexpr int E = EV<T>::N;
   const int cu = c / E;
   const int n = blockIdx.y;
   const float slope = (act == FSR_ACT_PRELU) ? prelu[0] : (act == FSR_ACT_NONE ? 1.f : (act == FSR_ACT_RELU ? 0.f : slope_in));
@@ -110,23 +83,23 @@ __global__ __launch_bounds__(256) void instnorm_act_fwd_kernel(const T* __restri
   unsigned u = blockIdx.x * 256 + threadIdx.x;
   for (; u + step < units; u += 2 * step) {      // two units per trip: up to four 16-byte loads in flight per lane
     float va[E], ra[E], vb[E], rb[E];
-    V16<T>::ld(x + img + (size_t)u * E, va);
-    V16<T>::ld(x + img + (size_t)(u + step) * E, vb);
+    EV<T>::ld(x + img + (size_t)u * E, va);
+    EV<T>::ld(x + img + (size_t)(u + step) * E, vb);
     if (res) {
-      V16<T>::ld(res + img + (size_t)u * E, ra);
-      V16<T>::ld(res + img + (size_t)(u + step) * E, rb);
+      EV<T>::ld(res + img + (size_t)u * E, ra);
+      EV<T>::ld(res + img + (size_t)(u + step) * E, rb);
     }
     apply(va, ra);
     apply(vb, rb);
-    V16<T>::st(out + img + (size_t)u * E, va);
-    V16<T>::st(out + img + (size_t)(u + step) * E, vb);
+    EV<T>::st(out + img + (size_t)u * E, va);
+    EV<T>::st(out + img + (size_t)(u + step) * E, vb);
   }
   if (u < units) {
     float v[E], r[E];
-    V16<T>::ld(x + img + (size_t)u * E, v);
-    if (res) V16<T>::ld(res + img + (size_t)u * E, r);
+    EV<T>::ld(x + img + (size_t)u * E, v);
+    if (res) EV<T>::ld(res + img + (size_t)u * E, r);
     apply(v, r);
-    V16<T>::st(out + img + (size_t)u * E, v);
+    EV<T>::st(out + img + (size_t)u * E, v);
   }
 }
 
@@ -140,7 +113,7 @@ __global__ __launch_bounds__(256) void instnorm_act_bwd_reduce_kernel(const T* _
                                                                       float slope_in, const float* __restrict__ prelu,
                                                                       float* __restrict__ sums, float* __restrict__ dprelu,
                                                                       int hw, int c, int slabs) {
-  constexpr int E = V16<T>::N;
+  constexpr int E = EV<T>::N;
   __shared__ float red[4][256 / 4 * 2 * E];   // [wave][unit slot][2E]: one value per (wave, channel unit, quantity)
   __shared__ float red_p[4];
   const int cu = c / E;            // <= 256 (host checked)
@@ -172,18 +145,18 @@ __global__ __launch_bounds__(256) void instnorm_act_bwd_reduce_kernel(const T* _
     for (; p + rows < p1; p += 2 * rows) {     // two pixels per trip: four 16-byte loads in flight per lane
       const size_t off = ((size_t)n * hw + p) * c + unit * E;
       float ga[E], xa[E], gb[E], xb[E];
-      V16<T>::ld(g + off, ga);
-      V16<T>::ld(x + off, xa);
-      V16<T>::ld(g + off + (size_t)rows * c, gb);
-      V16<T>::ld(x + off + (size_t)rows * c, xb);
+      EV<T>::ld(g + off, ga);
+      EV<T>::ld(x + off, xa);
+      EV<T>::ld(g + off + (size_t)rows * c, gb);
+      EV<T>::ld(x + off + (size_t)rows * c, xb);
       body(ga, xa);
       body(gb, xb);
     }
     if (p < p1) {
       const size_t off = ((size_t)n * hw + p) * c + unit * E;
       float ga[E], xa[E];
-      V16<T>::ld(g + off, ga);
-      V16<T>::ld(x + off, xa);
+      EV<T>::ld(g + off, ga);
+      EV<T>::ld(x + off, xa);
       body(ga, xa);
     }
   }
@@ -232,7 +205,7 @@ __global__ __launch_bounds__(256) void instnorm_act_bwd_apply_kernel(const T* __
                                                                      const float* __restrict__ sums, int act,
                                                                      float slope_in, const float* __restrict__ prelu,
                                                                      T* __restrict__ dx, int hw, int c) {
-  constexpr int E = V16<T>::N;
+  constexpr int E = EV<T>::N;
   const int cu = c / E;
   const int n = blockIdx.y;
   const float slope = (act == FSR_ACT_PRELU) ? prelu[0] : (act == FSR_ACT_NONE ? 1.f : (act == FSR_ACT_RELU ? 0.f : slope_in));
@@ -265,21 +238,21 @@ __global__ __launch_bounds__(256) void instnorm_act_bwd_apply_kernel(const T* __
   unsigned u = blockIdx.x * 256 + threadIdx.x;
   for (; u + step < units; u += 2 * step) {      // two units per trip: four 16-byte loads in flight per lane
     float ga[E], xa[E], gb[E], xb[E];
-    V16<T>::ld(g + img + (size_t)u * E, ga);
-    V16<T>::ld(x + img + (size_t)u * E, xa);
-    V16<T>::ld(g + img + (size_t)(u + step) * E, gb);
-    V16<T>::ld(x + img + (size_t)(u + step) * E, xb);
+    EV<T>::ld(g + img + (size_t)u * E, ga);
+    EV<T>::ld(x + img + (size_t)u * E, xa);
+    EV<T>::ld(g + img + (size_t)(u + step) * E, gb);
+    EV<T>::ld(x + img + (size_t)(u + step) * E, xb);
     apply(ga, xa);
     apply(gb, xb);
-    V16<T>::st(dx + img + (size_t)u * E, xa);
-    V16<T>::st(dx + img + (size_t)(u + step) * E, xb);
+    EV<T>::st(dx + img + (size_t)u * E, xa);
+    EV<T>::st(dx + img + (size_t)(u + step) * E, xb);
   }
   if (u < units) {
     float gv[E], xv[E];
-    V16<T>::ld(g + img + (size_t)u * E, gv);
-    V16<T>::ld(x + img + (size_t)u * E, xv);
+    EV<T>::ld(g + img + (size_t)u * E, gv);
+    EV<T>::ld(x + img + (size_t)u * E, xv);
     apply(gv, xv);
-    V16<T>::st(dx + img + (size_t)u * E, xv);
+    EV<T>::st(dx + img + (size_t)u * E, xv);
   }
 }
 
@@ -291,7 +264,7 @@ __global__ __launch_bounds__(256) void act_bwd_kernel(const T* __restrict__ g, c
                                                       float slope_in, const float* __restrict__ prelu, T* __restrict__ dz,
                                                       float* __restrict__ dbias, float* __restrict__ dprelu, int h, int w,
                                                       int c, int ps, int slabs) {
-  constexpr int E = V16<T>::N;
+  constexpr int E = EV<T>::N;
   __shared__ float red[256 * E];
   __shared__ float red_p[4];
   const int cu = c / E;
@@ -324,8 +297,8 @@ __global__ __launch_bounds__(256) void act_bwd_kernel(const T* __restrict__ g, c
       }
       const size_t off = ((size_t)n * hw + (size_t)py * w + px) * c + unit * E;
       float gv[E], sv[E];
-      V16<T>::ld(g + off, gv);
-      V16<T>::ld(saved + off, sv);
+      EV<T>::ld(g + off, gv);
+      EV<T>::ld(saved + off, sv);
 #pragma unroll
       for (int i = 0; i < E; ++i) {
         const float d = gv[i] * act_dz(sv[i], act, slope);
@@ -333,7 +306,7 @@ __global__ __launch_bounds__(256) void act_bwd_kernel(const T* __restrict__ g, c
         s1[i] += d;
         gv[i] = d;
       }
-      if (dz) V16<T>::st(dz + off, gv);
+      if (dz) EV<T>::st(dz + off, gv);
     }
   }
   if (dprelu) {
@@ -366,7 +339,7 @@ __global__ __launch_bounds__(256) void image_to_nhwc_kernel(const float* __restr
                                                             long long sh, long long sw, int h, int w, float a0, float a1,
                                                             float a2, float b0, float b1, float b2, T* __restrict__ out,
                                                             int cpad) {
-  constexpr int E = V16<T>::N;
+  constexpr int E = EV<T>::N;
   const int upp = cpad / E;  // 16-byte units per pixel
   const int row = blockIdx.x;
   const int n = row / h, y = row - n * h;
@@ -384,7 +357,7 @@ __global__ __launch_bounds__(256) void image_to_nhwc_kernel(const float* __restr
       v[1] = s[sc] * a1 + b1;
       v[2] = s[2 * sc] * a2 + b2;
     }
-    V16<T>::st(dst + (size_t)u * E, v);
+    EV<T>::st(dst + (size_t)u * E, v);
   }
 }
 
@@ -393,7 +366,7 @@ __global__ __launch_bounds__(256) void tanh_bwd_to_nhwc_kernel(const float* __re
                                                                long long sh, long long sw, const float* __restrict__ y,
                                                                int h, int w, T* __restrict__ dz, int cpad, int nrows,
                                                                float* __restrict__ dbias) {
-  constexpr int E = V16<T>::N;
+  constexpr int E = EV<T>::N;
   __shared__ float red[3][4];
   const int upp = cpad / E;
   float b0 = 0.f, b1 = 0.f, b2 = 0.f;
@@ -418,7 +391,7 @@ __global__ __launch_bounds__(256) void tanh_bwd_to_nhwc_kernel(const float* __re
         b1 += v[1];
         b2 += v[2];
       }
-      V16<T>::st(dst + (size_t)u * E, v);
+      EV<T>::st(dst + (size_t)u * E, v);
     }
   }
   if (dbias) {
@@ -442,6 +415,20 @@ __global__ __launch_bounds__(256) void u8_to_image_kernel(const unsigned char* _
     dst[i] = (float)src[i] / 127.5f - 1.0f;
 }
 
+// ------------------------------------------------------------------ out = a + b (gradient accumulation of a tensor with two consumers)
+template <typename T>
+__global__ __launch_bounds__(256) void add_kernel(const T* __restrict__ a, const T* __restrict__ b, T* __restrict__ out, long long units) {
+  constexpr int E = EV<T>::N;
+  for (long long u = (long long)blockIdx.x * 256 + threadIdx.x; u < units; u += (long long)gridDim.x * 256) {
+    float va[E], vb[E];
+    EV<T>::ld(a + u * E, va);
+    EV<T>::ld(b + u * E, vb);
+#pragma unroll
+    for (int i = 0; i < E; ++i) va[i] += vb[i];
+    EV<T>::st(out + u * E, va);
+  }
+}
+
 // ------------------------------------------------------------------ MaxPool2d(2,2)
 // Grid = (output rows n*oh, column blocks); 32-bit index arithmetic per row.
 // `idx` (optional, training): one byte per pooled element -- bits 0..1 = which of the four inputs (row-major, the FIRST one equal
@@ -450,7 +437,7 @@ __global__ __launch_bounds__(256) void u8_to_image_kernel(const unsigned char* _
 template <typename T>
 __global__ __launch_bounds__(256) void maxpool2_fwd_kernel(const T* __restrict__ x, T* __restrict__ y, unsigned char* __restrict__ idx,
                                                            int h, int w, int c) {
-  constexpr int E = V16<T>::N;
+  constexpr int E = EV<T>::N;
   const int cu = c / E, oh = h / 2, ow = w / 2;
   const int row = blockIdx.x;
   const int n = row / oh, oy = row - n * oh;
@@ -462,10 +449,10 @@ __global__ __launch_bounds__(256) void maxpool2_fwd_kernel(const T* __restrict__
     const unsigned ox = u / cu, un = u - ox * cu;
     const T* s = src + (size_t)(2 * ox) * c + un * E;
     float a[E], b[E], d[E], e[E];
-    V16<T>::ld(s, a);
-    V16<T>::ld(s + c, b);
-    V16<T>::ld(s + rs, d);
-    V16<T>::ld(s + rs + c, e);
+    EV<T>::ld(s, a);
+    EV<T>::ld(s + c, b);
+    EV<T>::ld(s + rs, d);
+    EV<T>::ld(s + rs + c, e);
     unsigned code[E];
 #pragma unroll
     for (int i = 0; i < E; ++i) {
@@ -473,7 +460,7 @@ __global__ __launch_bounds__(256) void maxpool2_fwd_kernel(const T* __restrict__
       code[i] = (a[i] == m ? 0u : (b[i] == m ? 1u : (d[i] == m ? 2u : 3u))) | (m > 0.f ? 4u : 0u);
       a[i] = m;
     }
-    V16<T>::st(dst + (size_t)u * E, a);
+    EV<T>::st(dst + (size_t)u * E, a);
     if (idx) {
       unsigned char* ip = idx + (size_t)row * ow * c + (size_t)u * E;
       if constexpr (E == 8) {
@@ -489,7 +476,7 @@ __global__ __launch_bounds__(256) void maxpool2_fwd_kernel(const T* __restrict__
 template <typename T>
 __global__ __launch_bounds__(256) void maxpool2_bwd_idx_kernel(const T* __restrict__ g, const unsigned char* __restrict__ idx,
                                                                T* __restrict__ dx, int h, int w, int c, int relu_mask) {
-  constexpr int E = V16<T>::N;
+  constexpr int E = EV<T>::N;
   const int cu = c / E, oh = h / 2, ow = w / 2;
   const int row = blockIdx.x;
   const int n = row / oh, oy = row - n * oh;
@@ -502,7 +489,7 @@ __global__ __launch_bounds__(256) void maxpool2_bwd_idx_kernel(const T* __restri
     const size_t base = in0 + (size_t)(2 * ox) * c + un * E;
     float gv[E], o[E];
     unsigned code[E];
-    V16<T>::ld(g + out0 + (size_t)u * E, gv);
+    EV<T>::ld(g + out0 + (size_t)u * E, gv);
     const unsigned char* ip = idx + out0 + (size_t)u * E;
     if constexpr (E == 8) {
       const u32x2 t = *(const u32x2*)ip;
@@ -520,7 +507,7 @@ __global__ __launch_bounds__(256) void maxpool2_bwd_idx_kernel(const T* __restri
     for (int k = 0; k < 4; ++k) {
 #pragma unroll
       for (int i = 0; i < E; ++i) o[i] = ((code[i] & 3u) == (unsigned)k && (!relu_mask || (code[i] & 4u))) ? gv[i] : 0.f;
-      V16<T>::st(dx + base + (size_t)(k >> 1) * rs + (k & 1) * c, o);
+      EV<T>::st(dx + base + (size_t)(k >> 1) * rs + (k & 1) * c, o);
     }
   }
 }
@@ -529,7 +516,7 @@ template <typename T>
 __global__ __launch_bounds__(256) void maxpool2_bwd_kernel(const T* __restrict__ g, const T* __restrict__ x,
                                                            const T* __restrict__ y, T* __restrict__ dx, int h, int w, int c,
                                                            int relu_mask) {
-  constexpr int E = V16<T>::N;
+  constexpr int E = EV<T>::N;
   const int cu = c / E, oh = h / 2, ow = w / 2;
   const int row = blockIdx.x;
   const int n = row / oh, oy = row - n * oh;
@@ -542,10 +529,10 @@ __global__ __launch_bounds__(256) void maxpool2_bwd_kernel(const T* __restrict__
     const size_t base = in0 + (size_t)(2 * ox) * c + un * E;
     float gv[E], yv[E], xv[4][E], o[E];
     bool taken[E];
-    V16<T>::ld(g + out0 + (size_t)u * E, gv);
-    V16<T>::ld(y + out0 + (size_t)u * E, yv);
+    EV<T>::ld(g + out0 + (size_t)u * E, gv);
+    EV<T>::ld(y + out0 + (size_t)u * E, yv);
 #pragma unroll
-    for (int k = 0; k < 4; ++k) V16<T>::ld(x + base + (size_t)(k >> 1) * rs + (k & 1) * c, xv[k]);
+    for (int k = 0; k < 4; ++k) EV<T>::ld(x + base + (size_t)(k >> 1) * rs + (k & 1) * c, xv[k]);
 #pragma unroll
     for (int i = 0; i < E; ++i) taken[i] = false;
 #pragma unroll
@@ -556,7 +543,7 @@ __global__ __launch_bounds__(256) void maxpool2_bwd_kernel(const T* __restrict__
         o[i] = (hit && !(relu_mask && xv[k][i] <= 0.f)) ? gv[i] : 0.f;
         taken[i] = taken[i] || hit;
       }
-      V16<T>::st(dx + base + (size_t)(k >> 1) * rs + (k & 1) * c, o);
+      EV<T>::st(dx + base + (size_t)(k >> 1) * rs + (k & 1) * c, o);
     }
   }
 }
@@ -605,9 +592,15 @@ template <typename T> T* P(void* p) { return (T*)p; }
 template <typename T> const T* P(const void* p) { return (const T*)p; }
 
 int check_c(const char* what, int dtype, int c) {
-  const int e = dtype != FSR_F32 ? 8 : 4;
-  if (dtype != FSR_F32 && dtype != FSR_BF16 && dtype != FSR_F16) return fsr_fail(-2, "%s: unknown dtype %d", what, dtype);
+  const int e = dtype == FSR_X3 ? 32 : (dtype != FSR_F32 ? 8 : 4);   // x3: whole hi / lo groups of 32 channels
+  if (dtype != FSR_F32 && dtype != FSR_BF16 && dtype != FSR_F16 && dtype != FSR_X3) return fsr_fail(-2, "%s: unknown dtype %d", what, dtype);
   if (c <= 0 || c % e != 0) return fsr_fail(-2, "%s: channel count %d is not a multiple of %d", what, c, e);
+  return 0;
+}
+// x3 tensors: the split hi / lo addressing needs 128-byte aligned bases
+int check_x3(const char* what, int dtype, const void* a, const void* b = nullptr, const void* c = nullptr, const void* d = nullptr) {
+  if (dtype != FSR_X3) return 0;
+  if ((((size_t)a | (size_t)b | (size_t)c | (size_t)d) & 127) != 0) return fsr_fail(-2, "%s: x3 tensors must be 128-byte aligned", what);
   return 0;
 }
 int check_reduce_c(const char* what, int dtype, int c) {
@@ -634,6 +627,9 @@ int slabs_for(int n, int hw) {
   } else if ((dtype) == FSR_F16) {                    \
     typedef f16_t T;                                  \
     __VA_ARGS__                                       \
+  } else if ((dtype) == FSR_X3) {                     \
+    typedef x3_t T;                                   \
+    __VA_ARGS__                                       \
   } else {                                            \
     typedef float T;                                  \
     __VA_ARGS__                                       \
@@ -645,6 +641,7 @@ extern "C" int fsr_instnorm_act_fwd(int dtype, const void* x, const float* stats
   if (!x || !stats || !out) return fsr_fail(-1, "fsr_instnorm_act_fwd: null argument");
   if (act == FSR_ACT_PRELU && !prelu_weight) return fsr_fail(-1, "fsr_instnorm_act_fwd: PReLU needs its weight");
   if (int rc = check_reduce_c("fsr_instnorm_act_fwd", dtype, c)) return rc;
+  if (int rc = check_x3("fsr_instnorm_act_fwd", dtype, x, res, out)) return rc;
   const long long units = (long long)hw * (c / (dtype != FSR_F32 ? 8 : 4));   // per image
   if (units >= (1LL << 31)) return fsr_fail(-2, "fsr_instnorm_act_fwd: image too large");
   FSR_DISPATCH_T(dtype, hipLaunchKernelGGL(instnorm_act_fwd_kernel<T>, dim3(image_blocks(units, n), n), dim3(256), 0,
@@ -664,6 +661,7 @@ extern "C" int fsr_instnorm_act_bwd_reduce(int dtype, const void* g, const void*
   if (!g || !x || !stats || !sums || !scratch) return fsr_fail(-1, "fsr_instnorm_act_bwd_reduce: null argument");
   if (act == FSR_ACT_PRELU && !prelu_weight) return fsr_fail(-1, "fsr_instnorm_act_bwd_reduce: PReLU needs its weight");
   if (int rc = check_reduce_c("fsr_instnorm_act_bwd_reduce", dtype, c)) return rc;
+  if (int rc = check_x3("fsr_instnorm_act_bwd_reduce", dtype, g, x)) return rc;
   const int slabs = slabs_for(n, hw);
   float* part = (float*)scratch;                         // [n][slabs][c][2]
   float* part_p = part + (size_t)n * slabs * c * 2;      // [n * slabs]
@@ -683,6 +681,7 @@ extern "C" int fsr_instnorm_act_bwd_apply(int dtype, const void* g, const void* 
   if (!g || !x || !stats || !sums || !dx) return fsr_fail(-1, "fsr_instnorm_act_bwd_apply: null argument");
   if (act == FSR_ACT_PRELU && !prelu_weight) return fsr_fail(-1, "fsr_instnorm_act_bwd_apply: PReLU needs its weight");
   if (int rc = check_reduce_c("fsr_instnorm_act_bwd_apply", dtype, c)) return rc;
+  if (int rc = check_x3("fsr_instnorm_act_bwd_apply", dtype, g, x, dx)) return rc;
   const long long units = (long long)hw * (c / (dtype != FSR_F32 ? 8 : 4));
   if (units >= (1LL << 31)) return fsr_fail(-2, "fsr_instnorm_act_bwd_apply: image too large");
   FSR_DISPATCH_T(dtype, hipLaunchKernelGGL(instnorm_act_bwd_apply_kernel<T>, dim3(image_blocks(units, n), n), dim3(256), 0,
@@ -708,6 +707,7 @@ extern "C" int fsr_act_bwd(int dtype, const void* g, const void* saved, int act,
   if (act == FSR_ACT_PRELU && !prelu_weight) return fsr_fail(-1, "fsr_act_bwd: PReLU needs its weight");
   if (act == FSR_ACT_TANH) return fsr_fail(-2, "fsr_act_bwd: tanh is handled by fsr_tanh_bwd_to_nhwc");
   if (int rc = check_reduce_c("fsr_act_bwd", dtype, c)) return rc;
+  if (int rc = check_x3("fsr_act_bwd", dtype, g, saved, dz)) return rc;
   if (pixel_shuffled && ((h | w) & 1)) return fsr_fail(-2, "fsr_act_bwd: pixel-shuffled tensors have even extents");
   if (!saved) saved = g;  // FSR_ACT_NONE: only the bias gradient is wanted; act_dz ignores the value
   const int nclass = pixel_shuffled ? 4 : 1;
@@ -731,6 +731,7 @@ extern "C" int fsr_image_to_nhwc(int dtype, const float* img, long long sn, long
   hipStream_t stream = (hipStream_t)stream_;
   if (!img || !out) return fsr_fail(-1, "fsr_image_to_nhwc: null argument");
   if (int rc = check_c("fsr_image_to_nhwc", dtype, cpad)) return rc;
+  if (int rc = check_x3("fsr_image_to_nhwc", dtype, out)) return rc;
   const int rowunits = w * (cpad / (dtype != FSR_F32 ? 8 : 4));
   FSR_DISPATCH_T(dtype, hipLaunchKernelGGL(image_to_nhwc_kernel<T>, dim3(n * h, row_blocks(rowunits)), dim3(256), 0, stream,
                                            img, sn, sc, sh, sw, h, w, scale0, scale1, scale2, shift0, shift1, shift2,
@@ -755,6 +756,7 @@ extern "C" int fsr_tanh_bwd_to_nhwc(int dtype, const float* g, long long sn, lon
   if (!g || !y_nhwc3 || !dz) return fsr_fail(-1, "fsr_tanh_bwd_to_nhwc: null argument");
   if (dbias && !scratch) return fsr_fail(-1, "fsr_tanh_bwd_to_nhwc: the bias gradient needs the scratch buffer");
   if (int rc = check_c("fsr_tanh_bwd_to_nhwc", dtype, cpad)) return rc;
+  if (int rc = check_x3("fsr_tanh_bwd_to_nhwc", dtype, dz)) return rc;
   const int rowunits = w * (cpad / (dtype != FSR_F32 ? 8 : 4));
   const int gx = n * h < 512 ? n * h : 512, gy = row_blocks(rowunits);   // <= 512 x 64 workgroups
   FSR_DISPATCH_T(dtype, hipLaunchKernelGGL(tanh_bwd_to_nhwc_kernel<T>, dim3(gx, gy), dim3(256), 0,
@@ -779,10 +781,25 @@ extern "C" int fsr_tanh_bwd_image(const float* g, long long sn, long long sc, lo
   return 0;
 }
 
+extern "C" int fsr_add(int dtype, const void* a, const void* b, void* out, long long count, fsr_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  if (!a || !b || !out || count <= 0) return fsr_fail(-1, "fsr_add: bad argument");
+  if (dtype != FSR_F32 && dtype != FSR_BF16 && dtype != FSR_F16 && dtype != FSR_X3) return fsr_fail(-2, "fsr_add: unknown dtype %d", dtype);
+  const int e = dtype == FSR_X3 ? 32 : (dtype != FSR_F32 ? 8 : 4);
+  if (count % e) return fsr_fail(-2, "fsr_add: count %lld is not a multiple of %d", count, e);
+  if (int rc = check_x3("fsr_add", dtype, a, b, out)) return rc;
+  const long long units = count / (dtype != FSR_F32 ? 8 : 4);
+  long long blocks = (units + 255) / 256;
+  if (blocks > 4096) blocks = 4096;
+  FSR_DISPATCH_T(dtype, hipLaunchKernelGGL(add_kernel<T>, dim3((unsigned)blocks), dim3(256), 0, stream, P<T>(a), P<T>(b), P<T>(out), units);)
+  return fsr_check_launch("add_kernel");
+}
+
 extern "C" int fsr_maxpool2_fwd(int dtype, const void* x, void* y, void* argmax, int n, int h, int w, int c, fsr_stream_t stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   if (!x || !y) return fsr_fail(-1, "fsr_maxpool2_fwd: null argument");
   if (int rc = check_c("fsr_maxpool2_fwd", dtype, c)) return rc;
+  if (int rc = check_x3("fsr_maxpool2_fwd", dtype, x, y)) return rc;
   if ((h | w) & 1) return fsr_fail(-2, "fsr_maxpool2_fwd: odd extent %dx%d", h, w);
   const int rowunits = (w / 2) * (c / (dtype != FSR_F32 ? 8 : 4));
   FSR_DISPATCH_T(dtype, hipLaunchKernelGGL(maxpool2_fwd_kernel<T>, dim3(n * (h / 2), row_blocks(rowunits)), dim3(256), 0,
@@ -795,6 +812,7 @@ extern "C" int fsr_maxpool2_bwd_argmax(int dtype, const void* g, const void* arg
   hipStream_t stream = (hipStream_t)stream_;
   if (!g || !argmax || !dx) return fsr_fail(-1, "fsr_maxpool2_bwd_argmax: null argument");
   if (int rc = check_c("fsr_maxpool2_bwd_argmax", dtype, c)) return rc;
+  if (int rc = check_x3("fsr_maxpool2_bwd_argmax", dtype, g, dx)) return rc;
   if ((h | w) & 1) return fsr_fail(-2, "fsr_maxpool2_bwd_argmax: odd extent %dx%d", h, w);
   const int rowunits = (w / 2) * (c / (dtype != FSR_F32 ? 8 : 4));
   FSR_DISPATCH_T(dtype, hipLaunchKernelGGL(maxpool2_bwd_idx_kernel<T>, dim3(n * (h / 2), row_blocks(rowunits)), dim3(256), 0,
@@ -807,6 +825,7 @@ extern "C" int fsr_maxpool2_bwd(int dtype, const void* g, const void* x, const v
   hipStream_t stream = (hipStream_t)stream_;
   if (!g || !x || !y || !dx) return fsr_fail(-1, "fsr_maxpool2_bwd: null argument");
   if (int rc = check_c("fsr_maxpool2_bwd", dtype, c)) return rc;
+  if (int rc = check_x3("fsr_maxpool2_bwd", dtype, g, x, y, dx)) return rc;
   if ((h | w) & 1) return fsr_fail(-2, "fsr_maxpool2_bwd: odd extent %dx%d", h, w);
   const int rowunits = (w / 2) * (c / (dtype != FSR_F32 ? 8 : 4));
   FSR_DISPATCH_T(dtype, hipLaunchKernelGGL(maxpool2_bwd_kernel<T>, dim3(n * (h / 2), row_blocks(rowunits)), dim3(256), 0,

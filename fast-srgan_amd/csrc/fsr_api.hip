@@ -114,7 +114,7 @@ static int conv3x3_impl(const fsr_conv_desc* d, const void* in, const void* pack
   a.dmask_bits = (dact_mask && d->mask_is_addend == 2) ? 1 : 0;
   if (d->mask_is_addend && !dact_mask) return fsr_fail(-1, "fsr_conv3x3: mask_is_addend needs the dact_mask tensor");
   if (d->mask_is_addend < 0 || d->mask_is_addend > 2) return fsr_fail(-2, "fsr_conv3x3: mask_is_addend must be 0, 1 or 2");
-  if (a.dmask_bits && (d->mode != FSR_CONV_DGRAD || d->stride != 2 || d->dtype == FSR_F32 || d->cout % 64 != 0))
+  if (a.dmask_bits && (d->mode != FSR_CONV_DGRAD || d->stride != 2 || d->dtype == FSR_F32 || d->dtype == FSR_X3 || d->cout % 64 != 0))
     return fsr_fail(-2, "fsr_conv3x3: a sign-bit mask (mask_is_addend = 2) is read by the stride-2 data gradients of the 16-bit modes, cout %% 64 == 0");
   a.stats = stats ? (float*)scratch : nullptr;   // the kernels write per-workgroup partials; finished below
   a.stats_P_max = stats ? (int)stats_slots_bound(d) : 0;   // launchers compare their slot count with this BEFORE launching
@@ -124,8 +124,16 @@ static int conv3x3_impl(const fsr_conv_desc* d, const void* in, const void* pack
   a.N = d->n;
   a.IH = d->ih;
   a.IW = d->iw;
-  a.Cin = d->cin;
+  a.Cin = d->dtype == FSR_X3 ? 2 * d->cin : d->cin;   // x3: the kernels see a bf16 tensor of 2 x cin channels (hi / lo chunks of 32)
   a.Cout = d->cout;
+  if (d->dtype == FSR_X3) {
+    if (d->cin % 32 != 0) return fsr_fail(-2, "fsr_conv3x3: x3 tensors have a multiple of 32 channels (cin = %d)", d->cin);
+    if (!d->out_f32 && d->cout % 32 != 0) return fsr_fail(-2, "fsr_conv3x3: x3 tensors have a multiple of 32 channels (cout = %d)", d->cout);
+    if (d->pixel_shuffle && (d->cout / 4) % 32 != 0) return fsr_fail(-2, "fsr_conv3x3: x3 pixel shuffle needs cout / 4 %% 32 == 0");
+    if (d->in_pixel_shuffled && (d->cin / 4) % 32 != 0) return fsr_fail(-2, "fsr_conv3x3: x3 in_pixel_shuffled needs cin / 4 %% 32 == 0");
+    if (!query_block && ((((size_t)in | (d->out_f32 ? 0 : (size_t)out) | (size_t)preact | (size_t)dact_mask) & 127) != 0))
+      return fsr_fail(-2, "fsr_conv3x3: x3 tensors must be 128-byte aligned");
+  }
   a.CoutPad = (d->cout + 15) / 16 * 16;
   a.FOH = d->oh;
   a.FOW = d->ow;

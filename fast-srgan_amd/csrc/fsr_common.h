@@ -169,6 +169,107 @@ template <typename T> __device__ __forceinline__ float cvt_lo(unsigned w) { retu
 template <typename T> __device__ __forceinline__ float cvt_hi(unsigned w) { return Num16<T>::hi(w); }
 template <typename T> __device__ __forceinline__ f32x4 mfma16(s16x8 a, s16x8 b, f32x4 c) { return Num16<T>::mfma(a, b, c); }
 
+// ---- FSR_X3, the split-bf16 storage type (include/fsr_hip.h): a logical element is 4 bytes; per pixel and per group of 32
+// channels the tensor holds 64 bytes of hi[32] (bf16(v)) followed by 64 bytes of lo[32] (bf16(v - hi)).  x3_t is only a
+// pointer type: `p + e` is the logical element e (4-byte steps), and the helpers below turn that pointer into the two physical
+// addresses -- byte b of the logical (float-like) layout lies in the 128-byte block b & ~127; its hi half word sits at
+// (b & 127) / 2 inside the block and its lo half word 64 bytes later.  Tensor bases are 128-byte aligned (host checked), and
+// every vector access covers 4 or 8 consecutive channels of one group, so a V16 unit is two 16-byte accesses 64 bytes apart.
+struct x3_t { unsigned raw; };
+static_assert(sizeof(x3_t) == 4, "x3_t is a 4-byte element");
+template <typename P> __device__ __forceinline__ P* x3_hi_ptr(P* p) {
+  const size_t b = (size_t)p;
+  return (P*)((b & ~(size_t)127) | ((b & (size_t)127) >> 1));
+}
+// two floats -> packed bf16 pair of the hi parts and packed pair of the lo parts (both round to nearest even)
+__device__ __forceinline__ void x3_split2(float a, float b, unsigned& hi, unsigned& lo) {
+  hi = pack_bf16x2(a, b);
+  lo = pack_bf16x2(a - __uint_as_float(hi << 16), b - __uint_as_float(hi & 0xffff0000u));
+}
+__device__ __forceinline__ float x3_join_lo(unsigned hi, unsigned lo) { return __uint_as_float(hi << 16) + __uint_as_float(lo << 16); }
+__device__ __forceinline__ float x3_join_hi(unsigned hi, unsigned lo) { return __uint_as_float(hi & 0xffff0000u) + __uint_as_float(lo & 0xffff0000u); }
+template <> struct ElemIO<x3_t> {
+  static __device__ __forceinline__ float ld(const x3_t* p) {
+    const bf16_t* h = (const bf16_t*)x3_hi_ptr(p);
+    return bf2f(h[0]) + bf2f(h[32]);
+  }
+  static __device__ __forceinline__ void st(x3_t* p, float v) {
+    bf16_t* h = (bf16_t*)x3_hi_ptr(p);
+    const bf16_t hi = f2bf(v);
+    h[0] = hi;
+    h[32] = f2bf(v - bf2f(hi));
+  }
+};
+// 4 consecutive channels (one lane's accumulator tile row): two 8-byte accesses
+__device__ __forceinline__ void x3_st4(x3_t* p, f32x4 v) {
+  unsigned h0, l0, h1, l1;
+  x3_split2(v[0], v[1], h0, l0);
+  x3_split2(v[2], v[3], h1, l1);
+  char* h = (char*)x3_hi_ptr(p);
+  *(u32x2*)h = (u32x2){h0, h1};
+  *(u32x2*)(h + 64) = (u32x2){l0, l1};
+}
+__device__ __forceinline__ f32x4 x3_ld4(const x3_t* p) {
+  const char* h = (const char*)x3_hi_ptr(p);
+  const u32x2 hi = *(const u32x2*)h, lo = *(const u32x2*)(h + 64);
+  return (f32x4){x3_join_lo(hi.x, lo.x), x3_join_hi(hi.x, lo.x), x3_join_lo(hi.y, lo.y), x3_join_hi(hi.y, lo.y)};
+}
+
+// ---- one 16-byte unit of a storage type viewed as floats (the HBM-bound kernels move one unit per lane and access):
+// 8 elements of a 16-bit type, 4 floats, or 8 x3 elements (16 bytes of hi + 16 bytes of lo)
+template <typename T, int NTBIT = 0> struct V16 {   // the 16-bit storage types (bf16_t, f16_t)
+  static constexpr int N = 8;
+  static __device__ __forceinline__ void ld(const T* p, float (&v)[8]) {
+    const u32x4 t = *(const u32x4*)p;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      v[2 * i] = cvt_lo<T>(t[i]);
+      v[2 * i + 1] = cvt_hi<T>(t[i]);
+    }
+  }
+  static __device__ __forceinline__ void st(T* p, const float (&v)[8]) {
+    u32x4 t;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) t[i] = pack2<T>(v[2 * i], v[2 * i + 1]);
+    fsr_st<NTBIT>((u32x4*)p, t);
+  }
+};
+template <int NTBIT> struct V16<float, NTBIT> {
+  static constexpr int N = 4;
+  static __device__ __forceinline__ void ld(const float* p, float (&v)[4]) {
+    const f32x4 t = *(const f32x4*)p;
+    v[0] = t[0]; v[1] = t[1]; v[2] = t[2]; v[3] = t[3];
+  }
+  static __device__ __forceinline__ void st(float* p, const float (&v)[4]) {
+    *(f32x4*)p = (f32x4){v[0], v[1], v[2], v[3]};
+  }
+};
+template <int NTBIT> struct V16<x3_t, NTBIT> {
+  static constexpr int N = 8;
+  static __device__ __forceinline__ void ld(const x3_t* p, float (&v)[8]) {
+    const char* h = (const char*)x3_hi_ptr(p);
+    const u32x4 hi = *(const u32x4*)h, lo = *(const u32x4*)(h + 64);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      v[2 * i] = x3_join_lo(hi[i], lo[i]);
+      v[2 * i + 1] = x3_join_hi(hi[i], lo[i]);
+    }
+  }
+  static __device__ __forceinline__ void st(x3_t* p, const float (&v)[8]) {
+    u32x4 hi, lo;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      unsigned a, b;
+      x3_split2(v[2 * i], v[2 * i + 1], a, b);
+      hi[i] = a;
+      lo[i] = b;
+    }
+    char* h = (char*)x3_hi_ptr(p);
+    fsr_st<NTBIT>((u32x4*)h, hi);
+    fsr_st<NTBIT>((u32x4*)(h + 64), lo);
+  }
+};
+
 __device__ __forceinline__ f32x4 mfma_f32_16x16x4(float a, float b, f32x4 c) {
   return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
 }

@@ -50,31 +50,7 @@ __global__ __launch_bounds__(256) void bce_logits_bwd_kernel(const float* __rest
   }
 }
 
-template <typename T> struct LV {  // 16-byte unit loader; generic = the 16-bit storage types (bf16_t, f16_t)
-  static constexpr int N = 8;
-  static __device__ __forceinline__ void ld(const T* p, float (&v)[8]) {
-    const u32x4 t = *(const u32x4*)p;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      v[2 * i] = cvt_lo<T>(t[i]);
-      v[2 * i + 1] = cvt_hi<T>(t[i]);
-    }
-  }
-  static __device__ __forceinline__ void st(T* p, const float (&v)[8]) {
-    u32x4 t;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) t[i] = pack2<T>(v[2 * i], v[2 * i + 1]);
-    *(u32x4*)p = t;
-  }
-};
-template <> struct LV<float> {
-  static constexpr int N = 4;
-  static __device__ __forceinline__ void ld(const float* p, float (&v)[4]) {
-    const f32x4 t = *(const f32x4*)p;
-    v[0] = t[0]; v[1] = t[1]; v[2] = t[2]; v[3] = t[3];
-  }
-  static __device__ __forceinline__ void st(float* p, const float (&v)[4]) { *(f32x4*)p = (f32x4){v[0], v[1], v[2], v[3]}; }
-};
+template <typename T> struct LV : V16<T, 0> {};   // 16-byte unit loader (fsr_common.h)
 template <typename T>
 __global__ __launch_bounds__(256) void smooth_l1_fwd_kernel(const T* __restrict__ a, const T* __restrict__ b,
                                                             float* __restrict__ loss, long long units) {
@@ -306,7 +282,8 @@ extern "C" int fsr_smooth_l1_fwd(int dtype, const void* a, const void* b, float*
                                  fsr_stream_t stream_) {
   if (!a || !b || !loss || !scratch || count <= 0) return fsr_fail(-1, "fsr_smooth_l1_fwd: bad argument");
   const int e = dtype != FSR_F32 ? 8 : 4;
-  if (count % e) return fsr_fail(-2, "fsr_smooth_l1_fwd: count %lld is not a multiple of %d", count, e);
+  if (count % (dtype == FSR_X3 ? 32 : e)) return fsr_fail(-2, "fsr_smooth_l1_fwd: count %lld is not a multiple of %d", count, dtype == FSR_X3 ? 32 : e);
+  if (dtype == FSR_X3 && ((((size_t)a | (size_t)b) & 127) != 0)) return fsr_fail(-2, "fsr_smooth_l1_fwd: x3 tensors must be 128-byte aligned");
   const long long units = count / e;
   const int blocks = red_blocks(units * 4);
   if (dtype == FSR_F16)
@@ -315,6 +292,9 @@ extern "C" int fsr_smooth_l1_fwd(int dtype, const void* a, const void* b, float*
   else if (dtype == FSR_BF16)
     hipLaunchKernelGGL(smooth_l1_fwd_kernel<bf16_t>, dim3(blocks), dim3(256), 0, (hipStream_t)stream_,
                        (const bf16_t*)a, (const bf16_t*)b, (float*)scratch, units);
+  else if (dtype == FSR_X3)
+    hipLaunchKernelGGL(smooth_l1_fwd_kernel<x3_t>, dim3(blocks), dim3(256), 0, (hipStream_t)stream_,
+                       (const x3_t*)a, (const x3_t*)b, (float*)scratch, units);
   else if (dtype == FSR_F32)
     hipLaunchKernelGGL(smooth_l1_fwd_kernel<float>, dim3(blocks), dim3(256), 0, (hipStream_t)stream_,
                        (const float*)a, (const float*)b, (float*)scratch, units);
@@ -327,7 +307,8 @@ extern "C" int fsr_smooth_l1_bwd(int dtype, const void* a, const void* b, const 
                                  fsr_stream_t stream_) {
   if (!a || !b || !gscale || !da || count <= 0) return fsr_fail(-1, "fsr_smooth_l1_bwd: bad argument");
   const int e = dtype != FSR_F32 ? 8 : 4;
-  if (count % e) return fsr_fail(-2, "fsr_smooth_l1_bwd: count %lld is not a multiple of %d", count, e);
+  if (count % (dtype == FSR_X3 ? 32 : e)) return fsr_fail(-2, "fsr_smooth_l1_bwd: count %lld is not a multiple of %d", count, dtype == FSR_X3 ? 32 : e);
+  if (dtype == FSR_X3 && ((((size_t)a | (size_t)b | (size_t)da) & 127) != 0)) return fsr_fail(-2, "fsr_smooth_l1_bwd: x3 tensors must be 128-byte aligned");
   const long long units = count / e;
   if (dtype == FSR_F16)
     hipLaunchKernelGGL(smooth_l1_bwd_kernel<f16_t>, dim3(red_blocks(units * 4)), dim3(256), 0, (hipStream_t)stream_,
@@ -335,6 +316,9 @@ extern "C" int fsr_smooth_l1_bwd(int dtype, const void* a, const void* b, const 
   else if (dtype == FSR_BF16)
     hipLaunchKernelGGL(smooth_l1_bwd_kernel<bf16_t>, dim3(red_blocks(units * 4)), dim3(256), 0, (hipStream_t)stream_,
                        (const bf16_t*)a, (const bf16_t*)b, gscale, (bf16_t*)da, units, 1.f / (float)count);
+  else if (dtype == FSR_X3)
+    hipLaunchKernelGGL(smooth_l1_bwd_kernel<x3_t>, dim3(red_blocks(units * 4)), dim3(256), 0, (hipStream_t)stream_,
+                       (const x3_t*)a, (const x3_t*)b, gscale, (x3_t*)da, units, 1.f / (float)count);
   else if (dtype == FSR_F32)
     hipLaunchKernelGGL(smooth_l1_bwd_kernel<float>, dim3(red_blocks(units * 4)), dim3(256), 0, (hipStream_t)stream_,
                        (const float*)a, (const float*)b, gscale, (float*)da, units, 1.f / (float)count);
@@ -343,9 +327,10 @@ extern "C" int fsr_smooth_l1_bwd(int dtype, const void* a, const void* b, const 
   return fsr_check_launch("smooth_l1_bwd_kernel");
 }
 
-static int c1_check(const char* what, int dtype, int c) {
-  if (dtype != FSR_F32 && dtype != FSR_BF16 && dtype != FSR_F16) return fsr_fail(-2, "%s: unknown dtype %d", what, dtype);
-  const int e = dtype != FSR_F32 ? 8 : 4;
+static int c1_check(const char* what, int dtype, int c, const void* x, const void* dx = nullptr) {
+  if (dtype != FSR_F32 && dtype != FSR_BF16 && dtype != FSR_F16 && dtype != FSR_X3) return fsr_fail(-2, "%s: unknown dtype %d", what, dtype);
+  if (dtype == FSR_X3 && ((((size_t)x | (size_t)dx) & 127) != 0)) return fsr_fail(-2, "%s: x3 tensors must be 128-byte aligned", what);
+  const int e = dtype == FSR_X3 ? 32 : (dtype != FSR_F32 ? 8 : 4);
   if (c <= 0 || c % e) return fsr_fail(-2, "%s: %d channels is not a multiple of %d", what, c, e);
   return 0;
 }
@@ -353,7 +338,7 @@ static int c1_check(const char* what, int dtype, int c) {
 extern "C" int fsr_conv1x1_c1_fwd(int dtype, const void* x, const float* w, const float* b, float* logits, int npix, int c,
                                   fsr_stream_t stream_) {
   if (!x || !w || !b || !logits || npix <= 0) return fsr_fail(-1, "fsr_conv1x1_c1_fwd: bad argument");
-  if (int rc = c1_check("fsr_conv1x1_c1_fwd", dtype, c)) return rc;
+  if (int rc = c1_check("fsr_conv1x1_c1_fwd", dtype, c, x)) return rc;
   int blocks = (npix + 3) / 4;
   if (blocks > 2048) blocks = 2048;
   if (dtype == FSR_F16)
@@ -361,6 +346,9 @@ extern "C" int fsr_conv1x1_c1_fwd(int dtype, const void* x, const float* w, cons
                        b, logits, npix, c);
   else if (dtype == FSR_BF16)
     hipLaunchKernelGGL(conv1x1_c1_fwd_kernel<bf16_t>, dim3(blocks), dim3(256), 0, (hipStream_t)stream_, (const bf16_t*)x, w,
+                       b, logits, npix, c);
+  else if (dtype == FSR_X3)
+    hipLaunchKernelGGL(conv1x1_c1_fwd_kernel<x3_t>, dim3(blocks), dim3(256), 0, (hipStream_t)stream_, (const x3_t*)x, w,
                        b, logits, npix, c);
   else
     hipLaunchKernelGGL(conv1x1_c1_fwd_kernel<float>, dim3(blocks), dim3(256), 0, (hipStream_t)stream_, (const float*)x, w, b,
@@ -373,7 +361,7 @@ extern "C" size_t fsr_conv1x1_c1_bwd_scratch(int c) { return c > 0 ? (size_t)512
 extern "C" int fsr_conv1x1_c1_bwd(int dtype, const float* g, const void* x, const float* w, void* dx, float* dw, float* db,
                                   void* scratch, int npix, int c, fsr_stream_t stream_) {
   if (!g || !x || !w || !dw || !db || !scratch || npix <= 0) return fsr_fail(-1, "fsr_conv1x1_c1_bwd: bad argument");
-  if (int rc = c1_check("fsr_conv1x1_c1_bwd", dtype, c)) return rc;
+  if (int rc = c1_check("fsr_conv1x1_c1_bwd", dtype, c, x, dx)) return rc;
   const int cu = c / (dtype != FSR_F32 ? 8 : 4);
   if (cu > 256 || 256 % cu) return fsr_fail(-2, "fsr_conv1x1_c1_bwd: %d channels do not tile a 256-thread workgroup", c);
   const int rows = 256 / cu;
@@ -387,6 +375,9 @@ extern "C" int fsr_conv1x1_c1_bwd(int dtype, const float* g, const void* x, cons
   else if (dtype == FSR_BF16)
     hipLaunchKernelGGL(conv1x1_c1_bwd_kernel<bf16_t>, dim3(blocks), dim3(256), 0, (hipStream_t)stream_, g, (const bf16_t*)x,
                        w, (bf16_t*)dx, part, npix, c);
+  else if (dtype == FSR_X3)
+    hipLaunchKernelGGL(conv1x1_c1_bwd_kernel<x3_t>, dim3(blocks), dim3(256), 0, (hipStream_t)stream_, g, (const x3_t*)x,
+                       w, (x3_t*)dx, part, npix, c);
   else
     hipLaunchKernelGGL(conv1x1_c1_bwd_kernel<float>, dim3(blocks), dim3(256), 0, (hipStream_t)stream_, g, (const float*)x, w,
                        (float*)dx, part, npix, c);

@@ -3,13 +3,16 @@
 #include "fsr_common.h"
 #include "fsr_host.h"
 
-template <typename T>
+// X3 (FSR_X3, T = bf16_t): K counts PHYSICAL channels, 2 x the logical K; physical index kp holds the hi (bit 5 clear) or
+// lo (bit 5 set) part of logical channel (kp >> 6) * 32 + (kp & 31) -- the chunk order of an x3 activation tensor.
+template <typename T, bool X3 = false>
 __global__ void pack_conv3x3_kernel(const float* __restrict__ w, T* __restrict__ out, int cout, int cin, int mode,
                                     int rows, int rows_pad, int K, int Kreal) {
   const long long total = 9LL * rows_pad * K;
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
        i += (long long)gridDim.x * blockDim.x) {
-    const int k = (int)(i % K);
+    const int kp = (int)(i % K);
+    const int k = X3 ? (kp >> 6) * 32 + (kp & 31) : kp;
     const int row = (int)((i / K) % rows_pad);
     const int t = (int)(i / ((long long)K * rows_pad));
     float v = 0.f;
@@ -32,7 +35,12 @@ __global__ void pack_conv3x3_kernel(const float* __restrict__ w, T* __restrict__
       }
       v = w[((size_t)co * cin + ci) * 9 + t];
     }
-    ElemIO<T>::st(out + i, v);
+    if constexpr (X3) {
+      const bf16_t hi = f2bf(v);
+      out[i] = (kp & 32) ? f2bf(v - bf2f(hi)) : hi;
+    } else {
+      ElemIO<T>::st(out + i, v);
+    }
   }
 }
 
@@ -109,7 +117,8 @@ extern "C" int fsr_pack_conv3x3(int dtype, int mode, const float* w_oihw, int co
   const bool fwd = (mode == FSR_PACK_FWD || mode == FSR_PACK_FWD_PS);
   const int rows = fwd ? cout : cin, Kreal = fwd ? cin : cout;
   if (k_pad < Kreal) return fsr_fail(-2, "fsr_pack_conv3x3: k_pad %d < K %d", k_pad, Kreal);
-  const int K = k_pad;
+  if (dtype == FSR_X3 && k_pad % 32) return fsr_fail(-2, "fsr_pack_conv3x3: x3 packs need k_pad %% 32 == 0");
+  const int K = dtype == FSR_X3 ? 2 * k_pad : k_pad;      // x3: physical channels, hi / lo chunks of 32
   const int rows_pad = (rows + 15) / 16 * 16;
   const long long total = 9LL * rows_pad * K;
   int blocks = (int)((total + 255) / 256);
@@ -119,6 +128,9 @@ extern "C" int fsr_pack_conv3x3(int dtype, int mode, const float* w_oihw, int co
                        cin, mode, rows, rows_pad, K, Kreal);
   else if (dtype == FSR_BF16)
     hipLaunchKernelGGL(pack_conv3x3_kernel<bf16_t>, dim3(blocks), dim3(256), 0, stream, w_oihw, (bf16_t*)packed, cout,
+                       cin, mode, rows, rows_pad, K, Kreal);
+  else if (dtype == FSR_X3)
+    hipLaunchKernelGGL((pack_conv3x3_kernel<bf16_t, true>), dim3(blocks), dim3(256), 0, stream, w_oihw, (bf16_t*)packed, cout,
                        cin, mode, rows, rows_pad, K, Kreal);
   else if (dtype == FSR_F32)
     hipLaunchKernelGGL(pack_conv3x3_kernel<float>, dim3(blocks), dim3(256), 0, stream, w_oihw, (float*)packed, cout,

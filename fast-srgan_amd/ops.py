@@ -14,21 +14,100 @@ import torch
 
 from . import _lib as L
 
-_DT = {"f32": (L.FSR_F32, torch.float32, 16), "bf16": (L.FSR_BF16, torch.bfloat16, 32), "f16": (L.FSR_F16, torch.float16, 32)}
+_DT = {"f32": (L.FSR_F32, torch.float32, 16), "bf16": (L.FSR_BF16, torch.bfloat16, 32), "f16": (L.FSR_F16, torch.float16, 32),
+       "x3": (L.FSR_X3, torch.float32, 32)}
 
 
 class Compute:
-    """Compute mode of a module: 'bf16' / 'f16' (16-bit MFMA, f32 accumulate; f16 = BASELINE configs[4]) or 'f32' (exact-f32
-    MFMA, the parity mode)."""
+    """Compute mode of a module: 'bf16' / 'f16' (16-bit MFMA, f32 accumulate; f16 = BASELINE configs[4]), 'f32' (exact-f32
+    MFMA, the parity mode) or 'x3' (split bf16: every value is the pair hi = bf16(v), lo = bf16(v - hi), every product three
+    bf16 MFMAs into one f32 accumulator -- the fast mode inside the reference's fp32 tolerance).
+
+    An x3 activation lives in a float32 tensor of its logical shape (same bytes: per pixel and 32-channel group 64 bytes of
+    hi, then 64 bytes of lo; include/fsr_hip.h).  The container is NOT float data: torch arithmetic on it is meaningless, only
+    copies (cat along the batch, clone, slicing whole pixels) are legal -- x3_encode / x3_decode convert."""
 
     def __init__(self, name="bf16"):
         if name not in _DT:
-            raise ValueError("compute dtype must be 'bf16', 'f16' or 'f32', got %r" % (name,))
+            raise ValueError("compute dtype must be 'bf16', 'f16', 'x3' or 'f32', got %r" % (name,))
         self.name = name
         self.code, self.torch_dtype, self.cpad = _DT[name]
+        self.x3 = name == "x3"
+        # packed filters: the MFMA operand type; an x3 pack holds 2 x K bf16 elements per row ([w_hi | w_lo] per 32 channels)
+        self.pack_dtype = torch.bfloat16 if self.x3 else self.torch_dtype
+        self.pack_kmul = 2 if self.x3 else 1
+        self.is16 = name in ("bf16", "f16")     # plain 16-bit storage: the kernels that exist for those modes only
 
     def pad(self, c):
         return (c + self.cpad - 1) // self.cpad * self.cpad
+
+
+def _empty(shape, dtype, device):
+    """Activation storage.  x3 kernels address hi / lo halves through 128-byte blocks of the tensor: the GPU allocator hands out
+    512-byte aligned blocks, the CPU allocator of the emulated test runs only 64-byte aligned ones."""
+    if torch.device(device).type != "cpu":
+        return torch.empty(shape, dtype=dtype, device=device)
+    n = 1
+    for d in shape:
+        n *= d
+    es = torch.empty((), dtype=dtype).element_size()
+    flat = torch.empty(n + 128 // es, dtype=dtype, device=device)
+    off = (-flat.data_ptr() % 128) // es
+    return flat[off:off + n].view(shape)
+
+
+def _empty_like(t):
+    return _empty(tuple(t.shape), t.dtype, t.device)
+
+
+def _aligned(t):
+    """t, or a 128-byte aligned copy of it (CPU tensors of the emulated runs only)."""
+    if t is None or t.is_cuda or t.data_ptr() % 128 == 0:
+        return t
+    out = _empty_like(t)
+    out.copy_(t)
+    return out
+
+
+def x3_encode(x):
+    """float32 (..., C) tensor, C % 32 == 0 -> its x3 storage form (a float32 tensor of the same shape; see Compute)."""
+    if x.dtype != torch.float32 or x.shape[-1] % 32:
+        raise ValueError("x3_encode expects a float32 tensor with a multiple of 32 channels, got %s %s" % (x.dtype, tuple(x.shape)))
+    x = x.contiguous()
+    hi = x.to(torch.bfloat16)
+    lo = (x - hi.float()).to(torch.bfloat16)
+    g = x.shape[-1] // 32
+    pair = torch.stack([hi.view(*x.shape[:-1], g, 32), lo.view(*x.shape[:-1], g, 32)], dim=-2)     # (..., g, 2, 32) bf16
+    out = _empty(tuple(x.shape), torch.float32, x.device)
+    out.view(torch.bfloat16).view(*x.shape[:-1], g, 2, 32).copy_(pair)
+    return out
+
+
+def x3_decode(t):
+    """x3 storage (float32 container, (..., C)) -> the float32 values hi + lo."""
+    t = t.contiguous()
+    g = t.shape[-1] // 32
+    pair = t.view(torch.bfloat16).view(*t.shape[:-1], g, 2, 32).float()
+    return (pair[..., 0, :] + pair[..., 1, :]).reshape(t.shape)
+
+
+def to_storage(cd, x):
+    """float32 NHWC values -> the storage tensor of compute mode `cd` (tests, module boundaries)."""
+    return x3_encode(x.float()) if cd.x3 else x.to(cd.torch_dtype)
+
+
+def from_storage(cd, t):
+    """storage tensor of compute mode `cd` -> float32 values."""
+    return x3_decode(t) if cd.x3 else t.float()
+
+
+def add(cd, a, b):
+    """a + b of two activation tensors (fsr_add): what autograd's accumulation would do, legal for x3 containers."""
+    _check_dev(a, b)
+    a, b = _aligned(a.contiguous()), _aligned(b.contiguous())
+    out = _empty_like(a)
+    L.check(L.lib().fsr_add(cd.code, _p(a), _p(b), _p(out), a.numel(), _stream()), "fsr_add")
+    return out
 
 
 def _stream():
@@ -94,13 +173,15 @@ def packed_filter(cd, weight, mode, k_pad, lin=0):
     if w.dtype != torch.float32 or not w.is_contiguous():
         w = w.float().contiguous()
     _check_dev(w)
+    if cd.x3 and (lin or mode in (PACK_C3, PACK_C3T)):
+        raise L.FsrError("x3 filters exist in the standard pack only")
     if mode == PACK_C3T:
         numel = ((cin + 15) // 16 * 16) * 32
     else:
-        numel = ((cout + 15) // 16 * 16) * 32 if mode == PACK_C3 else 9 * (rows if lin else rows_pad) * k_pad
+        numel = ((cout + 15) // 16 * 16) * 32 if mode == PACK_C3 else 9 * (rows if lin else rows_pad) * k_pad * cd.pack_kmul
     out = hit[1] if (hit is not None and hit[1].device == w.device) else None
     if out is None:
-        out = torch.empty(numel, dtype=cd.torch_dtype, device=w.device)
+        out = torch.empty(numel, dtype=cd.pack_dtype, device=w.device)
     if lin:
         if k_pad != (cin if fwd else cout) or mode in (PACK_C3, PACK_C3T):
             raise L.FsrError("the stage-contiguous filter pack has no padding")
@@ -270,7 +351,7 @@ def wgrad_stream_begin(device):
 def _wgrad_defer(cd, xin, dz, cout, cin, cfg, arena):
     """Queue a weight gradient for the grouped launch; False if this layer is not of the groupable class."""
     st = _wgrad_state
-    if not st["group"] or cfg.stride != 1 or cfg.pixel_shuffle:
+    if not st["group"] or cfg.stride != 1 or cfg.pixel_shuffle or cd.x3:
         return False
     if not (cout == cin == 64 and xin.shape[3] == 64 and dz.shape[3] == 64):
         return False
@@ -361,6 +442,8 @@ def conv3x3_raw(cd, x, wpk, cout, *, mode=L.CONV_FWD, out_hw=None, stride=1, bia
     dact_add: `dact_mask` is ADDED to the result (the gradient of a skip connection) instead of gating it.
     dact_bits: `dact_mask` is the packed sign-bit tensor (N,OH,OW,Cout/8) uint8 of the producing layer's output (stride-2 data gradients)."""
     _check_dev(x)
+    if cd.x3:
+        x, dact_mask = _aligned(x), (_aligned(dact_mask) if dact_mask is not None else None)
     n = x.shape[0]
     if in_pixel_shuffled:
         ih, iw, cin = x.shape[1] // 2, x.shape[2] // 2, x.shape[3] * 4
@@ -372,8 +455,8 @@ def conv3x3_raw(cd, x, wpk, cout, *, mode=L.CONV_FWD, out_hw=None, stride=1, bia
         oh, ow = out_hw
     odt = torch.uint8 if out_u8 else (torch.float32 if out_f32 else cd.torch_dtype)
     oshape = (n, 2 * oh, 2 * ow, cout // 4) if pixel_shuffle else ((n, oh // 2, ow // 2, cout) if pool2 else (n, oh, ow, cout))
-    out = torch.empty(oshape, dtype=odt, device=x.device)
-    pre = torch.empty(oshape, dtype=odt, device=x.device) if want_preact else None
+    out = _empty(oshape, odt, x.device)
+    pre = _empty(oshape, odt, x.device) if want_preact else None
     stats = _assigned((n, cout, 2), x.device) if want_stats else None
     d = L.ConvDesc(cd.code, mode, n, ih, iw, cin, oh, ow, cout, stride, act, float(slope), int(pixel_shuffle),
                    int(in_pixel_shuffled), L.OUT_U8 if out_u8 else int(out_f32), int(pool2), 2 if dact_bits else int(bool(dact_add)), 0)
@@ -409,6 +492,8 @@ def conv3x3_raw(cd, x, wpk, cout, *, mode=L.CONV_FWD, out_hw=None, stride=1, bia
 
 def conv3x3_wgrad_raw(cd, x, dy, cout, cin, stride, dy_pixel_shuffled=False, out=None):
     """OIHW float weight gradient.  x (N,IH,IW,CinPad); dy (N,OH,OW,CoutPad) or its depth-to-space form."""
+    if cd.x3:
+        x, dy = _aligned(x), _aligned(dy)
     n, ih, iw, cin_pad = x.shape
     if dy_pixel_shuffled:
         oh, ow, cout_pad = dy.shape[1] // 2, dy.shape[2] // 2, dy.shape[3] * 4
@@ -440,7 +525,7 @@ def image_to_nhwc(cd, img, scale=(1.0, 1.0, 1.0), shift=(0.0, 0.0, 0.0)):
     n, c, h, w = img.shape
     if c != 3:
         raise ValueError("expected a 3-channel image batch, got %s" % (tuple(img.shape),))
-    out = torch.empty((n, h, w, cd.cpad), dtype=cd.torch_dtype, device=img.device)
+    out = _empty((n, h, w, cd.cpad), cd.torch_dtype, img.device)
     sn, sc, sh, sw = img.stride()
     L.check(L.lib().fsr_image_to_nhwc(cd.code, _p(img), sn, sc, sh, sw, n, h, w, scale[0], scale[1], scale[2], shift[0],
                                       shift[1], shift[2], _p(out), cd.cpad, _stream()), "fsr_image_to_nhwc")
@@ -497,11 +582,11 @@ class Conv3x3Fn(torch.autograd.Function):
         cd = cfg.cd
         cout, cin = weight.shape[0], weight.shape[1]
         if (cfg.image_in and cfg.stride == 1 and cout % 16 == 0 and not (cfg.pixel_shuffle or cfg.stats or cfg.tanh_head)
-                and USE_C3_KERNELS):
+                and USE_C3_KERNELS and not cd.x3):
             return Conv3x3Fn._forward_c3(ctx, x, weight, bias, prelu, cfg)
         ctx.c3 = False
         # sign bits of the input (hung on it by the first-layer kernel that produced it): the stride-2 data gradient's mask
-        ctx.in_signs = getattr(x, "_fsr_signs", None) if (cfg.input_act_bwd is not None and cfg.stride == 2 and cd.name != "f32") else None
+        ctx.in_signs = getattr(x, "_fsr_signs", None) if (cfg.input_act_bwd is not None and cfg.stride == 2 and cd.is16) else None
         if cfg.image_in:
             xin = image_to_nhwc(cd, x, cfg.in_scale, cfg.in_shift)
         else:
@@ -558,7 +643,7 @@ class Conv3x3Fn(torch.autograd.Function):
         out = torch.empty((n, h, w, cout), dtype=cd.torch_dtype, device=x.device)
         pre = torch.empty_like(out) if want_pre else None
         signs = (torch.empty((n, h, w, cout // 8), dtype=torch.uint8, device=x.device)
-                 if (cfg.emit_signs and USE_SIGN_BITS and training and cd.name != "f32" and cout % 64 == 0) else None)
+                 if (cfg.emit_signs and USE_SIGN_BITS and training and cd.is16 and cout % 64 == 0) else None)
         sn, sc, sh, sw = x.stride()
         prof = PROFILE_CONV
         if prof is not None:
@@ -592,7 +677,7 @@ class Conv3x3Fn(torch.autograd.Function):
         if g is None:       # (gradients are not materialised: only the statistics output -- or only a skip alias -- was used)
             dx = None
             for t in skips:
-                dx = t if dx is None else dx + t
+                dx = t if dx is None else add(ctx.cfg.cd, dx, t)
             return dx, None, None, None, None, None
         cfg, cd = ctx.cfg, ctx.cfg.cd
         xin, weight, prelu, saved = ctx.saved_tensors
@@ -602,19 +687,21 @@ class Conv3x3Fn(torch.autograd.Function):
         dbias = _zeros((cout,), xin.device) if ctx.has_bias else None
         dprelu = None
         act = L.ACT_TANH if cfg.tanh_head else cfg.act
-        if cfg.tanh_head and USE_C3_KERNELS and cout == 3 and cin_pad % 16 == 0 and cin == cin_pad:
+        if cfg.tanh_head and USE_C3_KERNELS and cout == 3 and cin_pad % 16 == 0 and cin == cin_pad and not cd.x3:
             return Conv3x3Fn._backward_head_c3(ctx, g)
         if cfg.tanh_head:
             # g: (N,3,H,W) float of any strides; saved: head output (N,H,W,3) float
             if g.dtype != torch.float32:
                 g = g.float()
             _, _, h, w = g.shape
-            dz = torch.empty((n, h, w, cd.cpad), dtype=cd.torch_dtype, device=xin.device)
+            dz = _empty((n, h, w, cd.cpad), cd.torch_dtype, xin.device)
             sn, sc, sh, sw = g.stride()
             L.check(lib.fsr_tanh_bwd_to_nhwc(cd.code, _p(g), sn, sc, sh, sw, _p(saved), n, h, w, _p(dz), cd.cpad, _p(dbias),
                                              _p(_workspace(lib.fsr_tanh_bwd_scratch(), xin.device)), st), "fsr_tanh_bwd_to_nhwc")
         else:
             g = g if g.is_contiguous() else g.contiguous()
+            if cd.x3:
+                g, saved = _aligned(g), _aligned(saved)
             # first-layer kernels with arena gradients: the weight-gradient launch also produces the bias gradient (a column
             # of ones in its padded K dimension), straight into the bias' arena slice
             bias_arena = getattr(getattr(ctx, "bias_param", None), "_fsr_grad", None) if ctx.c3 else None
@@ -630,7 +717,7 @@ class Conv3x3Fn(torch.autograd.Function):
             elif act != L.ACT_NONE or ctx.has_bias:
                 if act == L.ACT_PRELU:
                     dprelu = _zeros((1,), xin.device)
-                dz = torch.empty_like(g)
+                dz = _empty_like(g)
                 _, h, w, c = g.shape
                 scr = _workspace(lib.fsr_act_bwd_scratch(n, h, w, c, int(cfg.pixel_shuffle)), xin.device)
                 L.check(lib.fsr_act_bwd(cd.code, _p(g), _p(saved), act, float(cfg.slope), _p(prelu), _p(dz), _p(dbias),
@@ -660,7 +747,7 @@ class Conv3x3Fn(torch.autograd.Function):
                                        dact_slope=cfg.input_act_bwd or 0.0, dact_add=addend is not None,
                                        dact_bits=(bits is not None and addend is None))
                 for t in skips[1:]:
-                    dx += t
+                    dx = add(cd, dx, t)
         dw = None
         if ctx.needs_input_grad[1]:
             arena = getattr(weight, "_fsr_grad", None)  # optim.ArenaAdamW: accumulate in place, hand autograd nothing
@@ -758,9 +845,11 @@ class InstNormActFn(torch.autograd.Function):
     def forward(ctx, x, stats, res, prelu, cd, act, slope):
         _check_dev(x)
         n, h, w, c = x.shape
-        out = torch.empty_like(x)
         if res is not None and not res.is_contiguous():
             res = res.contiguous()
+        if cd.x3:
+            x, res = _aligned(x), _aligned(res)
+        out = _empty_like(x)
         L.check(L.lib().fsr_instnorm_act_fwd(cd.code, _p(x), _p(stats), _p(res), act, float(slope), _p(prelu), _p(out), n,
                                              h * w, c, _stream()), "fsr_instnorm_act_fwd")
         ctx.meta = (cd, act, slope, res is not None)
@@ -773,13 +862,15 @@ class InstNormActFn(torch.autograd.Function):
         x, stats, prelu = ctx.saved_tensors
         n, h, w, c = x.shape
         g = g if g.is_contiguous() else g.contiguous()
+        if cd.x3:
+            g = _aligned(g)
         lib, st = L.lib(), _stream()
         sums = _zeros((n, c, 2), x.device)
         dprelu = _zeros((1,), x.device) if act == L.ACT_PRELU else None
         scr = _workspace(lib.fsr_instnorm_act_bwd_scratch(n, h * w, c), x.device)
         L.check(lib.fsr_instnorm_act_bwd_reduce(cd.code, _p(g), _p(x), _p(stats), act, float(slope), _p(prelu), _p(sums),
                                                 _p(dprelu), _p(scr), n, h * w, c, st), "fsr_instnorm_act_bwd_reduce")
-        dx = torch.empty_like(x)
+        dx = _empty_like(x)
         L.check(lib.fsr_instnorm_act_bwd_apply(cd.code, _p(g), _p(x), _p(stats), _p(sums), act, float(slope), _p(prelu),
                                                _p(dx), n, h * w, c, st), "fsr_instnorm_act_bwd_apply")
         return dx, None, (g if has_res else None), dprelu, None, None, None
@@ -799,7 +890,9 @@ class MaxPool2Fn(torch.autograd.Function):
     def forward(ctx, x, cd, relu_mask=False, grad_on=True):
         _check_dev(x)
         n, h, w, c = x.shape
-        y = torch.empty((n, h // 2, w // 2, c), dtype=x.dtype, device=x.device)
+        if cd.x3:
+            x = _aligned(x)
+        y = _empty((n, h // 2, w // 2, c), x.dtype, x.device)
         idx = torch.empty((n, h // 2, w // 2, c), dtype=torch.uint8, device=x.device) if (grad_on and USE_POOL_ARGMAX) else None
         L.check(L.lib().fsr_maxpool2_fwd(cd.code, _p(x), _p(y), _p(idx), n, h, w, c, _stream()), "fsr_maxpool2_fwd")
         ctx.cd, ctx.relu_mask, ctx.xshape = cd, relu_mask, tuple(x.shape)
@@ -814,7 +907,9 @@ class MaxPool2Fn(torch.autograd.Function):
     def backward(ctx, g):
         n, h, w, c = ctx.xshape
         g = g if g.is_contiguous() else g.contiguous()
-        dx = torch.empty((n, h, w, c), dtype=g.dtype, device=g.device)
+        if ctx.cd.x3:
+            g = _aligned(g)
+        dx = _empty((n, h, w, c), g.dtype, g.device)
         if ctx.by_idx:
             (idx,) = ctx.saved_tensors
             L.check(L.lib().fsr_maxpool2_bwd_argmax(ctx.cd.code, _p(g), _p(idx), _p(dx), n, h, w, c, int(ctx.relu_mask), _stream()),
@@ -839,6 +934,8 @@ class Conv1x1ToLogitsFn(torch.autograd.Function):
         _check_dev(x)
         n, h, w, c = x.shape
         x = x if x.is_contiguous() else x.contiguous()
+        if cd.x3:
+            x = _aligned(x)
         wv = weight.detach().reshape(-1)
         logits = torch.empty((n, 1, h, w), dtype=torch.float32, device=x.device)
         L.check(L.lib().fsr_conv1x1_c1_fwd(cd.code, _p(x), _p(wv), _p(bias), _p(logits), n * h * w, c, _stream()),
@@ -852,7 +949,7 @@ class Conv1x1ToLogitsFn(torch.autograd.Function):
         x, weight = ctx.saved_tensors
         n, h, w, c = x.shape
         g = g.contiguous().float()
-        dx = torch.empty_like(x) if ctx.needs_input_grad[0] else None
+        dx = _empty_like(x) if ctx.needs_input_grad[0] else None
         dw = _zeros(tuple(weight.shape), x.device)
         db = _zeros((1,), x.device)
         scr = _workspace(L.lib().fsr_conv1x1_c1_bwd_scratch(c), x.device)
@@ -904,7 +1001,7 @@ class SmoothL1Fn(torch.autograd.Function):
     """torch.nn.SmoothL1Loss() (beta 1, mean) (trainer.py:43); the second argument is the target."""
 
     @staticmethod
-    def forward(ctx, a, b):
+    def forward(ctx, a, b, x3=False):
         _check_dev(a, b)
         if a.dtype != b.dtype or a.shape != b.shape:
             raise L.FsrError("SmoothL1: operands must share dtype and shape")
@@ -913,6 +1010,11 @@ class SmoothL1Fn(torch.autograd.Function):
         code = {torch.bfloat16: L.FSR_BF16, torch.float16: L.FSR_F16, torch.float32: L.FSR_F32}.get(a.dtype)
         if code is None:
             raise L.FsrError("SmoothL1: unsupported dtype %s" % a.dtype)
+        if x3:      # x3 containers are float32 tensors: the caller says what they hold
+            if a.dtype != torch.float32:
+                raise L.FsrError("SmoothL1: x3 operands live in float32 containers")
+            code = L.FSR_X3
+            a, b = _aligned(a), _aligned(b)
         loss = _zeros((1,), a.device).view(())
         scr = _workspace(L.lib().fsr_loss_scratch(), a.device)
         L.check(L.lib().fsr_smooth_l1_fwd(code, _p(a), _p(b), _p(loss), _p(scr), a.numel(), _stream()), "fsr_smooth_l1_fwd")
@@ -924,17 +1026,18 @@ class SmoothL1Fn(torch.autograd.Function):
     def backward(ctx, g):
         a, b = ctx.saved_tensors
         g = g.contiguous().float()
-        da = torch.empty_like(a)
+        da = _empty_like(a) if ctx.code == L.FSR_X3 else torch.empty_like(a)
         L.check(L.lib().fsr_smooth_l1_bwd(ctx.code, _p(a), _p(b), _p(g), _p(da), a.numel(), _stream()), "fsr_smooth_l1_bwd")
-        return da, None
+        return da, None, None
 
 
 def bce_with_logits(x, t):
     return BCEWithLogitsFn.apply(x, t)
 
 
-def smooth_l1(a, b):
-    return SmoothL1Fn.apply(a, b)
+def smooth_l1(a, b, cd=None):
+    """cd: the compute mode of activation operands (needed for x3, whose containers are float32 tensors); images: None."""
+    return SmoothL1Fn.apply(a, b, bool(cd is not None and cd.x3))
 
 
 # ---------------------------------------------------------------------------------- validation metrics

@@ -173,7 +173,7 @@ class Trainer:
         sr_images = G(lr_images)                                                # :173 / :185 (shared)
         # content branch of the generator step (:190, :192): queued behind G(lr) only -- the side stream starts it as soon
         # as sr_images exists, beside the discriminator's forward and backward
-        content_loss = on_side(lambda: self.l1_loss(V.features_nhwc(sr_images), real_features))
+        content_loss = on_side(lambda: self.l1_loss(V.features_nhwc(sr_images), real_features, cd=V.compute))
         # :172 and :174 use the same discriminator weights and every op is per-sample, so real and fake images go
         # through D as ONE batch of 2B: half the launches, one weight-gradient pass instead of two
         y_both = Dm(torch.cat([hr_images, sr_images.detach()], dim=0))

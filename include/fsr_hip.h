@@ -15,7 +15,15 @@
  *     packed filters: FSR_F32 (exact-f32 MFMA, parity mode), FSR_BF16 (bf16 MFMA, f32 accumulate) or
  *     FSR_F16 (fp16 MFMA, f32 accumulate: BASELINE configs[4]); parameters, biases, statistics,
  *     parameter gradients and losses are float;
- *   - channel counts of NHWC activations are multiples of FSR_CPAD(dtype) = 16 (f32) / 32 (bf16, f16);
+ *   - FSR_X3 ("split bf16", the fast mode INSIDE the reference's fp32 tolerance): an element is 4 bytes, the pair
+ *     hi = bf16(v), lo = bf16(v - hi), and every product of a convolution is three bf16 MFMAs into one f32 accumulator,
+ *     x_hi*w_hi + x_lo*w_hi + x_hi*w_lo (the dropped x_lo*w_lo term is <= 2^-16 of the product).  Storage: an NHWC tensor of
+ *     C channels (C %% 32 == 0) holds, per pixel and per group of 32 channels, 64 bytes of hi[32] followed by 64 bytes of
+ *     lo[32] -- the same bytes as float32 (the torch container IS a float32 tensor of the logical shape), and to the MFMA
+ *     kernels a bf16 tensor of 2C channels whose 32-channel chunks alternate hi / lo.  Tensor bases are 128-byte aligned.
+ *     Packed filters are bf16 [9][rows][2K] with the same hi / lo chunk order along K.  Everything that is float in the
+ *     other modes (parameters, statistics, gradients of parameters, losses, 3-channel images) is float here too;
+ *   - channel counts of NHWC activations are multiples of FSR_CPAD(dtype) = 16 (f32) / 32 (bf16, f16, x3);
  *     3-channel images are stored zero-padded to that width;
  *   - reductions over pixels (InstanceNorm statistics, backward sums, bias / PReLU-slope gradients, loss
  *     means) are two-level and ORDER-FIXED: the producing kernel stores one partial vector per workgroup into
@@ -38,9 +46,9 @@
 extern "C" {
 #endif
 
-#define FSR_ABI_VERSION 9
+#define FSR_ABI_VERSION 10
 
-enum { FSR_F32 = 0, FSR_BF16 = 1, FSR_F16 = 2 };
+enum { FSR_F32 = 0, FSR_BF16 = 1, FSR_F16 = 2, FSR_X3 = 3 };
 enum { FSR_ACT_NONE = 0, FSR_ACT_RELU = 1, FSR_ACT_LEAKY = 2, FSR_ACT_PRELU = 3, FSR_ACT_TANH = 4 };
 enum { FSR_CONV_FWD = 0, FSR_CONV_DGRAD = 1 };
 enum { FSR_PACK_FWD = 0, FSR_PACK_FWD_PS = 1, FSR_PACK_DGRAD = 2, FSR_PACK_DGRAD_PS = 3 };
@@ -194,6 +202,11 @@ size_t fsr_act_bwd_scratch(int n, int h, int w, int c, int pixel_shuffled);
 int fsr_act_bwd(int dtype, const void* g, const void* saved, int act, float slope, const float* prelu_weight,
                 void* dz, float* dbias, float* dprelu, void* scratch, int n, int h, int w, int c, int pixel_shuffled,
                 fsr_stream_t stream);
+
+/* out = a + b over `count` elements of `dtype` tensors of one layout (out may alias a): the gradient accumulation of an activation
+ * with two consumers (the generator's long skip, model.py:115) -- in the x3 mode torch's own add cannot do it (the container's
+ * float32 arithmetic is not the arithmetic of the pairs it holds). */
+int fsr_add(int dtype, const void* a, const void* b, void* out, long long count, fsr_stream_t stream);
 
 /* ------------------------------------------------------------------ 3-channel images <-> padded NHWC
  * img: float, element strides (sn, sc, sh, sw) -- any of NCHW (dataloader.py:36-38 tensors) or
