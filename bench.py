@@ -52,7 +52,8 @@ import torch
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-MFMA_PEAK_TFLOPS = {"bf16": 2500.0, "f16": 2500.0, "f32": 157.3}   # /opt/skills/guides/MI355X_MICROARCH.md, dense
+MFMA_PEAK_TFLOPS = {"bf16": 2500.0, "f16": 2500.0, "f32": 157.3,   # /opt/skills/guides/MI355X_MICROARCH.md, dense
+                    "x3": 2500.0 / 3}   # x3: three bf16 MFMAs per algorithmic MAC (hi*hi + lo*hi + hi*lo): the bf16 peak over 3
 HBM_PEAK_GBS = 8000.0    # same guide: HBM3E ~8 TB/s
 NOMINAL_SCLK_MHZ = 2400.0   # the boost clock MI355X's dense peaks are quoted at
 LDS_FED_CEILING_TFLOPS = {"bf16": 1740.0, "f16": 1740.0}   # measured: profiles/r03_ubench_lds_mfma32.txt (32x32x16, 4+2 reads per 8 MFMAs, 8 waves per CU)
@@ -345,7 +346,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--batch", type=int, default=None, help="per-GPU batch (default: 32 for cfg3, 4 for cfg5)")
     ap.add_argument("--workload", default="cfg3", choices=sorted(WORKLOADS), help="cfg3 = the headline metric; cfg5 = BASELINE configs[4]")
-    ap.add_argument("--dtype", default=None, choices=["bf16", "f16", "f32"], help="default: the workload's (cfg3 bf16, cfg5 f16)")
+    ap.add_argument("--dtype", default=None, choices=["bf16", "f16", "f32", "x3"], help="default: the workload's (cfg3 bf16, cfg5 f16)")
     ap.add_argument("--no-cfg5", action="store_true", help="skip the BASELINE configs[4] leg of the default N = 1 line")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-inference", action="store_true")

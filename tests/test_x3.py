@@ -1,0 +1,218 @@
+"""The x3 compute mode (FSR_X3: split-bf16 storage, three bf16 MFMAs per product, f32 accumulate) -- the fast mode that is held
+to the FP32 gates: every kernel against the plain PyTorch fp32 op it replaces, the modules and one training iteration against
+the fp32 oracle, all through the C ABI on both backends (tests/backend.py).  Tolerances are the f32 mode's 1e-3 on outputs and
+losses (north_star) and a few 1e-5 at operator level (bf16 pairs carry 16 mantissa bits, the dropped lo x lo term is 2^-16)."""
+import importlib
+import types
+import warnings
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+from backend import BACKENDS, L, check_grads, ops, relerr, report, select
+from oracle import srgan_cpu as O
+
+OP_TOL = 5e-5       # operator level, max-norm relative (measured 4e-6 .. 8e-6)
+
+
+def ns(**k):
+    return types.SimpleNamespace(**k)
+
+
+@pytest.fixture(params=BACKENDS)
+def dev(request):
+    return select(request.param)
+
+
+@pytest.fixture()
+def cd():
+    return ops.Compute("x3")
+
+
+def _nhwc(x, cd, dev):
+    return ops.to_storage(cd, x.permute(0, 2, 3, 1).contiguous()).to(dev)
+
+
+def _nchw(y, cd):
+    return ops.from_storage(cd, y.cpu()).permute(0, 3, 1, 2)
+
+
+def leaf(t):
+    return t.detach().clone().requires_grad_(True)
+
+
+def test_x3_storage_layout_and_roundtrip(cd):
+    """Per pixel and 32-channel group: 64 bytes of bf16(v), then 64 bytes of bf16(v - hi); decode(encode(v)) is v to 2^-16."""
+    torch.manual_seed(0)
+    v = torch.randn(2, 3, 5, 64) * torch.logspace(-6, 3, 64)
+    t = ops.x3_encode(v)
+    assert t.dtype == torch.float32 and t.shape == v.shape and t.data_ptr() % 128 == 0
+    raw = t.view(torch.bfloat16).view(2, 3, 5, 2, 2, 32)          # [group][hi | lo][32]
+    hi = v.to(torch.bfloat16)
+    assert torch.equal(raw[..., 0, :].reshape(v.shape), hi)
+    assert torch.equal(raw[..., 1, :].reshape(v.shape), (v - hi.float()).to(torch.bfloat16))
+    back = ops.x3_decode(t)
+    assert float(((back - v).abs() / v.abs()).max()) < 2.0 ** -16
+    with pytest.raises(ValueError):
+        ops.x3_encode(torch.zeros(1, 1, 1, 48))
+
+
+@pytest.mark.parametrize("stride,cin,cout,ps", [(1, 32, 64, False), (1, 64, 64, False), (2, 64, 64, False), (1, 32, 128, True), (1, 64, 3, False),
+                                                (1, 64, 128, False), (1, 64, 256, True), (2, 64, 128, False), (1, 128, 128, False), (2, 128, 128, False)])
+def test_x3_conv_fwd_dgrad_wgrad(dev, cd, stride, cin, cout, ps):
+    torch.manual_seed(1)
+    big = dev.type == "cuda"
+    n, h, w = (3, 37, 45) if big else (1, 7, 19)
+    x = torch.randn(n, cin, h, w)
+    wt = torch.randn(cout, cin, 3, 3) * 0.1
+    bias = torch.randn(cout) * 0.1
+    xd = _nhwc(x, cd, dev)
+    wpk = ops.packed_filter(cd, wt.to(dev), L.PACK_FWD_PS if ps else L.PACK_FWD, cin)
+    y, _, stats = ops.conv3x3_raw(cd, xd, wpk, cout, stride=stride, bias=bias.to(dev), pixel_shuffle=ps, want_stats=(not ps and cout % 16 == 0),
+                                  out_f32=(cout == 3))
+    ref = F.conv2d(x, wt, bias, stride, 1)
+    refo = F.pixel_shuffle(ref, 2) if ps else ref
+    yo = y.float().cpu().permute(0, 3, 1, 2) if cout == 3 else _nchw(y, cd)
+    assert report("x3.conv.fwd", relerr(yo, refo)) < OP_TOL
+    if stats is not None:
+        s = stats.cpu()
+        assert relerr(s[..., 0], ref.sum((2, 3))) < 1e-4
+        assert relerr(s[..., 1], (ref * ref).sum((2, 3))) < 1e-4
+    g = torch.randn_like(refo)
+    xr, wr = leaf(x), leaf(wt)
+    yr = F.conv2d(xr, wr, None, stride, 1)
+    yr = F.pixel_shuffle(yr, 2) if ps else yr
+    yr.backward(g)
+    cpad_out = cd.pad(cout)
+    gd = torch.zeros(n, g.shape[2], g.shape[3], (cpad_out // 4) if ps else cpad_out)
+    gd[..., :g.shape[1]] = g.permute(0, 2, 3, 1)
+    gd = ops.to_storage(cd, gd).to(dev)
+    wpk_d = ops.packed_filter(cd, wt.to(dev), L.PACK_DGRAD_PS if ps else L.PACK_DGRAD, cpad_out)
+    dx, _, _ = ops.conv3x3_raw(cd, gd, wpk_d, cin, mode=L.CONV_DGRAD, out_hw=(h, w), stride=stride, in_pixel_shuffled=ps)
+    assert report("x3.conv.dgrad", relerr(_nchw(dx, cd), xr.grad)) < OP_TOL
+    dw = ops.conv3x3_wgrad_raw(cd, xd, gd, cout, cin, stride, dy_pixel_shuffled=ps)
+    assert report("x3.conv.wgrad", relerr(dw, wr.grad)) < OP_TOL
+
+
+def test_x3_conv_epilogues_autograd(dev, cd):
+    """Conv3x3Fn with the fused epilogues in x3 storage: bias + PReLU + PixelShuffle (pre-activation copy, act_bwd with its
+    bias / slope reductions), LeakyReLU applied by the consumer's data-gradient mask, the residual skip added in the
+    data-gradient epilogue, InstanceNorm forward / backward -- against torch autograd on the same values."""
+    torch.manual_seed(2)
+    n, c, h, w = (2, 64, 18, 22) if dev.type == "cuda" else (1, 32, 6, 9)
+    x = torch.randn(n, c, h, w)
+    w1, b1, a1 = torch.randn(4 * c, c, 3, 3) * 0.05, torch.randn(4 * c) * 0.1, torch.tensor([0.25])
+    w2 = torch.randn(c, c, 3, 3) * 0.05
+    xd = leaf(_nhwc(x, cd, dev))
+    p = [leaf(t.to(dev)) for t in (w1, b1, a1, w2)]
+    up, _ = ops.conv3x3(xd, p[0], p[1], p[2], ops.ConvCfg(cd, act=L.ACT_PRELU, pixel_shuffle=True))
+    u, st, skip = ops.conv3x3(up, p[3], None, None, ops.ConvCfg(cd, stats=True, n_alias=1))
+    y = ops.instnorm_act(u, st, skip, None, cd, L.ACT_LEAKY, 0.2)
+    r = torch.randn(n, c, 2 * h, 2 * w)
+    # the seed gradient is an x3 tensor too
+    y.backward(_nhwc(r, cd, dev))
+    xr = leaf(x)
+    q = [leaf(t) for t in (w1, b1, a1, w2)]
+    upr = F.prelu(F.pixel_shuffle(F.conv2d(xr, q[0], q[1], 1, 1), 2), q[2])
+    ur = F.conv2d(upr, q[3], None, 1, 1)
+    yr = F.leaky_relu(F.instance_norm(ur), 0.2) + upr
+    yr.backward(r)
+    assert report("x3.epi.y", relerr(_nchw(y.detach(), cd), yr)) < 1e-4
+    assert report("x3.epi.dx", relerr(_nchw(xd.grad, cd), xr.grad)) < 2e-4
+    for name, a, b in zip(("w1", "b1", "a1", "w2"), p, q):
+        # (the PReLU slope gradient is ONE cancelling sum over the layer: its error is relative to the sum of magnitudes)
+        assert report("x3.epi.d" + name, relerr(a.grad, b.grad)) < (2e-3 if name == "a1" else 2e-4), name
+
+
+def test_x3_pool_conv1x1_smoothl1_add(dev, cd):
+    torch.manual_seed(3)
+    n, c, h, w = (2, 64, 12, 20) if dev.type == "cuda" else (1, 32, 4, 6)
+    x, t = torch.randn(n, c, h, w), torch.randn(n, c, h // 2, w // 2)
+    w1, b1 = torch.randn(1, c, 1, 1) * 0.1, torch.randn(1)
+    # (an x3 tensor must have ONE consumer in autograd -- torch would accumulate two gradient containers with float adds;
+    # the modules route their skip connections through Conv3x3Fn's aliases for exactly that reason -- so: two graphs)
+    for relu_mask in (False, True):
+        for head in ("l1", "c1"):
+            xd = leaf(_nhwc(x, cd, dev))
+            wd, bd = leaf(w1.to(dev)), leaf(b1.to(dev))
+            pooled = ops.maxpool2(xd, cd, relu_mask=relu_mask)
+            xr, wr, br = leaf(x), leaf(w1), leaf(b1)
+            pr = F.max_pool2d(xr, 2)
+            if head == "l1":
+                loss, lref = ops.smooth_l1(pooled, _nhwc(t, cd, dev), cd=cd), F.smooth_l1_loss(pr, t)
+            else:
+                loss, lref = ops.conv1x1_to_logits(pooled, wd, bd, cd).sum(), F.conv2d(pr, wr, br).sum()
+            loss.backward()
+            lref.backward()
+            # relu_mask: the pool's backward also applies the backward of the ReLU that produced x (dx = 0 where x <= 0)
+            gref = xr.grad * (x > 0) if relu_mask else xr.grad
+            assert report("x3.pool.loss", abs(float(loss.detach()) - float(lref.detach())) / abs(float(lref.detach()))) < 1e-5
+            assert report("x3.pool.dx", relerr(_nchw(xd.grad, cd), gref)) < OP_TOL
+            if head == "c1":
+                assert relerr(wd.grad, wr.grad) < OP_TOL and relerr(bd.grad, br.grad) < OP_TOL
+    a, b = torch.randn(n, c, h, w), torch.randn(n, c, h, w) * 1e-3
+    s = ops.add(cd, _nhwc(a, cd, dev), _nhwc(b, cd, dev))
+    assert relerr(_nchw(s, cd), a + b) < 1e-5
+
+
+def test_x3_generator_discriminator_vs_oracle(dev):
+    """G (32 filters, 1 block) -> D, forward and every gradient against the fp32 oracle at the F32 mode's gates."""
+    pkg = importlib.import_module("fast-srgan_amd")
+    torch.manual_seed(5)
+    big = dev.type == "cuda"
+    nf = 64 if big else 32
+    G = pkg.Generator(ns(n_filters=nf, n_layers=2 if big else 1), compute_dtype="x3")
+    D = pkg.Discriminator(ns(n_filters=nf, n_layers=7), compute_dtype="x3")
+    gsd = {k: v.clone() for k, v in G.state_dict().items()}
+    dsd = {k: v.clone() for k, v in D.state_dict().items()}
+    G.to(dev), D.to(dev)
+    x = torch.rand(2, 3, 24, 40) * 2 - 1 if big else torch.rand(1, 3, 8, 12) * 2 - 1
+    sr = G(x.to(dev))
+    assert sr.dtype == torch.float32
+    logits = D(sr)
+    r = torch.randn(logits.shape)
+    (logits * r.to(dev)).sum().backward()
+    gp = {k: v.clone().requires_grad_(True) for k, v in gsd.items()}
+    dp = {k: v.clone().requires_grad_(True) for k, v in dsd.items()}
+    sr_ref = O.generator_forward(gp, x)
+    lg_ref = O.discriminator_forward(dp, sr_ref)
+    grads = torch.autograd.grad((lg_ref * r).sum(), list(gp.values()) + list(dp.values()))
+    ref = dict(zip(["g." + k for k in gp] + ["d." + k for k in dp], grads))
+    assert report("modules.x3.sr.%s" % dev.type, relerr(sr, sr_ref)) < 1e-3
+    assert report("modules.x3.logits.%s" % dev.type, relerr(logits, lg_ref)) < 1e-3
+    named = [("g." + k, p.grad) for k, p in G.named_parameters()] + [("d." + k, p.grad) for k, p in D.named_parameters()]
+    bad = check_grads("modules.x3.grad.%s" % dev.type, named, ref, t_tensor=1e-2, t_slope=1e-2, t_cos=0.9999)
+    assert not bad, bad
+
+
+def test_x3_train_step_vs_oracle(dev):
+    """One whole iteration (trainer.py:171-196) in x3 mode against the fp32 oracle: four losses to 1e-3 (measured ~1e-5),
+    one AdamW update of both networks in the mean."""
+    pkg = importlib.import_module("fast-srgan_amd")
+    torch.manual_seed(9)
+    big = dev.type == "cuda"
+    nf, wd, nl = (64, 2, 2) if big else (32, 2, 1)
+    cfg = ns(experiment=ns(name="t", seed=1234), generator=ns(n_filters=nf, n_layers=nl), discriminator=ns(n_filters=nf, n_layers=7),
+             training=ns(compiled=False, device=str(dev), log_iter=1, checkpoint_iter=10 ** 9, generator_lr=1e-4, discriminator_lr=1e-4,
+                         batch_size=2, compute_dtype="x3"))
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        V = pkg.VGG19(compute_dtype="x3", width_div=wd, seed=1234)
+        T = pkg.Trainer(cfg, perceptual_network=V)
+    g_sd = {k: v.detach().cpu().clone() for k, v in T.generator.state_dict().items()}
+    d_sd = {k: v.detach().cpu().clone() for k, v in T.discriminator.state_dict().items()}
+    g0, d0 = {k: v.clone() for k, v in g_sd.items()}, {k: v.clone() for k, v in d_sd.items()}
+    v_sd = O.vgg_standin_state_dict(1234, wd)
+    b, s = (2, 16) if big else (1, 8)
+    lr, hr = torch.rand(b, 3, s, s) * 2 - 1, torch.rand(b, 3, 4 * s, 4 * s) * 2 - 1
+    noise = [torch.rand(b, 1, s // 4, s // 4) for _ in range(3)]
+    got = T.train_step(lr.to(dev), hr.to(dev), [t.to(dev) for t in noise])
+    want = O.train_step(g_sd, d_sd, v_sd, lr, hr, noise, {}, {})
+    for k in want:
+        e = report("step.x3.%s.%s" % (dev.type, k), abs(float(got[k]) - float(want[k])) / abs(float(want[k])))
+        assert e <= 1e-3, (k, float(got[k]), float(want[k]))
+    for sd_ref, sd0, mod in ((g_sd, g0, T.generator), (d_sd, d0, T.discriminator)):
+        for k, p in mod.state_dict().items():
+            upd = (sd_ref[k] - sd0[k]).abs().mean()
+            assert (p.cpu() - sd_ref[k]).abs().mean() <= 0.1 * upd + 1e-12, k
