@@ -110,6 +110,15 @@ def test_generator_shipped_weights_kat_gpu(pkg):
     with torch.no_grad():
         y1 = G(x[1:2].to(dev)).cpu()
     assert relerr(y1, y[1:2]) < 1e-5
+    # the x3 mode (split bf16, three MFMAs per product) reproduces the SAME known answer at the same 1e-3
+    G3 = pkg.Generator(ns(n_filters=64, n_layers=8), compute_dtype="x3")
+    G3.load_state_dict(sd)
+    G3.to(dev).eval()
+    with torch.no_grad():
+        y3 = G3(x.to(dev)).cpu()
+    assert abs(y3.double().sum().item() - float(z["y_sum"])) < 1e-3 * abs(float(z["y_sum"]))
+    assert report("kat.x3.strided", relerr(y3[:, :, ::16, ::16], torch.from_numpy(z["y_strided"]))) < 1e-3
+    assert report("kat.x3.vs_f32_mode", relerr(y3, y)) < 1e-3
     # bf16 mode on the same weights stays close to fp32 (reported, loose gate: 18 stacked convs + IN)
     Gb = pkg.Generator(ns(n_filters=64, n_layers=8), compute_dtype="bf16")
     Gb.load_state_dict(sd)
@@ -122,7 +131,7 @@ def test_generator_shipped_weights_kat_gpu(pkg):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("cdn", ["f32", "bf16"])
+@pytest.mark.parametrize("cdn", ["f32", "x3", "bf16"])
 def test_full_size_modules_vs_oracle_gpu(pkg, cdn):
     """Full-width G and D (64 filters) at a moderate size against the CPU oracle: forward and gradients.
     f32 mode: the plain fp32 oracle.  bf16 mode: the oracle with the bf16 mode's storage roundings (O.Q_BF16) -- and, for
@@ -150,11 +159,11 @@ def test_full_size_modules_vs_oracle_gpu(pkg, cdn):
         grads = torch.autograd.grad((lg_ref * r).sum(), list(gp.values()) + list(dp.values()))
         return sr_ref, lg_ref, dict(zip(["g." + k for k in gp] + ["d." + k for k in dp], grads))
 
-    if cdn == "f32":
+    if cdn in ("f32", "x3"):        # the x3 mode (split bf16, three MFMAs per product) is held to the f32 mode's gates
         sr_ref, lg_ref, ref = oracle(None)
-        assert report("modules.f32.sr", relerr(sr, sr_ref)) < 1e-3
-        assert report("modules.f32.logits", relerr(logits, lg_ref)) < 1e-3
-        bad = check_grads("modules.f32.grad", named, ref, t_tensor=1e-2, t_slope=1e-2, t_cos=0.9999)
+        assert report("modules.%s.sr" % cdn, relerr(sr, sr_ref)) < 1e-3
+        assert report("modules.%s.logits" % cdn, relerr(logits, lg_ref)) < 1e-3
+        bad = check_grads("modules.%s.grad" % cdn, named, ref, t_tensor=1e-2, t_slope=1e-2, t_cos=0.9999)
         assert not bad, bad
         return
     sr_ref, lg_ref, ref = oracle(O.Q_BF16)

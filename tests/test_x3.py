@@ -153,7 +153,7 @@ def test_x3_pool_conv1x1_smoothl1_add(dev, cd):
                 assert relerr(wd.grad, wr.grad) < OP_TOL and relerr(bd.grad, br.grad) < OP_TOL
     a, b = torch.randn(n, c, h, w), torch.randn(n, c, h, w) * 1e-3
     s = ops.add(cd, _nhwc(a, cd, dev), _nhwc(b, cd, dev))
-    assert relerr(_nchw(s, cd), a + b) < 1e-5
+    assert relerr(_nchw(s, cd), a + b) < 3e-5
 
 
 def test_x3_generator_discriminator_vs_oracle(dev):
