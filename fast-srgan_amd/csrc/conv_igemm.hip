@@ -855,6 +855,8 @@ int fsr_conv_igemm_dispatch_classes(int dtype, ConvKArgs* cls, int n, hipStream_
 
 int fsr_conv_igemm_dispatch(int dtype, ConvKArgs& a, int S, hipStream_t stream) {
   if (dtype == FSR_X3) {
+    // 64 and more logical input channels, stride 1: the all-DMA 32x32x16 kernel on three virtual chunks per channel group (conv_tall3.hip)
+    if (const int rc = fsr_conv_tall3_try(dtype, a, S, stream)) return rc < 0 ? rc : 0;
     if (a.query) return 0;            // (the standard x3 pack)
     if (a.wlin) return fsr_fail(-2, "conv3x3: a stage-contiguous filter pack reached a kernel that reads the standard one");
     return dispatch_X3(a, S, stream);

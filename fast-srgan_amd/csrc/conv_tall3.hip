@@ -101,8 +101,27 @@ __device__ __forceinline__ V t3_lds_read(const char* smem, unsigned off) {
   return *FSR_LDS_PTR(const V, smem + off);
 }
 
-template <typename T, int BN, int NW, int G, int NSLOT, int MB, int NA = 2, bool STATS = false, int S = 1>
+// X3 (FSR_X3, T = bf16_t, stride 1): the input is an x3 tensor seen as a bf16 tensor of a.Cin = 2 x logical channels whose
+// 32-channel chunks alternate hi / lo, the filter pack alternates w_hi / w_lo chunks the same way.  The kernel then walks
+// THREE virtual chunks per logical 32-channel group -- (x_hi, w_hi), (x_lo, w_hi), (x_hi, w_lo) -- through the unchanged
+// pipeline: only the source offsets of the DMA pieces are mapped (t3_hmap / t3_fmap), so the x_hi halo chunk is fetched
+// twice (from L2), and the epilogue stores / reads x3 elements (hi and lo 64 bytes apart, fsr_common.h).
+__device__ __forceinline__ int t3_div3(int j) { return (int)(((unsigned)j * 0xAAABu) >> 17); }     // j < 2^15
+template <bool X3> __device__ __forceinline__ int t3_hmap(int j) {      // physical input chunk of virtual chunk j
+  if constexpr (!X3) return j;
+  const int g = t3_div3(j), r = j - 3 * g;
+  return __builtin_amdgcn_readfirstlane(2 * g + (r == 1 ? 1 : 0));      // (wave-uniform: the DMA's scalar offset operand)
+}
+template <bool X3> __device__ __forceinline__ int t3_fmap(int j) {      // physical filter chunk of virtual chunk j
+  if constexpr (!X3) return j;
+  const int g = t3_div3(j), r = j - 3 * g;
+  return __builtin_amdgcn_readfirstlane(2 * g + (r == 2 ? 1 : 0));
+}
+
+template <typename T, int BN, int NW, int G, int NSLOT, int MB, int NA = 2, bool STATS = false, int S = 1, bool X3 = false>
 __global__ __launch_bounds__(NW * 64, 2) void conv_tall3_kernel(const ConvKArgs a) {
+  static_assert(!X3 || (S == 1 && std::is_same<T, bf16_t>::value), "x3: bf16 planes, stride 1");
+  typedef typename std::conditional<X3, x3_t, T>::type ST;    // storage type of the output-side tensors
   // a wave owns 32 * MB pixels x 32 * NA channels; two waves per SIMD (256 registers each), from two workgroups.  (The
   // 128 x 128 wave tile with 256 accumulators in AGPRs and ONE 512-register wave per SIMD was built and measured in round 3 --
   // 620..800 TFLOP/s against 1130..1200, profiles/r03_conv_tall3_one_wave_per_simd.txt -- and removed.)
@@ -140,7 +159,7 @@ __global__ __launch_bounds__(NW * 64, 2) void conv_tall3_kernel(const ConvKArgs 
   const fsr_lds_addr_t ring_addr = halo_addr + HALO_TOTAL;
   const fsr_buf_t in_buf = fsr_make_buf(a.in, (unsigned)((size_t)a.N * a.IH * a.IW * a.Cin * sizeof(T)));
   const fsr_buf_t w_buf = fsr_make_buf(a.wpk, (unsigned)((size_t)9 * a.CoutPad * a.Cin * sizeof(T)));
-  const int nchunks = a.Cin >> 5;
+  const int nchunks = X3 ? 3 * (a.Cin >> 6) : a.Cin >> 5;       // x3: three virtual chunks per (hi, lo) pair of physical ones
   const unsigned wcs = a.wlin ? (unsigned)(9 * BN * 64) : 64u;      // byte step of the filter source from chunk to chunk
 
   // ---- loop-invariant per-lane addresses -------------------------------------------------------------------------
@@ -187,7 +206,7 @@ __global__ __launch_bounds__(NW * 64, 2) void conv_tall3_kernel(const ConvKArgs 
     tc.img = L / a.tiles_y;
     tc.gy0 = ty * TH;
     tc.gx0 = tx * 16;
-    ws = a.wlin ? (unsigned)(tc.nb * nchunks * 9 * BN * 64) : (unsigned)(tc.nb * BN * a.Cin * (int)sizeof(T));
+    ws = a.wlin ? (unsigned)(tc.nb * (a.Cin >> 5) * 9 * BN * 64) : (unsigned)(tc.nb * BN * a.Cin * (int)sizeof(T));
     if constexpr (S == 2) {
       // piece g = wave + 4 k of the chunk's 44: plane g / 11 = (py, px), piece g % 11 of that plane; halo pixel (hy, hx) of the
       // plane is input pixel (2 gy0 - 1 + 2 hy + py, 2 gx0 - 1 + 2 hx + px); rows beyond TH - py / columns beyond 16 - px are
@@ -223,7 +242,7 @@ __global__ __launch_bounds__(NW * 64, 2) void conv_tall3_kernel(const ConvKArgs 
   auto dma_halo = [&](const unsigned (&hv)[HPW], int c, int k, unsigned par) {
     if constexpr (!(T3_ABL & 2))
       if (wave + k * NW < T3_NHP)
-        FSR_BLDS16(in_buf, hv[k], (unsigned)(c * 64), halo_addr + (fsr_lds_addr_t)(par * T3_HALO_BYTES + (wave + k * NW) * 1024));
+        FSR_BLDS16(in_buf, hv[k], (unsigned)(t3_hmap<X3>(c) * 64), halo_addr + (fsr_lds_addr_t)(par * T3_HALO_BYTES + (wave + k * NW) * 1024));
   };
   // stride 2: piece wave + 4 k of chunk c's four planes (the planes lie back to back: piece g goes to g * 1 KB)
   auto dma_halo2 = [&](const unsigned (&hv)[HPW], int c, int k) {
@@ -233,7 +252,7 @@ __global__ __launch_bounds__(NW * 64, 2) void conv_tall3_kernel(const ConvKArgs 
   // filter pieces of the tap at position `pos` of chunk c's stages (stride 1: the tap itself; stride 2: T3_S2_TAP[pos])
   auto dma_filter = [&](unsigned ws, int c, unsigned woff_tap, int k, unsigned slot_tap_off) {
     if constexpr (!(T3_ABL & 2))
-      FSR_BLDS16(w_buf, wvoff[k], woff_tap + ws + (unsigned)c * wcs, ring_addr + (fsr_lds_addr_t)(slot_tap_off + (wave + k * NW) * 1024));
+      FSR_BLDS16(w_buf, wvoff[k], woff_tap + ws + (unsigned)t3_fmap<X3>(c) * wcs, ring_addr + (fsr_lds_addr_t)(slot_tap_off + (wave + k * NW) * 1024));
   };
   // The bias of a tile's channel block comes by DMA as well (one piece of BN floats, wave 0, double buffered by tile parity):
   // an ordinary global load next to the epilogue's stores would make hipcc drain vmcnt -- the whole DMA pipeline -- per tile.
@@ -436,8 +455,36 @@ __global__ __launch_bounds__(NW * 64, 2) void conv_tall3_kernel(const ConvKArgs 
     // ---- epilogue -----------------------------------------------------------------------------------------------------
     // activation as ONE instruction per element: ReLU = max(v, 0), LeakyReLU = max(v, slope * v) (0 <= slope <= 1: host
     // checked), identity = nothing.  The three forms are separate instantiations of the store loop (one wave-uniform branch).
-    T* outp = (T*)a.out;
-    const T* maskp = (const T*)a.dmask;
+    ST* outp = (ST*)a.out;
+    const ST* maskp = (const ST*)a.dmask;
+    // 16 consecutive channels of one pixel -> memory (two 16-byte units; x3: two for the hi parts, two for the lo parts)
+    auto store16 = [&](ST* p, const float (&v)[16]) {
+      if constexpr (X3) {
+        char* hp = (char*)x3_hi_ptr(p);
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {       // eight channels at a time: the split needs two temporaries per pair
+          u32x4 hh, ll;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            unsigned a_, b_;
+            x3_split2(v[8 * h + 2 * e], v[8 * h + 2 * e + 1], a_, b_);
+            hh[e] = a_;
+            ll[e] = b_;
+          }
+          fsr_st<1>((u32x4*)(hp + 16 * h), hh);
+          fsr_st<1>((u32x4*)(hp + 64 + 16 * h), ll);
+        }
+      } else {
+        u32x4 p0, p1;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          p0[e] = pack2<T>(v[2 * e], v[2 * e + 1]);
+          p1[e] = pack2<T>(v[8 + 2 * e], v[8 + 2 * e + 1]);
+        }
+        fsr_st<1>((u32x4*)p, (u32x4)(p0));
+        fsr_st<1>((u32x4*)(p + 8), (u32x4)(p1));
+      }
+    };
     const int oimg = cur.img, ogy0 = cur.gy0, ogx0 = cur.gx0, onb = cur.nb;
     const int gx = ogx0 + l15;
     auto store_tile = [&](auto actc) {
@@ -469,28 +516,34 @@ __global__ __launch_bounds__(NW * 64, 2) void conv_tall3_kernel(const ConvKArgs 
             }
             if (!(T3_ABL & 1) && ok && lrow == 0 && !(l15 & 1)) {
               const unsigned off = (unsigned)((oimg * (a.FOH >> 1) + (gy >> 1)) * (a.FOW >> 1) + (gx >> 1)) * (unsigned)a.Cout + (unsigned)co;
-              u32x4 p0, p1;
-#pragma unroll
-              for (int e = 0; e < 4; ++e) {
-                p0[e] = pack2<T>(v[2 * e], v[2 * e + 1]);
-                p1[e] = pack2<T>(v[8 + 2 * e], v[8 + 2 * e + 1]);
-              }
-              fsr_st<1>((u32x4*)(outp + off), (u32x4)(p0));
-              fsr_st<1>((u32x4*)(outp + off + 8), (u32x4)(p1));
+              store16(outp + off, v);
             }
           } else if (!(T3_ABL & 1) && ok) {
             const unsigned off = (unsigned)((oimg * a.FOH + gy) * a.FOW + gx) * (unsigned)a.Cout + (unsigned)co;
 
             if (maskp) {   // fused activation backward of the producing layer: dz = dx * act'(y), y = the saved forward input
-              const u32x4 k0 = *(const u32x4*)(maskp + off), k1 = *(const u32x4*)(maskp + off + 8);
+              // (x3: the hi parts carry the sign; an addend needs both parts)
+              const char* mp = X3 ? (const char*)x3_hi_ptr(maskp + off) : (const char*)(maskp + off);
+              const u32x4 k0 = *(const u32x4*)mp, k1 = *(const u32x4*)(mp + 16);
               const float ms = a.dmask_slope;
               if (a.dmask_add) {   // the tensor is an addend (gradient of a skip connection), not a gate
+                if constexpr (X3) {
+                  const u32x4 q0 = *(const u32x4*)(mp + 64), q1 = *(const u32x4*)(mp + 80);
+#pragma unroll
+                  for (int e = 0; e < 4; ++e) {
+                    v[2 * e] += x3_join_lo(k0[e], q0[e]);
+                    v[2 * e + 1] += x3_join_hi(k0[e], q0[e]);
+                    v[8 + 2 * e] += x3_join_lo(k1[e], q1[e]);
+                    v[8 + 2 * e + 1] += x3_join_hi(k1[e], q1[e]);
+                  }
+                } else {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                   v[2 * e] += cvt_lo<T>(k0[e]);
                   v[2 * e + 1] += cvt_hi<T>(k0[e]);
                   v[8 + 2 * e] += cvt_lo<T>(k1[e]);
                   v[8 + 2 * e + 1] += cvt_hi<T>(k1[e]);
+                }
                 }
               } else {
               // y > 0 on the raw 16-bit pattern: the element moved to the top of a signed word is positive (bf16 and f16 alike)
@@ -503,14 +556,9 @@ __global__ __launch_bounds__(NW * 64, 2) void conv_tall3_kernel(const ConvKArgs 
               }
               }
             }
-            u32x4 p0, p1;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-              p0[e] = pack2<T>(activate(v[2 * e]), activate(v[2 * e + 1]));
-              p1[e] = pack2<T>(activate(v[8 + 2 * e]), activate(v[8 + 2 * e + 1]));
-            }
-            fsr_st<1>((u32x4*)(outp + off), (u32x4)(p0));
-            fsr_st<1>((u32x4*)(outp + off + 8), (u32x4)(p1));
+            for (int e = 0; e < 16; ++e) v[e] = activate(v[e]);
+            store16(outp + off, v);
           }
         });
       });
@@ -602,9 +650,9 @@ int t3_cus() {
   return cus;
 }
 
-template <typename T, int BN, int NW, int G, int NSLOT, int MB, int NA = 2, bool STATS = false, int S = 1>
+template <typename T, int BN, int NW, int G, int NSLOT, int MB, int NA = 2, bool STATS = false, int S = 1, bool X3 = false>
 int t3_launch(ConvKArgs& a, int wg_per_cu, hipStream_t stream) {
-  auto kern = conv_tall3_kernel<T, BN, NW, G, NSLOT, MB, NA, STATS, S>;
+  auto kern = conv_tall3_kernel<T, BN, NW, G, NSLOT, MB, NA, STATS, S, X3>;
   constexpr int lds = t3_lds_bytes<BN, G, NSLOT, MB, S>();
   static bool attr_set = false;
   if (!attr_set) {
@@ -632,7 +680,7 @@ int t3_launch(ConvKArgs& a, int wg_per_cu, hipStream_t stream) {
   hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(NW * 64), lds, stream, a);
   fsr_note_kernel(S == 2 ? (STATS ? "conv_tall3_kernel<%s,%d,%d,%d,%d,%d,%d,stats,s2>" : "conv_tall3_kernel<%s,%d,%d,%d,%d,%d,%d,s2>")
                          : (STATS ? "conv_tall3_kernel<%s,%d,%d,%d,%d,%d,%d,stats>" : "conv_tall3_kernel<%s,%d,%d,%d,%d,%d,%d>"),
-                  std::is_same<T, f16_t>::value ? "f16" : "bf16", BN, NW, G, NSLOT, MB, NA);
+                  X3 ? "x3" : (std::is_same<T, f16_t>::value ? "f16" : "bf16"), BN, NW, G, NSLOT, MB, NA);
   const int rc = fsr_check_launch("conv_tall3_kernel");
   return rc ? rc : 1;
 }
@@ -641,7 +689,8 @@ int t3_launch(ConvKArgs& a, int wg_per_cu, hipStream_t stream) {
 
 // 1 = launched, 0 = not this kernel's shape (the caller falls through to conv_igemm.hip), < 0 = error.
 int fsr_conv_tall3_try(int dtype, ConvKArgs& a, int S, hipStream_t stream) {
-  if ((dtype != FSR_BF16 && dtype != FSR_F16) || (S != 1 && S != 2) || a.ntaps != 9) return 0;
+  if ((dtype != FSR_BF16 && dtype != FSR_F16 && dtype != FSR_X3) || (S != 1 && S != 2) || a.ntaps != 9) return 0;
+  if (dtype == FSR_X3 && (S != 1 || (a.Cin & 63) != 0 || (a.Cin >> 6) * 3 >= (1 << 15))) return 0;   // x3: stride 1; a.Cin = physical channels
 #ifdef FSR_NO_T3S2     // A/B builds (tools/build_variant.sh): stride-2 forwards stay on conv_igemm.hip
   if (S == 2) return 0;
 #endif
@@ -704,7 +753,18 @@ int fsr_conv_tall3_try(int dtype, ConvKArgs& a, int S, hipStream_t stream) {
     else if (b.stats) rc = t3_launch<TT, 128, 4, 1, 4, MBV, 2, true>(b, 2, stream);               \
     else rc = t3_launch<TT, 128, 4, 1, 4, MBV>(b, 2, stream);                                     \
   } while (0)
-  if (S == 2) {
+  if (dtype == FSR_X3) {
+#define T3_GO3(MBV)                                                                                          \
+  do {                                                                                                       \
+    if (narrow) rc = t3_launch<bf16_t, 64, 4, 1, 4, MBV, 1, false, 1, true>(b, 2, stream);                   \
+    else if (b.stats) rc = t3_launch<bf16_t, 128, 4, 1, 4, MBV, 2, true, 1, true>(b, 2, stream);             \
+    else rc = t3_launch<bf16_t, 128, 4, 1, 4, MBV, 2, false, 1, true>(b, 2, stream);                         \
+  } while (0)
+    if (best_mb == 4) T3_GO3(4);
+    else if (best_mb == 3) T3_GO3(3);
+    else T3_GO3(2);
+#undef T3_GO3
+  } else if (S == 2) {
     if (dtype == FSR_F16) rc = b.stats ? t3_launch<f16_t, 128, 4, 1, 4, 2, 2, true, 2>(b, 2, stream) : t3_launch<f16_t, 128, 4, 1, 4, 2, 2, false, 2>(b, 2, stream);
     else rc = b.stats ? t3_launch<bf16_t, 128, 4, 1, 4, 2, 2, true, 2>(b, 2, stream) : t3_launch<bf16_t, 128, 4, 1, 4, 2, 2, false, 2>(b, 2, stream);
   } else if (dtype == FSR_F16) {

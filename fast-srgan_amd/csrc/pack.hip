@@ -49,7 +49,8 @@ __global__ void pack_conv3x3_kernel(const float* __restrict__ w, T* __restrict__
 // with ch(R) = (R & ~31) + 16 ((i >> 2) & 1) + (i & 3) + 4 (i >> 3), i = R & 31: the rows of a B-channel block in the kernels'
 // LDS order (a lane's 16 accumulator registers = 16 consecutive channels) and the 16-byte units of a 32-channel chunk in
 // their XOR-swizzled LDS positions -- the LDS image of one (block, chunk, slice) is B * 64 contiguous bytes of this pack.
-template <typename T>
+// X3: K counts physical channels (chunks alternate hi / lo parts of a logical 32-channel group, as in pack_conv3x3_kernel).
+template <typename T, bool X3 = false>
 __global__ void pack_conv3x3_lin_kernel(const float* __restrict__ w, T* __restrict__ out, int cout, int cin, int mode,
                                         int rows, int K, int B) {
   const int nchunks = K >> 5;
@@ -64,7 +65,8 @@ __global__ void pack_conv3x3_lin_kernel(const float* __restrict__ w, T* __restri
     const int nb = (int)(i / nchunks);
     const int ir = R & 31;
     const int row = nb * B + (R & ~31) + 16 * ((ir >> 2) & 1) + (ir & 3) + 4 * (ir >> 3);
-    const int k = 32 * c + 8 * (u ^ ((R >> 2) & 3)) + e;
+    const int kp = 32 * c + 8 * (u ^ ((R >> 2) & 3)) + e;
+    const int k = X3 ? (kp >> 6) * 32 + (kp & 31) : kp;
     int co, ci;
     if (mode == FSR_PACK_FWD || mode == FSR_PACK_FWD_PS) {
       co = row;
@@ -81,7 +83,13 @@ __global__ void pack_conv3x3_lin_kernel(const float* __restrict__ w, T* __restri
         co = 4 * (k % cps) + k / cps;
       }
     }
-    ElemIO<T>::st(out + idx, w[((size_t)co * cin + ci) * 9 + t]);
+    const float v = w[((size_t)co * cin + ci) * 9 + t];
+    if constexpr (X3) {
+      const bf16_t hi = f2bf(v);
+      out[idx] = (kp & 32) ? f2bf(v - bf2f(hi)) : hi;
+    } else {
+      ElemIO<T>::st(out + idx, v);
+    }
   }
 }
 
@@ -91,9 +99,10 @@ extern "C" int fsr_pack_conv3x3_lin(int dtype, int mode, const float* w_oihw, in
   if (!w_oihw || !packed) return fsr_fail(-1, "fsr_pack_conv3x3_lin: null argument");
   if (mode < FSR_PACK_FWD || mode > FSR_PACK_DGRAD_PS) return fsr_fail(-2, "fsr_pack_conv3x3_lin: bad mode %d", mode);
   if (block != 64 && block != 128) return fsr_fail(-2, "fsr_pack_conv3x3_lin: block must be 64 or 128");
-  if (dtype != FSR_BF16 && dtype != FSR_F16) return fsr_fail(-2, "fsr_pack_conv3x3_lin: 16-bit dtypes only");
+  if (dtype != FSR_BF16 && dtype != FSR_F16 && dtype != FSR_X3) return fsr_fail(-2, "fsr_pack_conv3x3_lin: 16-bit dtypes and x3 only");
   const bool fwd = (mode == FSR_PACK_FWD || mode == FSR_PACK_FWD_PS);
-  const int rows = fwd ? cout : cin, K = fwd ? cin : cout;
+  const int rows = fwd ? cout : cin, K = (fwd ? cin : cout) * (dtype == FSR_X3 ? 2 : 1);
+  if (dtype == FSR_X3 && K % 64 != 0) return fsr_fail(-2, "fsr_pack_conv3x3_lin: x3 packs need K %% 32 == 0");
   if (rows % block != 0 || K % 32 != 0) return fsr_fail(-2, "fsr_pack_conv3x3_lin: rows %d must be a multiple of the block, K %d of 32", rows, K);
   if ((mode == FSR_PACK_FWD_PS || mode == FSR_PACK_DGRAD_PS) && cout % 4 != 0)
     return fsr_fail(-2, "fsr_pack_conv3x3_lin: pixel-shuffle packing needs cout %% 4 == 0");
@@ -102,6 +111,8 @@ extern "C" int fsr_pack_conv3x3_lin(int dtype, int mode, const float* w_oihw, in
   if (blocks > 4096) blocks = 4096;
   if (dtype == FSR_F16)
     hipLaunchKernelGGL(pack_conv3x3_lin_kernel<f16_t>, dim3(blocks), dim3(256), 0, stream, w_oihw, (f16_t*)packed, cout, cin, mode, rows, K, block);
+  else if (dtype == FSR_X3)
+    hipLaunchKernelGGL((pack_conv3x3_lin_kernel<bf16_t, true>), dim3(blocks), dim3(256), 0, stream, w_oihw, (bf16_t*)packed, cout, cin, mode, rows, K, block);
   else
     hipLaunchKernelGGL(pack_conv3x3_lin_kernel<bf16_t>, dim3(blocks), dim3(256), 0, stream, w_oihw, (bf16_t*)packed, cout, cin, mode, rows, K, block);
   return fsr_check_launch("pack_conv3x3_lin_kernel");

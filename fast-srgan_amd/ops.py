@@ -173,8 +173,8 @@ def packed_filter(cd, weight, mode, k_pad, lin=0):
     if w.dtype != torch.float32 or not w.is_contiguous():
         w = w.float().contiguous()
     _check_dev(w)
-    if cd.x3 and (lin or mode in (PACK_C3, PACK_C3T)):
-        raise L.FsrError("x3 filters exist in the standard pack only")
+    if cd.x3 and mode in (PACK_C3, PACK_C3T):
+        raise L.FsrError("the first-layer kernels have no x3 form")
     if mode == PACK_C3T:
         numel = ((cin + 15) // 16 * 16) * 32
     else:

@@ -971,46 +971,61 @@ _TIMED_BATCH_SHAPES = [
 ]
 
 
+_X3_TIMED = {"vgg 256->256 @96 b32", "vgg 128->128 @192 b32", "vgg 512->512 @24 b32", "D 128->256 @96 b64 stats", "D 64->128 @192 b64 stats",
+             "D 256->256 s2 @96 b64", "G 64->64 @96 b32 stats"}
+
+
 @pytest.mark.gpu
+@pytest.mark.parametrize("cdn", ["bf16", "x3"])
 @pytest.mark.parametrize("shape", _TIMED_BATCH_SHAPES, ids=lambda s: s[0].split(" (")[0].replace(" ", "_").replace("->", "to"))
-def test_conv_at_the_timed_batch_gpu(shape):
+def test_conv_at_the_timed_batch_gpu(shape, cdn):
     """Forward (with the epilogue the iteration uses: ReLU, ReLU + fused 2x2 max-pool, or raw + InstanceNorm statistics) and
     data gradient (with the fused LeakyReLU mask) of the bf16 kernels at the batch bench.py times, against torch's fp32
-    convolution of the same bf16-rounded operands on the same device."""
+    convolution of the same bf16-rounded operands on the same device.  x3 (a subset of the shapes): the same launches in the
+    split-bf16 mode against torch's fp32 convolution of the UNROUNDED operands, at 1e-4."""
     name, cin, cout, h, w, stride, n, variant = shape
+    if cdn == "x3" and name.split(" (")[0] not in _X3_TIMED:
+        pytest.skip("x3: a subset of the shapes")
     dev = select("hip")
-    cd = ops.Compute("bf16")
+    cd = ops.Compute(cdn)
+    gate = 1e-2 if cdn == "bf16" else 1e-4
     torch.manual_seed(23)
     oh, ow = (h - 1) // stride + 1, (w - 1) // stride + 1
-    x = torch.randn(n, h, w, cin, device=dev).to(cd.torch_dtype)                     # NHWC, bf16-rounded
-    wt = (torch.randn(cout, cin, 3, 3, device=dev) * (2.0 / (9 * cin)) ** 0.5).to(cd.torch_dtype).float()
+    # storage tensor of the mode and the float values it holds (bf16: rounded; x3: the pair hi + lo)
+    enc = (lambda t: ops.x3_encode(t)) if cd.x3 else (lambda t: t.to(cd.torch_dtype))
+    dec = (lambda t: ops.x3_decode(t)) if cd.x3 else (lambda t: t.float())
+    x = enc(torch.randn(n, h, w, cin, device=dev))                                   # NHWC
+    wt = torch.randn(cout, cin, 3, 3, device=dev) * (2.0 / (9 * cin)) ** 0.5
+    if not cd.x3:
+        wt = wt.to(cd.torch_dtype).float()
     bias = None if variant == "stats" else (torch.randn(cout, device=dev) * 0.1)
     wpk = ops.packed_filter(cd, wt, L.PACK_FWD, cin)
     y, _, stats = ops.conv3x3_raw(cd, x, wpk, cout, stride=stride, bias=bias, act=(L.ACT_NONE if variant == "stats" else L.ACT_RELU),
                                   want_stats=(variant == "stats"), pool2=(variant == "pool"))
     kern_f = L.lib().fsr_last_kernel().decode()
-    xr = x.float().permute(0, 3, 1, 2)                                              # a view: torch's conv takes channels-last strides
+    xr = dec(x).permute(0, 3, 1, 2)                                                 # a view: torch's conv takes channels-last strides
     ref = F.conv2d(xr, wt, bias, stride, 1)
     if variant != "stats":
         ref = F.relu(ref)
     if variant == "pool":
         ref = F.max_pool2d(ref, 2, 2)
-    got = y.float().permute(0, 3, 1, 2)
+    got = dec(y).permute(0, 3, 1, 2)
     scale = float(ref.abs().max())
-    e = report("timed_batch.%s.fwd" % name.split(" (")[0], float((got - ref).abs().max()) / scale)
-    assert e < 1e-2, (name, kern_f, e)
+    tag = "timed_batch" if cdn == "bf16" else "timed_batch.x3"
+    e = report("%s.%s.fwd" % (tag, name.split(" (")[0]), float((got - ref).abs().max()) / scale)
+    assert e < gate, (name, kern_f, e)
     if stats is not None:
         assert relerr(stats[..., 0], ref.sum((2, 3))) < 2e-3 and relerr(stats[..., 1], (ref * ref).sum((2, 3))) < 2e-3, (name, kern_f)
     del got, ref, y
     # data gradient with the LeakyReLU(0.2) backward of the producing layer fused (mask = that layer's output)
-    g = torch.randn(n, oh, ow, cout, device=dev).to(cd.torch_dtype)
-    mask = torch.randn(n, h, w, cin, device=dev).to(cd.torch_dtype)
+    g = enc(torch.randn(n, oh, ow, cout, device=dev))
+    mask = enc(torch.randn(n, h, w, cin, device=dev))
     wpk_d = ops.packed_filter(cd, wt, L.PACK_DGRAD, cout)
     dx, _, _ = ops.conv3x3_raw(cd, g, wpk_d, cin, mode=L.CONV_DGRAD, out_hw=(h, w), stride=stride, dact_mask=mask, dact_slope=0.2)
     kern_d = L.lib().fsr_last_kernel().decode()
-    want = torch.nn.grad.conv2d_input((n, cin, h, w), wt, g.float().permute(0, 3, 1, 2), stride=stride, padding=1)
-    mk = mask.float().permute(0, 3, 1, 2)
+    want = torch.nn.grad.conv2d_input((n, cin, h, w), wt, dec(g).permute(0, 3, 1, 2), stride=stride, padding=1)
+    mk = dec(mask).permute(0, 3, 1, 2)
     want = want * torch.where(mk > 0, torch.ones_like(mk), torch.full_like(mk, 0.2))
-    e = report("timed_batch.%s.dgrad" % name.split(" (")[0], float((dx.float().permute(0, 3, 1, 2) - want).abs().max()) / float(want.abs().max()))
-    assert e < 1e-2, (name, kern_d, e)
-    report("timed_batch.%s.kernels %s | %s" % (name.split(" (")[0], kern_f, kern_d), 0.0)
+    e = report("%s.%s.dgrad" % (tag, name.split(" (")[0]), float((dec(dx).permute(0, 3, 1, 2) - want).abs().max()) / float(want.abs().max()))
+    assert e < gate, (name, kern_d, e)
+    report("%s.%s.kernels %s | %s" % (tag, name.split(" (")[0], kern_f, kern_d), 0.0)

@@ -38,8 +38,12 @@ F32_VGG_DX = 2e-2
 # layer: 0.14 .. 4.7 x either way, so they are held to F64_SMALL of their norm instead (slopes, as everywhere: unbounded, the
 # float32 oracle itself misses some by 60 .. 180 %).
 F64_NET, F64_TENSOR, F64_FLOOR, F64_SMALL = 1.5, 2.0, 2e-4, 0.05
-# the x3 mode against the same float64 reference (network ratio, tensor ratio, floor, small tensors): provisional until measured
-X3_F64 = (6.0, 8.0, 2e-3, 0.1)
+# The x3 mode (split bf16, three MFMAs per product) against the same float64 reference: (network ratio, tensor ratio, floor, small
+# tensors).  Measured on the MI355X (profiles/r05_parity_errors.log): losses 0 .. 4e-6 (gate 1e-3); D network 6.0e-3 against the
+# float32 oracle's own 2.1e-3 = 2.8x, G network 0.113 against 0.087 = 1.3x, filter tensors 1.3 .. 3.1x.  So x3 meets the f32
+# mode's gates on every loss and output, its G-network gradient gate (1.5x), NOT its D-network one (1.5x; x3 sits at 2.8x):
+# the bounds below are ~1.5x the measured ratios.
+X3_F64 = (4.5, 5.0, 2e-4, 0.05)
 VGGQ_OUT, VGGQ_DX, VGG_BF16_OUT, VGG_BF16_DX = 1.2e-2, 0.45, 2e-2, 0.7
 #    Measured at cfg #1 (bf16 kernels vs the bf16-storage oracle): the four losses 3e-5, 3e-5, 1.7e-4, 3e-6; gradient tensors
 #    0.15-0.5 relative L2 with norm ratios 0.94-1.01 and cosines 0.995 (D) / 0.90 (G): the forward pass is reproduced to 1e-3,

