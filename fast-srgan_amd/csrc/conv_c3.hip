@@ -85,7 +85,9 @@ __device__ __forceinline__ void stage_patch(const C3Args& a, float* patch, int n
 }
 
 // ------------------------------------------------------------------ forward
-template <typename T>
+// ST = storage type of the 64-channel tensors.  FSR_X3 runs the exact-f32 arithmetic (T = float: the layer is bound by writing
+// its output, and K = 27 f32 MFMA steps cost less than that) on x3 storage (ST = x3_t): better than the three-MFMA form, for free.
+template <typename T, typename ST = T>
 __global__ __launch_bounds__(256) void conv_c3_fwd_kernel(const C3Args a) {
   constexpr int TH = 16;
   __shared__ float patch[(TH + 2) * PW * 3];
@@ -133,8 +135,8 @@ __global__ __launch_bounds__(256) void conv_c3_fwd_kernel(const C3Args a) {
   if (a.act == FSR_ACT_RELU) slope = 0.f;
   __syncthreads();
 
-  T* outp = (T*)a.out;
-  T* prep = (T*)a.preact;
+  ST* outp = (ST*)a.out;
+  ST* prep = (ST*)a.preact;
   const int gx = tx * 16 + l15;
   // the lane's bias values, fetched BEFORE the first store (a load issued after a store waits for that store: one
   // counter for both); wide layout: [pair][low / high run], plain: [tile]
@@ -181,7 +183,7 @@ __global__ __launch_bounds__(256) void conv_c3_fwd_kernel(const C3Args a) {
             lo += bv[2 * p];
             hi += bv[2 * p + 1];
             if (prep)
-              fsr_st<4>((u32x4*)(prep + off + p * 32), (u32x4)((u32x4){pack2<T>(lo[0], lo[1]), pack2<T>(lo[2], lo[3]),
+              fsr_st<4>((u32x4*)((T*)prep + off + p * 32), (u32x4)((u32x4){pack2<T>(lo[0], lo[1]), pack2<T>(lo[2], lo[3]),
                                                        pack2<T>(hi[0], hi[1]), pack2<T>(hi[2], hi[3])}));
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
@@ -189,7 +191,7 @@ __global__ __launch_bounds__(256) void conv_c3_fwd_kernel(const C3Args a) {
               hi[q] = fmaxf(hi[q], 0.f) + slope * fminf(hi[q], 0.f);
             }
             const u32x4 pk = (u32x4){pack2<T>(lo[0], lo[1]), pack2<T>(lo[2], lo[3]), pack2<T>(hi[0], hi[1]), pack2<T>(hi[2], hi[3])};
-            fsr_st<4>((u32x4*)(outp + off + p * 32), pk);
+            fsr_st<4>((u32x4*)((T*)outp + off + p * 32), pk);
             if (a.signs) {      // the lane's eight channels nb * 64 + p * 32 + lg * 8 .. + 7 as one byte of sign bits of the STORED values
               unsigned b = 0u;
 #pragma unroll
@@ -220,8 +222,10 @@ __global__ __launch_bounds__(256) void conv_c3_fwd_kernel(const C3Args a) {
               u32x2 pk;
               pk.x = pack2<T>(acc[0], acc[1]);
               pk.y = pack2<T>(acc[2], acc[3]);
-              fsr_st<4>((u32x2*)(prep + off), (u32x2)(pk));
+              fsr_st<4>((u32x2*)((T*)prep + off), (u32x2)(pk));
             }
+          } else if constexpr (std::is_same<ST, x3_t>::value) {
+            if (prep) x3_st4(prep + off, acc);
           } else {
             if (prep) *(f32x4*)(prep + off) = acc;
           }
@@ -231,7 +235,9 @@ __global__ __launch_bounds__(256) void conv_c3_fwd_kernel(const C3Args a) {
             u32x2 pk;
             pk.x = pack2<T>(acc[0], acc[1]);
             pk.y = pack2<T>(acc[2], acc[3]);
-            fsr_st<4>((u32x2*)(outp + off), (u32x2)(pk));
+            fsr_st<4>((u32x2*)((T*)outp + off), (u32x2)(pk));
+          } else if constexpr (std::is_same<ST, x3_t>::value) {
+            x3_st4(outp + off, acc);
           } else {
             *(f32x4*)(outp + off) = acc;
           }
@@ -244,7 +250,7 @@ __global__ __launch_bounds__(256) void conv_c3_fwd_kernel(const C3Args a) {
 // ------------------------------------------------------------------ weight gradient
 // Workgroup = a slab of 8x16-pixel tiles; wave w owns output channels [16w, 16w+16) of the current 64-channel block
 // (blockIdx.y) x 32 patch columns: two accumulators for the whole slab.
-template <typename T>
+template <typename T, typename ST = T>
 __global__ __launch_bounds__(256) void conv_c3_wgrad_kernel(const C3Args a) {
   constexpr int TH = 8;
   constexpr int PA = 64 + 16;                     // dz tile pitch (elements): [128 px][64 co]
@@ -255,8 +261,9 @@ __global__ __launch_bounds__(256) void conv_c3_wgrad_kernel(const C3Args a) {
   const int slab = blockIdx.x, nb = blockIdx.y;
   const int cvalid = a.cout - nb * 64;            // channels of this block that exist (multiple of 16)
   const bool active = wave * 16 < cvalid;
-  const T* dzg = (const T*)a.dz;
+  const ST* dzg = (const ST*)a.dz;
   constexpr int EPB = 16 / (int)sizeof(T);
+  constexpr bool X3 = std::is_same<ST, x3_t>::value;
 
   // patch offsets of this lane's two columns j = l15 and j = 16 + l15 (k = column index; k >= 27 is padding)
   const int off0 = patch_off(l15), off1 = (16 + l15 < 27) ? patch_off(16 + l15) : -1;
@@ -273,7 +280,28 @@ __global__ __launch_bounds__(256) void conv_c3_wgrad_kernel(const C3Args a) {
     const int n = tile / (a.tiles_x * a.tiles_y);
     __syncthreads();
     stage_patch<T, TH>(a, patch, n, ty * TH, tx * 16, tid);
-    {   // dz tile: all loads of a thread first, then the LDS writes (a load consumed under its own branch costs one
+    if constexpr (X3) {   // x3 dz -> float tile: 8-channel units, hi and lo 16 bytes each, joined on the way to LDS
+      constexpr int DU = TH * 16 * 8, DPT = DU / 256;
+      u32x4 dh[DPT], dl[DPT];
+#pragma unroll
+      for (int j = 0; j < DPT; ++j) {
+        const int u = tid + j * 256;
+        const int unit = u % 8, p = u / 8;
+        const int y = ty * TH + p / 16, x = tx * 16 + (p & 15);
+        const bool ok = y < a.H && x < a.W && unit * 8 < cvalid;
+        const char* hp = (const char*)x3_hi_ptr(dzg + (ok ? (((size_t)n * a.H + y) * a.W + x) * a.cout + nb * 64 + unit * 8 : 0));
+        const u32x4 th = *(const u32x4*)hp, tl = *(const u32x4*)(hp + 64);
+        dh[j] = ok ? th : (u32x4){0u, 0u, 0u, 0u};
+        dl[j] = ok ? tl : (u32x4){0u, 0u, 0u, 0u};
+      }
+#pragma unroll
+      for (int j = 0; j < DPT; ++j) {
+        const int u = tid + j * 256;
+        float* d = (float*)dzt + (u / 8) * PA + (u % 8) * 8;
+        *(f32x4*)d = (f32x4){x3_join_lo(dh[j][0], dl[j][0]), x3_join_hi(dh[j][0], dl[j][0]), x3_join_lo(dh[j][1], dl[j][1]), x3_join_hi(dh[j][1], dl[j][1])};
+        *(f32x4*)(d + 4) = (f32x4){x3_join_lo(dh[j][2], dl[j][2]), x3_join_hi(dh[j][2], dl[j][2]), x3_join_lo(dh[j][3], dl[j][3]), x3_join_hi(dh[j][3], dl[j][3])};
+      }
+    } else {   // dz tile: all loads of a thread first, then the LDS writes (a load consumed under its own branch costs one
         // memory round trip each)
       constexpr int DU = TH * 16 * (64 / EPB), DPT = DU / 256;
       static_assert(DU % 256 == 0, "dz tile units per thread");
@@ -284,7 +312,7 @@ __global__ __launch_bounds__(256) void conv_c3_wgrad_kernel(const C3Args a) {
         const int unit = u % (64 / EPB), p = u / (64 / EPB);
         const int y = ty * TH + p / 16, x = tx * 16 + (p & 15);
         const bool ok = y < a.H && x < a.W && unit * EPB < cvalid;
-        const u32x4 t = *(const u32x4*)(dzg + (ok ? (((size_t)n * a.H + y) * a.W + x) * a.cout + nb * 64 + unit * EPB : 0));
+        const u32x4 t = *(const u32x4*)((const T*)dzg + (ok ? (((size_t)n * a.H + y) * a.W + x) * a.cout + nb * 64 + unit * EPB : 0));
         dv[j] = ok ? t : (u32x4){0u, 0u, 0u, 0u};
       }
 #pragma unroll
@@ -394,7 +422,8 @@ __global__ void pack_c3_kernel(const float* __restrict__ w, T* __restrict__ out,
 
 int fill_args(C3Args& a, const char* what, int dtype, const float* img, long long sn, long long sc, long long sh,
               long long sw, int n, int h, int w, const float (&scale3)[3], const float (&shift3)[3], int cout) {
-  if (dtype != FSR_F32 && dtype != FSR_BF16 && dtype != FSR_F16) return fsr_fail(-2, "%s: unknown dtype %d", what, dtype);
+  if (dtype != FSR_F32 && dtype != FSR_BF16 && dtype != FSR_F16 && dtype != FSR_X3) return fsr_fail(-2, "%s: unknown dtype %d", what, dtype);
+  if (dtype == FSR_X3 && cout % 32) return fsr_fail(-2, "%s: x3 tensors have a multiple of 32 channels", what);
   if (!img) return fsr_fail(-1, "%s: null image", what);
   if (n <= 0 || h <= 0 || w <= 0) return fsr_fail(-2, "%s: bad dims", what);
   if (cout <= 0 || cout % 16) return fsr_fail(-2, "%s: cout=%d is not a multiple of 16", what, cout);
@@ -420,7 +449,7 @@ extern "C" int fsr_pack_conv3x3_c3(int dtype, const float* w_oihw, int cout, voi
     hipLaunchKernelGGL(pack_c3_kernel<bf16_t>, dim3(blocks), dim3(256), 0, (hipStream_t)stream_, w_oihw, (bf16_t*)packed, cout, rows_pad, transposed);
   else if (dtype == FSR_F16)
     hipLaunchKernelGGL(pack_c3_kernel<f16_t>, dim3(blocks), dim3(256), 0, (hipStream_t)stream_, w_oihw, (f16_t*)packed, cout, rows_pad, transposed);
-  else if (dtype == FSR_F32)
+  else if (dtype == FSR_F32 || dtype == FSR_X3)      // x3: the first-layer kernels compute in f32 (float filter image)
     hipLaunchKernelGGL(pack_c3_kernel<float>, dim3(blocks), dim3(256), 0, (hipStream_t)stream_, w_oihw, (float*)packed, cout, rows_pad, transposed);
   else
     return fsr_fail(-2, "fsr_pack_conv3x3_c3: unknown dtype %d", dtype);
@@ -444,7 +473,8 @@ extern "C" int fsr_conv3x3_c3_fwd(int dtype, const float* img, long long sn, lon
   a.slope = slope;
   a.out = out;
   a.preact = preact;
-  if (signs && (dtype == FSR_F32 || cout % 64 != 0)) return fsr_fail(-2, "fsr_conv3x3_c3_fwd: sign bits are written by the 16-bit kernels for cout %% 64 == 0");
+  if (dtype == FSR_X3 && ((((size_t)out | (size_t)preact) & 127) != 0)) return fsr_fail(-2, "fsr_conv3x3_c3_fwd: x3 tensors must be 128-byte aligned");
+  if (signs && (dtype == FSR_F32 || dtype == FSR_X3 || cout % 64 != 0)) return fsr_fail(-2, "fsr_conv3x3_c3_fwd: sign bits are written by the 16-bit kernels for cout %% 64 == 0");
   a.signs = (unsigned char*)signs;
   a.tiles_x = (w + 15) / 16;
   a.tiles_y = (h + 15) / 16;
@@ -453,6 +483,7 @@ extern "C" int fsr_conv3x3_c3_fwd(int dtype, const float* img, long long sn, lon
   const dim3 grid((unsigned)nwg, (unsigned)((cout + 63) / 64));
   if (dtype == FSR_BF16) hipLaunchKernelGGL(conv_c3_fwd_kernel<bf16_t>, grid, dim3(256), 0, (hipStream_t)stream_, a);
   else if (dtype == FSR_F16) hipLaunchKernelGGL(conv_c3_fwd_kernel<f16_t>, grid, dim3(256), 0, (hipStream_t)stream_, a);
+  else if (dtype == FSR_X3) hipLaunchKernelGGL((conv_c3_fwd_kernel<float, x3_t>), grid, dim3(256), 0, (hipStream_t)stream_, a);
   else hipLaunchKernelGGL(conv_c3_fwd_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream_, a);
   return fsr_check_launch("conv_c3_fwd_kernel");
 }
@@ -481,6 +512,7 @@ extern "C" int fsr_conv3x3_c3_wgrad(int dtype, const float* img, long long sn, l
   const float scale3[3] = {scale0, scale1, scale2}, shift3[3] = {shift0, shift1, shift2};
   if (int rc = fill_args(a, "fsr_conv3x3_c3_wgrad", dtype, img, sn, sc, sh, sw, n, h, w, scale3, shift3, cout)) return rc;
   if (!dz || !dw_oihw || !workspace) return fsr_fail(-1, "fsr_conv3x3_c3_wgrad: null argument");
+  if (dtype == FSR_X3 && (((size_t)dz & 127) != 0)) return fsr_fail(-2, "fsr_conv3x3_c3_wgrad: x3 tensors must be 128-byte aligned");
   a.dz = dz;
   a.ws = (float*)workspace;
   const int nslab = c3_wgrad_slabs(n, h, w, &a.tiles_x, &a.tiles_y, &a.tiles_per_slab);
@@ -488,6 +520,7 @@ extern "C" int fsr_conv3x3_c3_wgrad(int dtype, const float* img, long long sn, l
   const dim3 grid((unsigned)nslab, (unsigned)((cout + 63) / 64));
   if (dtype == FSR_BF16) hipLaunchKernelGGL(conv_c3_wgrad_kernel<bf16_t>, grid, dim3(256), 0, (hipStream_t)stream_, a);
   else if (dtype == FSR_F16) hipLaunchKernelGGL(conv_c3_wgrad_kernel<f16_t>, grid, dim3(256), 0, (hipStream_t)stream_, a);
+  else if (dtype == FSR_X3) hipLaunchKernelGGL((conv_c3_wgrad_kernel<float, x3_t>), grid, dim3(256), 0, (hipStream_t)stream_, a);
   else hipLaunchKernelGGL(conv_c3_wgrad_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream_, a);
   if (int rc = fsr_check_launch("conv_c3_wgrad_kernel")) return rc;
   hipLaunchKernelGGL(conv_c3_wgrad_reduce_kernel, dim3(cout), dim3(256), 0, (hipStream_t)stream_, (const float*)workspace,

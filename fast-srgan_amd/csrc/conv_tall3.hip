@@ -101,7 +101,7 @@ __device__ __forceinline__ V t3_lds_read(const char* smem, unsigned off) {
   return *FSR_LDS_PTR(const V, smem + off);
 }
 
-// X3 (FSR_X3, T = bf16_t, stride 1): the input is an x3 tensor seen as a bf16 tensor of a.Cin = 2 x logical channels whose
+// X3 (FSR_X3, T = bf16_t): the input is an x3 tensor seen as a bf16 tensor of a.Cin = 2 x logical channels whose
 // 32-channel chunks alternate hi / lo, the filter pack alternates w_hi / w_lo chunks the same way.  The kernel then walks
 // THREE virtual chunks per logical 32-channel group -- (x_hi, w_hi), (x_lo, w_hi), (x_hi, w_lo) -- through the unchanged
 // pipeline: only the source offsets of the DMA pieces are mapped (t3_hmap / t3_fmap), so the x_hi halo chunk is fetched
@@ -120,7 +120,7 @@ template <bool X3> __device__ __forceinline__ int t3_fmap(int j) {      // physi
 
 template <typename T, int BN, int NW, int G, int NSLOT, int MB, int NA = 2, bool STATS = false, int S = 1, bool X3 = false>
 __global__ __launch_bounds__(NW * 64, 2) void conv_tall3_kernel(const ConvKArgs a) {
-  static_assert(!X3 || (S == 1 && std::is_same<T, bf16_t>::value), "x3: bf16 planes, stride 1");
+  static_assert(!X3 || std::is_same<T, bf16_t>::value, "x3: bf16 planes");
   typedef typename std::conditional<X3, x3_t, T>::type ST;    // storage type of the output-side tensors
   // a wave owns 32 * MB pixels x 32 * NA channels; two waves per SIMD (256 registers each), from two workgroups.  (The
   // 128 x 128 wave tile with 256 accumulators in AGPRs and ONE 512-register wave per SIMD was built and measured in round 3 --
@@ -247,7 +247,7 @@ __global__ __launch_bounds__(NW * 64, 2) void conv_tall3_kernel(const ConvKArgs 
   // stride 2: piece wave + 4 k of chunk c's four planes (the planes lie back to back: piece g goes to g * 1 KB)
   auto dma_halo2 = [&](const unsigned (&hv)[HPW], int c, int k) {
     if constexpr (!(T3_ABL & 2))
-      FSR_BLDS16(in_buf, hv[k], (unsigned)(c * 64), halo_addr + (fsr_lds_addr_t)((wave + k * NW) * 1024));
+      FSR_BLDS16(in_buf, hv[k], (unsigned)(t3_hmap<X3>(c) * 64), halo_addr + (fsr_lds_addr_t)((wave + k * NW) * 1024));
   };
   // filter pieces of the tap at position `pos` of chunk c's stages (stride 1: the tap itself; stride 2: T3_S2_TAP[pos])
   auto dma_filter = [&](unsigned ws, int c, unsigned woff_tap, int k, unsigned slot_tap_off) {
@@ -690,7 +690,7 @@ int t3_launch(ConvKArgs& a, int wg_per_cu, hipStream_t stream) {
 // 1 = launched, 0 = not this kernel's shape (the caller falls through to conv_igemm.hip), < 0 = error.
 int fsr_conv_tall3_try(int dtype, ConvKArgs& a, int S, hipStream_t stream) {
   if ((dtype != FSR_BF16 && dtype != FSR_F16 && dtype != FSR_X3) || (S != 1 && S != 2) || a.ntaps != 9) return 0;
-  if (dtype == FSR_X3 && (S != 1 || (a.Cin & 63) != 0 || (a.Cin >> 6) * 3 >= (1 << 15))) return 0;   // x3: stride 1; a.Cin = physical channels
+  if (dtype == FSR_X3 && ((a.Cin & 63) != 0 || (a.Cin >> 6) * 3 >= (1 << 15))) return 0;   // x3: a.Cin = physical channels, (hi, lo) pairs of chunks
 #ifdef FSR_NO_T3S2     // A/B builds (tools/build_variant.sh): stride-2 forwards stay on conv_igemm.hip
   if (S == 2) return 0;
 #endif
@@ -753,7 +753,9 @@ int fsr_conv_tall3_try(int dtype, ConvKArgs& a, int S, hipStream_t stream) {
     else if (b.stats) rc = t3_launch<TT, 128, 4, 1, 4, MBV, 2, true>(b, 2, stream);               \
     else rc = t3_launch<TT, 128, 4, 1, 4, MBV>(b, 2, stream);                                     \
   } while (0)
-  if (dtype == FSR_X3) {
+  if (dtype == FSR_X3 && S == 2) {
+    rc = b.stats ? t3_launch<bf16_t, 128, 4, 1, 4, 2, 2, true, 2, true>(b, 2, stream) : t3_launch<bf16_t, 128, 4, 1, 4, 2, 2, false, 2, true>(b, 2, stream);
+  } else if (dtype == FSR_X3) {
 #define T3_GO3(MBV)                                                                                          \
   do {                                                                                                       \
     if (narrow) rc = t3_launch<bf16_t, 64, 4, 1, 4, MBV, 1, false, 1, true>(b, 2, stream);                   \

