@@ -698,7 +698,8 @@ int fsr_conv_tall3_try(int dtype, ConvKArgs& a, int S, hipStream_t stream) {
   // Cout = 64 (the data gradient of a 64 -> 128 layer): 64-channel blocks, a wave = 32 MB pixels x 32 channels (one filter
   // fragment, 5 reads per 4 MFMAs)
   const bool narrow = a.Cout % 128 != 0;
-  if (narrow && (a.stats || a.pool2 || S == 2)) return 0;
+  // (statistics on the 64-channel block: x3 only -- the generator's 64 -> 64 forwards, which the 16-bit modes give to conv64_v2)
+  if (narrow && ((a.stats && dtype != FSR_X3) || a.pool2 || S == 2)) return 0;
   if (a.preact || a.oscale || a.ps || a.in_ps || a.out_f32) return 0;
   if (a.stats && (a.pool2 || a.dmask)) return 0;   // statistics: forward launches
   if (a.act != FSR_ACT_NONE && a.act != FSR_ACT_RELU && a.act != FSR_ACT_LEAKY) return 0;
@@ -758,7 +759,8 @@ int fsr_conv_tall3_try(int dtype, ConvKArgs& a, int S, hipStream_t stream) {
   } else if (dtype == FSR_X3) {
 #define T3_GO3(MBV)                                                                                          \
   do {                                                                                                       \
-    if (narrow) rc = t3_launch<bf16_t, 64, 4, 1, 4, MBV, 1, false, 1, true>(b, 2, stream);                   \
+    if (narrow && b.stats) rc = t3_launch<bf16_t, 64, 4, 1, 4, MBV, 1, true, 1, true>(b, 2, stream);         \
+    else if (narrow) rc = t3_launch<bf16_t, 64, 4, 1, 4, MBV, 1, false, 1, true>(b, 2, stream);              \
     else if (b.stats) rc = t3_launch<bf16_t, 128, 4, 1, 4, MBV, 2, true, 1, true>(b, 2, stream);             \
     else rc = t3_launch<bf16_t, 128, 4, 1, 4, MBV, 2, false, 1, true>(b, 2, stream);                         \
   } while (0)

@@ -51,6 +51,7 @@ struct WgradKArgs {
   int nbm, nbn;
   // grouped launch (group_n > 0): group_n layers of ONE shape share the launch; workgroup b serves layer b / nslab, slab
   // b % nslab of that layer (nbm = nbn = 1), operands gx[layer] / gdy[layer], partials at ws + layer * nslab * 9 * Cout * Cin
+  int x3;   // FSR_X3 on the physical bf16 views: channels come in (hi 32 | lo 32) groups; the lo x lo product blocks are not computed
   int group_n;
   const void* gx[WGRAD_GROUP_MAX];
   const void* gdy[WGRAD_GROUP_MAX];
@@ -118,7 +119,12 @@ __global__ __launch_bounds__((BM >= 64 && BN == 64) ? 512 : 256) void conv_wgrad
   constexpr bool COPAIR = (BM >= 64 && BN == 64);
   const bool active = wave * TPW < NPAIR;
   const int co_t = COPAIR ? (wave / NBT) * TPW : (wave * TPW) / NBT;
-  const int ci_t0 = COPAIR ? wave % NBT : (wave * TPW) % NBT;
+  // x3, 128 x 64 blocks: a wave's four co tiles are (hi, hi, lo, lo) of one channel group and ci tiles 0, 1 / 2, 3 the hi / lo part
+  // of the input group.  A wave on a lo ci tile skips its two lo co tiles (the dropped lo x lo block); the ci tiles are dealt so
+  // that the two waves of a SIMD (w, w + 4) are one hi and one lo wave: 6 instead of 8 MFMAs per stage and SIMD.
+  const bool x3blk = COPAIR && BM == 128 && a.x3 != 0;
+  const int ci_t0 = COPAIR ? (x3blk ? (wave + 2 * (wave / NBT)) % NBT : wave % NBT) : (wave * TPW) % NBT;
+  const bool skip_lo = x3blk && ci_t0 >= 2;
 
   f32x4 acc[9][TPW];
 #pragma unroll
@@ -342,22 +348,31 @@ __global__ __launch_bounds__((BM >= 64 && BN == 64) ? 512 : 256) void conv_wgrad
         const int ks = i / 9, t = i % 9;
         return frag(pb_base + ((ks * 2 * S + t / 3) * HW + t % 3) * PB, 4 * S * PB);
       };
-      s16x8 af[2][TPW], bf[3];
+      auto run_stages = [&](auto nwc) {      // nwc: co tiles this wave multiplies (TPW, or 2 for an x3 wave on a lo ci tile)
+        constexpr int NWC = decltype(nwc)::value;
+        s16x8 af[2][NWC], bf[3];
 #pragma unroll
-      for (int w = 0; w < TPW; ++w) af[0][w] = frag(pa_base + w * 16, 4 * PA);
-      bf[0] = xfrag(0);
-      bf[1] = xfrag(1);
+        for (int w = 0; w < NWC; ++w) af[0][w] = frag(pa_base + w * 16, 4 * PA);
+        bf[0] = xfrag(0);
+        bf[1] = xfrag(1);
 #pragma unroll
-      for (int i = 0; i < NSTAGE; ++i) {
-        const int ks = i / 9, t = i % 9;
-        if (i + 2 < NSTAGE) bf[(i + 2) % 3] = xfrag(i + 2);
-        if (t == 4 && ks + 1 < NS) {
+        for (int i = 0; i < NSTAGE; ++i) {
+          const int ks = i / 9, t = i % 9;
+          if (i + 2 < NSTAGE) bf[(i + 2) % 3] = xfrag(i + 2);
+          if (t == 4 && ks + 1 < NS) {
 #pragma unroll
-          for (int w = 0; w < TPW; ++w) af[(ks + 1) & 1][w] = frag(pa_base + (ks + 1) * 32 * PA + w * 16, 4 * PA);
+            for (int w = 0; w < NWC; ++w) af[(ks + 1) & 1][w] = frag(pa_base + (ks + 1) * 32 * PA + w * 16, 4 * PA);
+          }
+#pragma unroll
+          for (int w = 0; w < NWC; ++w) acc[t][w] = mfma16<T>(af[ks & 1][w], bf[i % 3], acc[t][w]);
+          __builtin_amdgcn_sched_barrier(0);
         }
-#pragma unroll
-        for (int w = 0; w < TPW; ++w) acc[t][w] = mfma16<T>(af[ks & 1][w], bf[i % 3], acc[t][w]);
-        __builtin_amdgcn_sched_barrier(0);
+      };
+      if constexpr (BM == 128) {
+        if (skip_lo) run_stages(std::integral_constant<int, 2>{});
+        else run_stages(std::integral_constant<int, TPW>{});
+      } else {
+        run_stages(std::integral_constant<int, TPW>{});
       }
     } else if constexpr (sizeof(T) == 2) {
       // K step = 32 pixels = tile rows 2s, 2s+1; lane group g owns pixels k = 8g..8g+7:
@@ -771,6 +786,7 @@ extern "C" int fsr_conv3x3_wgrad(const fsr_wgrad_desc* d_in, const void* x, cons
   a.nslab = p.nslab;
   a.nbm = p.nbm;
   a.nbn = p.nbn;
+  a.x3 = x3 ? 1 : 0;
   int rc = d->dtype == FSR_BF16 ? dispatch_wgrad<bf16_t, 8>(p, a, stream)
            : (d->dtype == FSR_F16 ? dispatch_wgrad<f16_t, 8>(p, a, stream) : dispatch_wgrad<float, 4>(p, a, stream));
   if (rc) return rc;
