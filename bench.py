@@ -351,6 +351,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-inference", action="store_true")
     ap.add_argument("--no-f32", action="store_true", help="skip the exact-f32 (reference precision) leg")
+    ap.add_argument("--no-x3", action="store_true", help="skip the x3 (split-bf16, reference tolerance) leg")
+    ap.add_argument("--inference-seconds", type=float, default=5.0, help="minimum timed region of every model-only inference leg")
+    ap.add_argument("--inference-dtypes", default="bf16,x3,f32", help="compute modes of the inference legs (the first one fills the top-level keys)")
     ap.add_argument("--no-sustained", action="store_true", help="skip the >= 5 s sustained legs that follow a short timed region")
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of hipGraph replays")
     args = ap.parse_args()
@@ -377,7 +380,7 @@ def main():
     if args.dtype is None:
         args.dtype = wl["dtype"]
     if args.workload != "cfg3":
-        args.no_inference = args.no_f32 = args.no_cpu_baseline = args.no_cfg5 = True     # those legs belong to the headline workload
+        args.no_inference = args.no_f32 = args.no_x3 = args.no_cpu_baseline = args.no_cfg5 = True     # those legs belong to the headline workload
     torch.manual_seed(1234)
     trainer = pkg.Trainer(make_config(args.batch, args.dtype, device, wl), perceptual_network=pkg.VGG19(compute_dtype=args.dtype, seed=1234))
     torch.manual_seed(100 + rank)
@@ -440,10 +443,11 @@ def main():
                       "collectives": ("rccl world %d" % torch.distributed.get_world_size()) if dist_mod.is_distributed() else "none",
                       "rccl_world_size": torch.distributed.get_world_size() if dist_mod.is_distributed() else 1,
                       "launch": launch,
-                      "precision": ("`value` is BASELINE configs[2]'s dtype (%s MFMA, f32 accumulate).  north_star's 1e-3 relative fp32 "
-                                    "tolerance is met by `f32_mode` (exact-f32 MFMA; tests/test_parity_bench.py), timed below with the "
-                                    "same steps / warm-up; the 16-bit mode is held to the operator-level and convergence gates of "
-                                    "tests/test_convergence.py" % args.dtype)},
+                      "precision": ("`value` is timed in the %s mode (BASELINE configs[1] names bf16).  north_star's 1e-3 relative fp32 "
+                                    "tolerance is met by `x3_mode` (split-bf16 operands, three bf16 MFMAs per product: the FAST mode "
+                                    "inside the tolerance) and by `f32_mode` (exact-f32 MFMA), both timed below with the same steps / "
+                                    "warm-up (tests/test_x3.py, tests/test_parity_bench.py); the plain 16-bit modes are held to the "
+                                    "operator-level and convergence gates of tests/test_convergence.py" % args.dtype)},
            "timed_region_s": round(elapsed, 3),
            "ms_per_step_ranks": {"min": round(min(per_rank) / args.steps * 1e3, 3), "max": round(max(per_rank) / args.steps * 1e3, 3)},
            "clock": clk.summary(),
@@ -465,28 +469,42 @@ def main():
         out["sustained"] = sustained
     if allreduce is not None:
         out["allreduce"] = allreduce
-    if rank == 0 and world == 1 and not args.no_f32 and args.dtype != "f32":
-        # the same iteration at the reference's own precision (exact-f32 MFMA: the mode inside north_star's 1e-3 tolerance),
-        # with the SAME --steps / --warmup and its own roofline against the f32 MFMA peak
-        del step_fn
+    def precision_leg(dt, described, meets):
+        """The same iteration in another compute mode, timed with the SAME --steps / --warmup, with its own roofline, clock and
+        (after a short timed region) sustained leg."""
         torch.manual_seed(1234)
-        t32 = pkg.Trainer(make_config(B, "f32", device, wl), perceptual_network=pkg.VGG19(compute_dtype="f32", seed=1234))
-        fn32, launch32 = build_step(pkg, t32, lr, hr, not args.no_graph)
-        with ClockSampler(local_rank) as clk32:
-            el = time_steps(fn32, lr, hr, args.steps, args.warmup, 1, device)
-        ms32 = el / args.steps * 1e3
-        roof32, gflop32 = measure_roofline(t32, ops, lr, hr, "f32", ms32, B)
-        roof32.pop("lds_fed_mfma_ceiling", None)
-        out["f32_mode"] = {"value": round(B * args.steps / el, 3), "unit": "images/s", "ms_per_step": round(ms32, 2), "steps": args.steps,
-                           "warmup": args.warmup, "timed_region_s": round(el, 3), "launch": launch32,
-                           "dtype": "f32 (v_mfma_f32_16x16x4_f32, exact fmaf chains)",
-                           "meets_north_star_tolerance": "1e-3 relative fp32 (tests/test_parity_bench.py, tests/test_trainer.py)",
-                           "step_tflops_executed": round(B * args.steps / el * gflop32 / 1e3, 2), "clock": clk32.summary(),
-                           "roofline": roof32}
+        t2 = pkg.Trainer(make_config(B, dt, device, wl), perceptual_network=pkg.VGG19(compute_dtype=dt, seed=1234))
+        fn2, launch2 = build_step(pkg, t2, lr, hr, not args.no_graph)
+        with ClockSampler(local_rank) as clk2:
+            el = time_steps(fn2, lr, hr, args.steps, args.warmup, 1, device)
+        ms2 = el / args.steps * 1e3
+        roof2, gflop2 = measure_roofline(t2, ops, lr, hr, dt, ms2, B)
+        roof2.pop("lds_fed_mfma_ceiling", None)
+        leg = {"value": round(B * args.steps / el, 3), "unit": "images/s", "ms_per_step": round(ms2, 2), "steps": args.steps,
+               "warmup": args.warmup, "timed_region_s": round(el, 3), "launch": launch2, "dtype": described,
+               "meets_north_star_tolerance": meets,
+               "step_tflops_executed": round(B * args.steps / el * gflop2 / 1e3, 2), "clock": clk2.summary(), "roofline": roof2}
         if sustained is not None and el < 5.0:
-            out["f32_mode"]["sustained"] = sustained_leg(fn32, ms32, B)
-        del t32, fn32
+            leg["sustained"] = sustained_leg(fn2, ms2, B)
+        del t2, fn2
         torch.cuda.empty_cache()
+        return leg
+
+    if rank == 0 and world == 1 and not args.no_x3 and args.dtype != "x3":
+        # the FAST mode inside north_star's 1e-3 tolerance: split-bf16 operands (hi = bf16(v), lo = bf16(v - hi)), three bf16 MFMAs
+        # per product into one f32 accumulator; its roofline peak is the bf16 MFMA peak over 3
+        out["x3_mode"] = precision_leg(
+            "x3", "x3 (split bf16: hi + lo 16-bit planes, x_hi*w_hi + x_lo*w_hi + x_hi*w_lo on v_mfma_f32_32x32x16_bf16, f32 accumulate)",
+            "1e-3 relative fp32 on every loss and output (measured 0 .. 7e-5: tests/test_x3.py, tests/test_parity_bench.py "
+            "[x3] cases, profiles/r05_parity_errors.log); gradients vs float64: G network 1.3x, D network 2.8x the float32 "
+            "oracle's own distance (the f32 mode: 1.05x / 1.1x)")
+        out["x3_mode"]["roofline"]["peak_note"] = "2500 / 3 TFLOP/s: three bf16 MFMAs per algorithmic multiply-add"
+    if rank == 0 and world == 1 and not args.no_f32 and args.dtype != "f32":
+        # the same iteration at the reference's own precision (exact-f32 MFMA), with the SAME --steps / --warmup and its own
+        # roofline against the f32 MFMA peak
+        del step_fn
+        out["f32_mode"] = precision_leg("f32", "f32 (v_mfma_f32_16x16x4_f32, exact fmaf chains)",
+                                        "1e-3 relative fp32 (tests/test_parity_bench.py, tests/test_trainer.py)")
 
     if rank == 0 and world == 1 and not args.no_cfg5:
         # BASELINE configs[4] as a measured configuration (round-3 verdict): 12 blocks, three pixel-shuffle stages, 128 -> 1024,
@@ -522,50 +540,119 @@ def main():
 
     if rank == 0 and not args.no_inference:
         import numpy as np
-        inf = {}
-        with torch.no_grad():
-            G = trainer.generator.eval()
+        gen_sd = {k: v.detach().clone() for k, v in trainer.generator.state_dict().items()}
+        modes = [m for m in args.inference_dtypes.split(",") if m]
+        if args.dtype not in modes:
+            modes = [args.dtype] + modes
+
+        def model_only(dt):
+            """Generator-only FPS in compute mode dt: every leg one hipGraph launch per call, >= --inference-seconds timed with the
+            shader clock sampled; plus the roofline of the forward's dominant kernel at 180x320, batch 32 (HIP events around
+            every convolution launch of one eager forward)."""
+            legs = {"dtype": dt}
+            Gm = trainer.generator.eval() if dt == args.dtype else pkg.Generator(ns(n_filters=64, n_layers=wl["n_layers"], n_upsample=wl["n_upsample"]),
+                                                                                  compute_dtype=dt).to(device).eval()
+            if dt != args.dtype:
+                Gm.load_state_dict(gen_sd)
+            launch_kind = "hipGraph replay"
             for name, (h, w) in (("90x160", (90, 160)), ("180x320", (180, 320))):
                 for bsz in (1, 32):
                     x = torch.rand(bsz, 3, h, w, device=device) * 2 - 1
-                    run = G
+                    run = Gm
                     try:   # one hipGraph launch per frame/batch (batch-1 eager inference is host-launch bound)
-                        run = pkg.GraphedGenerator(G, x)
+                        run = pkg.GraphedGenerator(Gm, x)
                     except Exception as exc:  # noqa: BLE001
                         print("bench: inference graph capture failed (%s); eager" % exc, file=sys.stderr)
+                        launch_kind = "eager"
                     for _ in range(3):
                         run(x)
                     torch.cuda.synchronize()
-                    iters = 100 if bsz == 1 else 8
                     t0 = time.perf_counter()
-                    for _ in range(iters):
+                    for _ in range(5):
                         run(x)
                     torch.cuda.synchronize()
-                    inf["fps_%s_b%d" % (name, bsz)] = round(bsz * iters / (time.perf_counter() - t0), 2)
-            inf["launch"] = "hipGraph replay" if run is not G else "eager"
+                    est = (time.perf_counter() - t0) / 5
+                    iters = max(10, int(args.inference_seconds / max(est, 1e-6)) + 1)
+                    with ClockSampler(local_rank) as c:
+                        t0 = time.perf_counter()
+                        for _ in range(iters):
+                            run(x)
+                        torch.cuda.synchronize()
+                        el = time.perf_counter() - t0
+                    key = "%s_b%d" % (name, bsz)
+                    legs["fps_" + key] = round(bsz * iters / el, 2)
+                    legs.setdefault("timed", {})[key] = {"calls": iters, "seconds": round(el, 2), "sclk_mhz_mean": c.summary().get("sclk_mhz_mean")}
+                    del run
+            legs["launch"] = launch_kind
+            x = torch.rand(32, 3, 180, 320, device=device) * 2 - 1
+            Gm(x)
+            rec = [r for r in conv_profile(ops, lambda: Gm(x)) if r[4] == "fwd"]
+            by = {}
+            for ms, fl, byts, kname, _ in rec:
+                e = by.setdefault(kname, [0, 0.0, 0.0, 0.0])
+                e[0] += 1; e[1] += ms; e[2] += fl; e[3] += byts
+            if by:
+                dom_name, dom = max(by.items(), key=lambda kv: kv[1][1])
+                peak = MFMA_PEAK_TFLOPS[dt]
+                tf = dom[2] / (dom[1] * 1e-3) / 1e12
+                conv_ms = sum(v[1] for v in by.values())
+                fps = legs["fps_180x320_b32"]
+                legs["roofline"] = {"bound": "mfma", "kernel": dom_name, "achieved": round(tf, 2), "peak": round(peak, 1), "unit": "TFLOP/s",
+                                    "frac": round(tf / peak, 4), "launches_per_forward": dom[0], "avg_launch_us": round(dom[1] * 1e3 / dom[0], 2),
+                                    "algorithmic_gflop_per_launch": round(dom[2] / dom[0] / 1e9, 3),
+                                    "algorithmic_bytes_per_launch": round(dom[3] / dom[0]), "hbm_frac": round(dom[3] / (dom[1] * 1e-3) / 1e9 / HBM_PEAK_GBS, 3),
+                                    "share_of_conv_time": round(dom[1] / conv_ms, 3),
+                                    "workload": "generator forward at 180x320, batch 32 (one eager forward, HIP events per convolution launch)",
+                                    "whole_forward": {"gflop_per_frame": round(sum(v[2] for v in by.values()) / 32 / 1e9, 2),
+                                                      "tflops_at_fps_180x320_b32": round(fps * sum(v[2] for v in by.values()) / 32 / 1e12, 1),
+                                                      "frac": round(fps * sum(v[2] for v in by.values()) / 32 / 1e12 / peak, 4)},
+                                    "kernels": [{"kernel": k, "launches": v[0], "ms": round(v[1], 3), "tflops": round(v[2] / (v[1] * 1e-3) / 1e12, 1),
+                                                 "mfma_frac": round(v[2] / (v[1] * 1e-3) / 1e12 / peak, 3), "hbm_frac": round(v[3] / (v[1] * 1e-3) / 1e9 / HBM_PEAK_GBS, 3)}
+                                                for k, v in sorted(by.items(), key=lambda kv: -kv[1][1])[:6]],
+                                    "rocprofv3_summary": "profiles/r05_inference_kernel_stats.csv (bf16) / profiles/r05_inference_kernel_stats_x3.csv"}
+            if dt != args.dtype:
+                del Gm
+            torch.cuda.empty_cache()
+            return legs
+
+        with torch.no_grad():
+            per_mode = {m: model_only(m) for m in modes}
+        inf = dict(per_mode[modes[0]])          # top level: the first mode (the dtype BASELINE configs[1] names)
+        inf["modes"] = {m: per_mode[m] for m in modes[1:]}
+        inf["modes_note"] = ("x3 = the fast mode inside north_star's 1e-3 (measured 6e-5 .. 7e-5 at these sizes, tests/test_parity_bench.py); "
+                             "f32 = exact-f32 MFMA; bf16 = BASELINE configs[1]'s dtype, mean |error| 2.9e-3 on (-1,1) images")
+        with torch.no_grad():
+            G = trainer.generator.eval()
             # end to end: uint8 frames in host memory -> H2D -> generator (uint8 head epilogue) -> D2H -> host arrays
             rng = np.random.default_rng(0)
+
+            def e2e_rate(pipe, frames, passes=5):
+                """frames per second of `passes` timed passes over `frames`, each pass timed on its own: median, min, max (the
+                single 4-pass figure of earlier rounds moved 3x between boxes -- host-side: the first pass after a pipeline is built
+                pays pinned-buffer page faults and graph instantiation, and a box's host threads are not always idle)."""
+                for _ in pipe.run(frames[:2 * pipe.batch]):
+                    pass
+                for _ in pipe.run(frames):          # one full untimed pass: every staging slot and plan is warm
+                    pass
+                rates = []
+                for _ in range(passes):
+                    t0, count = time.perf_counter(), 0
+                    for _y in pipe.run(frames):
+                        count += 1
+                    rates.append(count / (time.perf_counter() - t0))
+                rates.sort()
+                return round(rates[len(rates) // 2], 2), {"min": round(rates[0], 2), "max": round(rates[-1], 2), "passes": passes, "frames_per_pass": len(frames)}
+
+            inf["e2e_spread"] = {}
             for name, (h, w) in (("90x160", (90, 160)), ("180x320", (180, 320))):
                 for bsz in (1, 8):
-                    frames = [rng.integers(0, 256, size=(h, w, 3), dtype=np.uint8) for _ in range(16 if bsz == 1 else 64)]
+                    frames = [rng.integers(0, 256, size=(h, w, 3), dtype=np.uint8) for _ in range(64 if bsz == 1 else 128)]
                     pipe = pkg.InferencePipeline(G, device, batch=bsz, depth=2)
-                    for _ in pipe.run(frames[:2 * bsz]):
-                        pass
-                    reps = 4
-                    t0 = time.perf_counter()
-                    count = 0
-                    for _ in range(reps):
-                        for _y in pipe.run(frames):
-                            count += 1
-                    inf["e2e_fps_%s_b%d" % (name, bsz)] = round(count / (time.perf_counter() - t0), 2)
+                    key = "e2e_fps_%s_b%d" % (name, bsz)
+                    inf[key], inf["e2e_spread"][key] = e2e_rate(pipe, frames)
             pipe = pkg.InferencePipeline(G, device, batch=8, depth=3, copy=False)     # zero-copy hand-off of the pinned results
-            for _ in pipe.run(frames[:16]):
-                pass
-            t0, count = time.perf_counter(), 0
-            for _ in range(4):
-                for _y in pipe.run(frames):
-                    count += 1
-            inf["e2e_fps_180x320_b8_zero_copy"] = round(count / (time.perf_counter() - t0), 2)
+            inf["e2e_fps_180x320_b8_zero_copy"], inf["e2e_spread"]["e2e_fps_180x320_b8_zero_copy"] = e2e_rate(pipe, frames)
+            inf["e2e_dtype"] = args.dtype
             inf["e2e"] = "InferencePipeline: pinned uint8 frames -> H2D -> hipGraph(u8->[-1,1], G, uint8 head) -> D2H -> numpy, depth 2"
         out["inference"] = inf
         # device crop pipeline (dataloader.py:24-38 replacement): 96 -> 384 crops cut from a resident uint8 pool

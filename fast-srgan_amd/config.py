@@ -2,7 +2,7 @@
 
 hydra / omegaconf are not dependencies; PyYAML reads the same file and the result is an attribute tree with
 the reference's 20 keys (configs/config.yaml:1-25) plus `generator.n_upsample` (default 2),
-`training.compute_dtype` (bf16 | f16 | f32, default bf16), `training.vgg19_weights` (path of torchvision's vgg19
+`training.compute_dtype` (bf16 | f16 | x3 | f32, default bf16; x3 = split-bf16 operands, the fast mode inside the reference's fp32 tolerance), `training.vgg19_weights` (path of torchvision's vgg19
 checkpoint), `training.allow_random_vgg` (tests / benchmarks only), `training.hip_graph` (replay the iteration as hipGraphs)
 and the fp16 loss scaler:
 

@@ -233,16 +233,27 @@ __global__ __launch_bounds__(NW * 64, 2) void conv_tall3_kernel(const ConvKArgs 
       const int hy = hp / T3_P, hx = hp - hy * T3_P;
       const int iy = tc.gy0 - 1 + hy, ix = tc.gx0 - 1 + hx;
       unsigned o = ~0u;                                          // beyond the buffer: the DMA writes zeros
-      if (U < T3_HUNITS && iy >= 0 && iy < a.IH && ix >= 0 && ix < a.IW)
-        o = (unsigned)((((tc.img * a.IH + iy) * a.IW + ix) * a.Cin + ((ul ^ t3_swz_col(hx)) << 3)) * (int)sizeof(T));
+      if (U < T3_HUNITS && iy >= 0 && iy < a.IH && ix >= 0 && ix < a.IW) {
+        if (!a.in_ps) o = (unsigned)((((tc.img * a.IH + iy) * a.IW + ix) * a.Cin + ((ul ^ t3_swz_col(hx)) << 3)) * (int)sizeof(T));
+        // depth-to-space input [N][2 IH][2 IW][Cin / 4]: quadrant (0, 0) of the pixel; the chunk's quadrant is a scalar offset (hsoff)
+        else o = (unsigned)((((tc.img * 2 * a.IH + 2 * iy) * (2 * a.IW) + 2 * ix) * (a.Cin >> 2) + ((ul ^ t3_swz_col(hx)) << 3)) * (int)sizeof(T));
+      }
       hv[k] = o;
     }
+  };
+  // byte offset (wave-uniform) of virtual chunk c inside a pixel's channels; depth-to-space input: the chunk lies in quadrant
+  // q = chunk >> t3_ps_shift of the 2 x 2 block: + (q >> 1) rows and (q & 1) columns of Cin / 4 channels
+  auto hsoff = [&](int c) -> unsigned {
+    const int p = t3_hmap<X3>(c);
+    if (!a.in_ps) return (unsigned)(p * 64);
+    const int q = p >> a.t3_ps_shift, cq = p - (q << a.t3_ps_shift);
+    return (unsigned)__builtin_amdgcn_readfirstlane((((q >> 1) * 2 * a.IW + (q & 1)) * (a.Cin >> 2) + cq * 32) * (int)sizeof(T));
   };
   // DMA pieces.  Halo piece k of tile-chunk c -> halo buffer (global chunk parity); filter pieces of tap t of chunk c -> ring
   auto dma_halo = [&](const unsigned (&hv)[HPW], int c, int k, unsigned par) {
     if constexpr (!(T3_ABL & 2))
       if (wave + k * NW < T3_NHP)
-        FSR_BLDS16(in_buf, hv[k], (unsigned)(t3_hmap<X3>(c) * 64), halo_addr + (fsr_lds_addr_t)(par * T3_HALO_BYTES + (wave + k * NW) * 1024));
+        FSR_BLDS16(in_buf, hv[k], hsoff(c), halo_addr + (fsr_lds_addr_t)(par * T3_HALO_BYTES + (wave + k * NW) * 1024));
   };
   // stride 2: piece wave + 4 k of chunk c's four planes (the planes lie back to back: piece g goes to g * 1 KB)
   auto dma_halo2 = [&](const unsigned (&hv)[HPW], int c, int k) {
@@ -700,7 +711,15 @@ int fsr_conv_tall3_try(int dtype, ConvKArgs& a, int S, hipStream_t stream) {
   const bool narrow = a.Cout % 128 != 0;
   // (statistics on the 64-channel block: x3 only -- the generator's 64 -> 64 forwards, which the 16-bit modes give to conv64_v2)
   if (narrow && ((a.stats && dtype != FSR_X3) || a.pool2 || S == 2)) return 0;
-  if (a.preact || a.oscale || a.ps || a.in_ps || a.out_f32) return 0;
+  if (a.preact || a.oscale || a.ps || a.out_f32) return 0;
+  // depth-to-space input (the data gradient of a PixelShuffle convolution): x3 only (the 16-bit modes keep their measured
+  // dispatch), stride 1, whole power-of-two runs of 32-channel chunks per quadrant
+  int ps_shift = 0;
+  if (a.in_ps) {
+    const int cpq = a.Cin >> 7;          // 32-channel chunks per quadrant
+    if (dtype != FSR_X3 || S != 1 || cpq < 1 || (a.Cin & 127) != 0 || (cpq & (cpq - 1)) != 0) return 0;
+    while ((1 << ps_shift) < cpq) ++ps_shift;
+  }
   if (a.stats && (a.pool2 || a.dmask)) return 0;   // statistics: forward launches
   if (a.act != FSR_ACT_NONE && a.act != FSR_ACT_RELU && a.act != FSR_ACT_LEAKY) return 0;
   if (a.act == FSR_ACT_LEAKY && !(a.slope >= 0.f && a.slope <= 1.f)) return 0;   // the epilogue's max(v, slope * v) form
@@ -745,6 +764,7 @@ int fsr_conv_tall3_try(int dtype, ConvKArgs& a, int S, hipStream_t stream) {
   if (S == 2) best_mb = 2;
   ConvKArgs b = a;          // `a` stays untouched unless a launch is taken
   for (int t = 0; t < 9; ++t) b.t3_woff[t] = woff[t];
+  b.t3_ps_shift = ps_shift;
   b.tiles_x = (b.GW + 15) / 16;
   b.tiles_y = (b.GH + 4 * best_mb - 1) / (4 * best_mb);
   int rc = 0;

@@ -82,8 +82,9 @@ constexpr size_t wgrad_dma_lds_bytes() {   // two images of (dy tile, halo), eac
   return (size_t)2 * 1024 * (wgrad_dma_dy_instr<T, BM, BN, S, TPH>() + wgrad_dma_halo_instr<T, BM, BN, S, TPH>());
 }
 
-template <typename T, int BM, int BN, int S, int TPH>
+template <typename T, int BM, int BN, int S, int TPH, bool X3W = false>
 __global__ __launch_bounds__((BM >= 64 && BN == 64) ? 512 : 256) void conv_wgrad_kernel(const WgradKArgs a) {
+  static_assert(!X3W || (BM == 128 && BN == 64 && sizeof(T) == 2), "the x3 form of the 128 x 64 block");
   constexpr int NW = (BM >= 64 && BN == 64) ? 8 : 4;   // waves per workgroup
   static_assert(BM <= 64 || (BM == 128 && BN == 64 && sizeof(T) == 2), "128-row blocks: 16-bit, 64 input channels");
   constexpr int NTHR = NW * 64;
@@ -122,7 +123,7 @@ __global__ __launch_bounds__((BM >= 64 && BN == 64) ? 512 : 256) void conv_wgrad
   // x3, 128 x 64 blocks: a wave's four co tiles are (hi, hi, lo, lo) of one channel group and ci tiles 0, 1 / 2, 3 the hi / lo part
   // of the input group.  A wave on a lo ci tile skips its two lo co tiles (the dropped lo x lo block); the ci tiles are dealt so
   // that the two waves of a SIMD (w, w + 4) are one hi and one lo wave: 6 instead of 8 MFMAs per stage and SIMD.
-  const bool x3blk = COPAIR && BM == 128 && a.x3 != 0;
+  constexpr bool x3blk = X3W;
   const int ci_t0 = COPAIR ? (x3blk ? (wave + 2 * (wave / NBT)) % NBT : wave % NBT) : (wave * TPW) % NBT;
   const bool skip_lo = x3blk && ci_t0 >= 2;
 
@@ -348,31 +349,33 @@ __global__ __launch_bounds__((BM >= 64 && BN == 64) ? 512 : 256) void conv_wgrad
         const int ks = i / 9, t = i % 9;
         return frag(pb_base + ((ks * 2 * S + t / 3) * HW + t % 3) * PB, 4 * S * PB);
       };
-      auto run_stages = [&](auto nwc) {      // nwc: co tiles this wave multiplies (TPW, or 2 for an x3 wave on a lo ci tile)
-        constexpr int NWC = decltype(nwc)::value;
-        s16x8 af[2][NWC], bf[3];
+      // (x3: a wave on a lo ci tile leaves out its two lo co tiles -- ONE code path with a wave-uniform skip around their reads and
+      // MFMAs; two specialised copies of the unrolled stage loop made hipcc spill 220 registers)
+      constexpr int NWH = (BM == 128) ? 2 : TPW;       // co tiles every wave multiplies
+      s16x8 af[2][TPW], bf[3];
 #pragma unroll
-        for (int w = 0; w < NWC; ++w) af[0][w] = frag(pa_base + w * 16, 4 * PA);
-        bf[0] = xfrag(0);
-        bf[1] = xfrag(1);
+      for (int w = 0; w < TPW; ++w) af[0][w] = frag(pa_base + w * 16, 4 * PA);
+      bf[0] = xfrag(0);
+      bf[1] = xfrag(1);
 #pragma unroll
-        for (int i = 0; i < NSTAGE; ++i) {
-          const int ks = i / 9, t = i % 9;
-          if (i + 2 < NSTAGE) bf[(i + 2) % 3] = xfrag(i + 2);
-          if (t == 4 && ks + 1 < NS) {
+      for (int i = 0; i < NSTAGE; ++i) {
+        const int ks = i / 9, t = i % 9;
+        if (i + 2 < NSTAGE) bf[(i + 2) % 3] = xfrag(i + 2);
+        if (t == 4 && ks + 1 < NS) {
 #pragma unroll
-            for (int w = 0; w < NWC; ++w) af[(ks + 1) & 1][w] = frag(pa_base + (ks + 1) * 32 * PA + w * 16, 4 * PA);
+          for (int w = 0; w < NWH; ++w) af[(ks + 1) & 1][w] = frag(pa_base + (ks + 1) * 32 * PA + w * 16, 4 * PA);
+          if (!skip_lo) {
+#pragma unroll
+            for (int w = NWH; w < TPW; ++w) af[(ks + 1) & 1][w] = frag(pa_base + (ks + 1) * 32 * PA + w * 16, 4 * PA);
           }
-#pragma unroll
-          for (int w = 0; w < NWC; ++w) acc[t][w] = mfma16<T>(af[ks & 1][w], bf[i % 3], acc[t][w]);
-          __builtin_amdgcn_sched_barrier(0);
         }
-      };
-      if constexpr (BM == 128) {
-        if (skip_lo) run_stages(std::integral_constant<int, 2>{});
-        else run_stages(std::integral_constant<int, TPW>{});
-      } else {
-        run_stages(std::integral_constant<int, TPW>{});
+#pragma unroll
+        for (int w = 0; w < NWH; ++w) acc[t][w] = mfma16<T>(af[ks & 1][w], bf[i % 3], acc[t][w]);
+        if (!skip_lo) {
+#pragma unroll
+          for (int w = NWH; w < TPW; ++w) acc[t][w] = mfma16<T>(af[ks & 1][w], bf[i % 3], acc[t][w]);
+        }
+        __builtin_amdgcn_sched_barrier(0);
       }
     } else if constexpr (sizeof(T) == 2) {
       // K step = 32 pixels = tile rows 2s, 2s+1; lane group g owns pixels k = 8g..8g+7:
@@ -619,9 +622,9 @@ int make_plan(const fsr_wgrad_desc* d_in, WgradPlan& p) {
   return 0;
 }
 
-template <typename T, int BM, int BN, int S, int TPH>
+template <typename T, int BM, int BN, int S, int TPH, bool X3W = false>
 int launch_wgrad(const WgradKArgs& a, size_t lds, hipStream_t stream) {
-  auto kern = conv_wgrad_kernel<T, BM, BN, S, TPH>;
+  auto kern = conv_wgrad_kernel<T, BM, BN, S, TPH, X3W>;
   static bool attr_set = false;
   if (!attr_set) {
     (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -637,6 +640,9 @@ int dispatch_wgrad(const WgradPlan& p, const WgradKArgs& a, hipStream_t stream) 
   if constexpr (sizeof(T) == 2 && TPH == 8) {
     if (p.TPH == 4) {   // 16-bit stride 2, 64 input channels per block: LDS-DMA staging with 4-row tiles
       if (p.S != 2 || p.BN != 64) return fsr_fail(-2, "conv3x3_wgrad: 4-row tiles are a stride-2 configuration");
+      if constexpr (std::is_same<T, bf16_t>::value) {
+        if (p.BM == 128 && a.x3) return launch_wgrad<T, 128, 64, 2, 4, true>(a, p.lds, stream);
+      }
       if (p.BM == 128) return launch_wgrad<T, 128, 64, 2, 4>(a, p.lds, stream);
       if (p.BM == 64) return launch_wgrad<T, 64, 64, 2, 4>(a, p.lds, stream);
       return fsr_fail(-2, "conv3x3_wgrad: no 4-row kernel for block %dx%d", p.BM, p.BN);
@@ -645,6 +651,9 @@ int dispatch_wgrad(const WgradPlan& p, const WgradKArgs& a, hipStream_t stream) 
 #define FSR_WG_CASE(bm, bn)                                                           \
   if (p.BM == bm && p.BN == bn)                                                       \
     return p.S == 1 ? launch_wgrad<T, bm, bn, 1, TPH>(a, p.lds, stream) : launch_wgrad<T, bm, bn, 2, TPH>(a, p.lds, stream);
+  if constexpr (std::is_same<T, bf16_t>::value) {
+    if (p.BM == 128 && p.BN == 64 && p.S == 1 && a.x3) return launch_wgrad<T, 128, 64, 1, TPH, true>(a, p.lds, stream);
+  }
   if constexpr (sizeof(T) == 2) {
     if (p.BM == 128 && p.BN == 64 && p.S == 1) return launch_wgrad<T, 128, 64, 1, TPH>(a, p.lds, stream);
   }

@@ -47,6 +47,7 @@ struct ConvKArgs {
   // conv_tall3.hip: byte offset of the filter slice that serves canonical tap ky*3+kx, and the launch's tile count
   unsigned t3_woff[9];
   int t3_ntiles;
+  int t3_ps_shift;      // depth-to-space input: log2 of the 32-channel chunks per quadrant
   int wlin;             // 0: standard pack [9][rows][K]; 64 / 128: stage-contiguous pack of that channel-block size
                         // ([block][32-channel chunk][slice][row][32]: a DMA piece = 1 KB of contiguous memory; fsr_pack_conv3x3_lin)
   int query, wlin_want; // query = 1 (fsr_conv3x3_pack_block): nothing is launched; the kernel that WOULD run records the block

@@ -8,7 +8,8 @@ same random numbers in the same order as the reference); their forward methods a
 All math runs through fast-srgan_amd.ops on NHWC activations in the module's compute dtype.
 
 Extra constructor keyword (not in the reference): compute_dtype = "bf16" (default; bf16 MFMA with
-f32 accumulation, f32 parameters/statistics) or "f32" (exact-f32 MFMA; the parity mode).
+f32 accumulation, f32 parameters/statistics), "f16" (fp16 MFMA), "x3" (split-bf16 operands, three bf16
+MFMAs per product: the fast mode inside the reference's 1e-3 fp32 tolerance) or "f32" (exact-f32 MFMA).
 """
 import os
 import warnings
