@@ -702,7 +702,9 @@ static int launch_cfg(ConvKArgs& a, hipStream_t stream, ConvKArgs* more = nullpt
   a.premask = (stage_mode() & 65536) ? 0 : 1;
   a.HH = (TH - 1) * S + 3;
   a.HW = 15 * S + 3;
-  if ((long long)a.N * a.IH * a.IW * a.Cin >= (1LL << 31) || (long long)a.N * a.FOH * a.FOW * a.Cout * (X3 ? 2 : 1) >= (1LL << 31))
+  // (x3: a.Cin counts physical bf16 channels, 2 x logical; the kernel's input offsets are unsigned element offsets, good to 2^32 --
+  // a 64-channel 720p batch of 32 is 3.8e9 of them)
+  if ((long long)a.N * a.IH * a.IW * a.Cin >= (X3 ? (1LL << 32) : (1LL << 31)) || (long long)a.N * a.FOH * a.FOW * a.Cout >= (1LL << 31))
     return fsr_fail(-2, "conv3x3: tensors with 2^31 or more elements are not supported");
   if (G == 3 && (a.ntaps % 3 != 0 || nmore > 0)) return fsr_fail(-2, "conv3x3: three-tap stages need a multiple of 3 taps");
   if (a.stats && nmore > 0) return fsr_fail(-2, "conv3x3: statistics are not available for multi-class launches");
