@@ -102,8 +102,27 @@ __device__ __forceinline__ V s2d_lds_read(const char* smem, unsigned off) {
   return *FSR_LDS_PTR(const V, smem + off);
 }
 
-template <typename T>
+// X3 (FSR_X3, T = bf16_t): dy is an x3 tensor seen as a bf16 tensor of a.Cin = 2 x logical channels (hi / lo chunks of 32), the
+// filter pack alternates w_hi / w_lo chunks; the kernel walks three virtual chunks per channel group -- (dy_hi, w_hi), (dy_lo, w_hi),
+// (dy_hi, w_lo) -- through the unchanged pipeline (conv_tall3.hip's scheme: only the DMA source offsets are mapped) and the
+// epilogue sends the hi and the lo parts of a fragment through the transposing buffer one after the other (64 + 64 bytes per
+// pixel and 32-channel group).
+__device__ __forceinline__ int s2d_div3(int j) { return (int)(((unsigned)j * 0xAAABu) >> 17); }
+template <bool X3> __device__ __forceinline__ int s2d_hmap(int j) {
+  if constexpr (!X3) return j;
+  const int g = s2d_div3(j), r = j - 3 * g;
+  return __builtin_amdgcn_readfirstlane(2 * g + (r == 1 ? 1 : 0));
+}
+template <bool X3> __device__ __forceinline__ int s2d_fmap(int j) {
+  if constexpr (!X3) return j;
+  const int g = s2d_div3(j), r = j - 3 * g;
+  return __builtin_amdgcn_readfirstlane(2 * g + (r == 2 ? 1 : 0));
+}
+
+template <typename T, bool X3 = false>
 __global__ __launch_bounds__(S2D_NW * 64, 2) void conv_s2d3_kernel(const ConvKArgs a) {
+  static_assert(!X3 || std::is_same<T, bf16_t>::value, "x3: bf16 planes");
+  typedef typename std::conditional<X3, x3_t, T>::type ST;
   constexpr int BN = S2D_BN, NW = S2D_NW, TH = S2D_TH, MB = S2D_MB, HPW = S2D_HPW;
   HIP_DYNAMIC_SHARED(char, smem)
   const int tid = threadIdx.x, lane = tid & 63;
@@ -115,7 +134,7 @@ __global__ __launch_bounds__(S2D_NW * 64, 2) void conv_s2d3_kernel(const ConvKAr
   const fsr_lds_addr_t ring_addr = halo_addr + 2 * S2D_HALO_BYTES;
   const fsr_buf_t in_buf = fsr_make_buf(a.in, (unsigned)((size_t)a.N * a.IH * a.IW * a.Cin * sizeof(T)));
   const fsr_buf_t w_buf = fsr_make_buf(a.wpk, (unsigned)((size_t)9 * a.CoutPad * a.Cin * sizeof(T)));
-  const int nchunks = a.Cin >> 5;
+  const int nchunks = X3 ? 3 * (a.Cin >> 6) : a.Cin >> 5;       // x3: three virtual chunks per (hi, lo) pair of physical ones
   const unsigned wcs = a.wlin ? (unsigned)(9 * BN * 64) : 64u;      // byte step of the filter source from chunk to chunk
 
   // ---- loop-invariant per-lane addresses (the layouts of conv_tall3.hip) ------------------------------------------------
@@ -158,7 +177,7 @@ __global__ __launch_bounds__(S2D_NW * 64, 2) void conv_s2d3_kernel(const ConvKAr
     tc.img = L / a.tiles_y;
     tc.gy0 = ty * TH;
     tc.gx0 = tx * 16;
-    ws = a.wlin ? (unsigned)(tc.nb * nchunks * 9 * BN * 64) : (unsigned)(tc.nb * BN * a.Cin * (int)sizeof(T));
+    ws = a.wlin ? (unsigned)(tc.nb * (a.Cin >> 5) * 9 * BN * 64) : (unsigned)(tc.nb * BN * a.Cin * (int)sizeof(T));
 #pragma unroll
     for (int k = 0; k < HPW; ++k) {
       const int U = (wave + k * NW) * 64 + lane;
@@ -173,12 +192,12 @@ __global__ __launch_bounds__(S2D_NW * 64, 2) void conv_s2d3_kernel(const ConvKAr
   };
   auto dma_halo = [&](const unsigned (&hv)[HPW], int c, int k, unsigned hb) {
     if constexpr (!(S2D_ABL & 2))
-    FSR_BLDS16(in_buf, hv[k], (unsigned)(c * 64), halo_addr + (fsr_lds_addr_t)(hb + (wave + k * NW) * 1024));
+    FSR_BLDS16(in_buf, hv[k], (unsigned)(s2d_hmap<X3>(c) * 64), halo_addr + (fsr_lds_addr_t)(hb + (wave + k * NW) * 1024));
   };
   // this wave's piece of the tap at position `pos` of chunk c's nine (slice a.t3_woff[forward tap]) into slot offset `dst`
   auto dma_filter = [&](unsigned ws, int c, unsigned woff_tap, unsigned dst) {
     if constexpr (!(S2D_ABL & 2))
-    FSR_BLDS16(w_buf, wvoff, woff_tap + ws + (unsigned)c * wcs, ring_addr + (fsr_lds_addr_t)(dst + wave * 1024));
+    FSR_BLDS16(w_buf, wvoff, woff_tap + ws + (unsigned)s2d_fmap<X3>(c) * wcs, ring_addr + (fsr_lds_addr_t)(dst + wave * 1024));
   };
   auto slot_of = [&](int gs) { return (unsigned)((gs & (S2D_NSLOT - 1)) * S2D_SLOT_BYTES); };
 
@@ -313,8 +332,8 @@ __global__ __launch_bounds__(S2D_NW * 64, 2) void conv_s2d3_kernel(const ConvKAr
     // 2 KB LDS buffer: written in accumulator layout, read back as four lanes per pixel, so a store instruction covers 16
     // pixels x 64 contiguous bytes (16 segments instead of 64).  The mask travels the other way (coalesced load, transposed
     // into accumulator layout) so that the gate is applied to the f32 accumulators exactly as before.
-    T* outp = (T*)a.out;
-    const T* maskp = (const T*)a.dmask;
+    ST* outp = (ST*)a.out;
+    const ST* maskp = (const ST*)a.dmask;
     char* stg = smem + S2D_STAGE_OFF + wave * 2048;
     const int ct = lane >> 2, qt = lane & 3;                               // store layout: pixel column, 16-byte piece
     // Two swizzles (MI355X_MICROARCH.md, LDS: ds_write_b128 is served in groups of 8 contiguous lanes over 32 banks, ds_read_b128 in four
@@ -369,8 +388,9 @@ __global__ __launch_bounds__(S2D_NW * 64, 2) void conv_s2d3_kernel(const ConvKAr
           for (int e = 0; e < 16; ++e) v[e] = ((bits >> e) & 1u) ? v[e] : v[e] * ms;
         } else if (maskp) {   // fused activation backward of the producing layer: dz = dx * act'(y), y = its saved output
           u32x4 m0 = {0u, 0u, 0u, 0u}, m1 = {0u, 0u, 0u, 0u};
-          if (ok0) m0 = *(const u32x4*)(maskp + off0);
-          if (ok1) m1 = *(const u32x4*)(maskp + off1);
+          // (x3: the hi parts carry the sign)
+          if (ok0) m0 = *(const u32x4*)(X3 ? (const void*)x3_hi_ptr(maskp + off0) : (const void*)(maskp + off0));
+          if (ok1) m1 = *(const u32x4*)(X3 ? (const void*)x3_hi_ptr(maskp + off1) : (const void*)(maskp + off1));
           *FSR_LDS_PTR(u32x4, stg + mb0) = m0;
           *FSR_LDS_PTR(u32x4, stg + mb1) = m1;
           FSR_WAVE_SYNC();
@@ -385,6 +405,39 @@ __global__ __launch_bounds__(S2D_NW * 64, 2) void conv_s2d3_kernel(const ConvKAr
             v[8 + 2 * e + 1] = (int)(k1[e] & 0xffff0000u) > 0 ? v[8 + 2 * e + 1] : v[8 + 2 * e + 1] * ms;
           }
         }
+        if constexpr (X3) {
+          u32x4 h0, h1, l0, l1;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            unsigned hh, ll;
+            x3_split2(v[2 * e], v[2 * e + 1], hh, ll);
+            h0[e] = hh; l0[e] = ll;
+            x3_split2(v[8 + 2 * e], v[8 + 2 * e + 1], hh, ll);
+            h1[e] = hh; l1[e] = ll;
+          }
+          char* d0 = (char*)x3_hi_ptr(outp + off0);
+          char* d1 = (char*)x3_hi_ptr(outp + off1);
+          *FSR_LDS_PTR(u32x4, stg + sa0) = h0;
+          *FSR_LDS_PTR(u32x4, stg + sa1) = h1;
+          FSR_WAVE_SYNC();
+          const u32x4 o0 = *FSR_LDS_PTR(const u32x4, stg + sb0), o1 = *FSR_LDS_PTR(const u32x4, stg + sb1);
+          FSR_WAVE_SYNC();
+          *FSR_LDS_PTR(u32x4, stg + sa0) = l0;
+          *FSR_LDS_PTR(u32x4, stg + sa1) = l1;
+          FSR_WAVE_SYNC();
+          const u32x4 q0 = *FSR_LDS_PTR(const u32x4, stg + sb0), q1 = *FSR_LDS_PTR(const u32x4, stg + sb1);
+          FSR_WAVE_SYNC();
+          if (!(S2D_ABL & 1)) {
+            if (ok0) {
+              fsr_st<16>((u32x4*)d0, o0);
+              fsr_st<16>((u32x4*)(d0 + 64), q0);
+            }
+            if (ok1) {
+              fsr_st<16>((u32x4*)d1, o1);
+              fsr_st<16>((u32x4*)(d1 + 64), q1);
+            }
+          }
+        } else {
         u32x4 p0, p1;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
@@ -397,8 +450,9 @@ __global__ __launch_bounds__(S2D_NW * 64, 2) void conv_s2d3_kernel(const ConvKAr
         const u32x4 o0 = *FSR_LDS_PTR(const u32x4, stg + sb0), o1 = *FSR_LDS_PTR(const u32x4, stg + sb1);
         FSR_WAVE_SYNC();
         if (!(S2D_ABL & 1)) {
-          if (ok0) fsr_st<16>((u32x4*)(outp + off0), o0);
-          if (ok1) fsr_st<16>((u32x4*)(outp + off1), o1);
+          if (ok0) fsr_st<16>((u32x4*)((T*)outp + off0), o0);
+          if (ok1) fsr_st<16>((u32x4*)((T*)outp + off1), o1);
+        }
         }
       });
     });
@@ -430,9 +484,9 @@ int s2d_cus() {
   return cus;
 }
 
-template <typename T>
+template <typename T, bool X3 = false>
 int s2d_launch(ConvKArgs& a, hipStream_t stream) {
-  auto kern = conv_s2d3_kernel<T>;
+  auto kern = conv_s2d3_kernel<T, X3>;
   static bool attr_set = false;
   if (!attr_set) {
     (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, S2D_LDS);
@@ -441,7 +495,7 @@ int s2d_launch(ConvKArgs& a, hipStream_t stream) {
   long long grid = (long long)s2d_cus() * 2;
   if (grid > a.t3_ntiles) grid = a.t3_ntiles;
   hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(S2D_NW * 64), S2D_LDS, stream, a);
-  fsr_note_kernel("conv_s2d3_kernel<%s>", std::is_same<T, f16_t>::value ? "f16" : "bf16");
+  fsr_note_kernel("conv_s2d3_kernel<%s>", X3 ? "x3" : (std::is_same<T, f16_t>::value ? "f16" : "bf16"));
   const int rc = fsr_check_launch("conv_s2d3_kernel");
   return rc ? rc : 1;
 }
@@ -453,7 +507,8 @@ int s2d_launch(ConvKArgs& a, hipStream_t stream) {
 // gradient: in = dy (N, IH, IW, Cin), out = dx (N, FOH, FOW, Cout), wpk = the transposed pack [9][Cout][Cin] in forward tap order.
 int fsr_conv_s2d3_try(int dtype, ConvKArgs& a, hipStream_t stream) {
   static const bool off = getenv("FSR_S2D3") && atoi(getenv("FSR_S2D3")) == 0;   // A/B switch
-  if (off || (dtype != FSR_BF16 && dtype != FSR_F16)) return 0;
+  if (off || (dtype != FSR_BF16 && dtype != FSR_F16 && dtype != FSR_X3)) return 0;
+  if (dtype == FSR_X3 && ((a.Cin & 63) != 0 || (a.Cin >> 6) * 3 >= (1 << 15) || a.dmask_bits)) return 0;   // a.Cin: physical channels
   if (a.Cin < 64 || a.Cin % 32 != 0 || a.Cout % 64 != 0 || a.Cout < 64 || a.CoutPad != a.Cout) return 0;
   if (a.ps || a.in_ps || a.out_f32 || a.preact || a.oscale || a.bias || a.stats || a.pool2 || a.act != FSR_ACT_NONE || a.dmask_add) return 0;
   if (a.IH != (a.FOH - 1) / 2 + 1 || a.IW != (a.FOW - 1) / 2 + 1) return 0;
@@ -475,7 +530,7 @@ int fsr_conv_s2d3_try(int dtype, ConvKArgs& a, hipStream_t stream) {
   if (b.wlin != 0 && b.wlin != S2D_BN)
     return fsr_fail(-2, "conv_s2d3: the filter pack is stage-contiguous in blocks of %d channels, this launch needs %d", b.wlin, S2D_BN);
   for (int t = 0; t < 9; ++t) b.t3_woff[t] = b.wlin ? (unsigned)(t * S2D_BN * 64) : (unsigned)((size_t)t * b.CoutPad * b.Cin * 2);
-  const int rc = dtype == FSR_F16 ? s2d_launch<f16_t>(b, stream) : s2d_launch<bf16_t>(b, stream);
+  const int rc = dtype == FSR_X3 ? s2d_launch<bf16_t, true>(b, stream) : (dtype == FSR_F16 ? s2d_launch<f16_t>(b, stream) : s2d_launch<bf16_t>(b, stream));
   if (rc == 1) a = b;
   return rc;
 }

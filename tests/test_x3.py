@@ -91,6 +91,12 @@ def test_x3_conv_fwd_dgrad_wgrad(dev, cd, stride, cin, cout, ps):
     wpk_d = ops.packed_filter(cd, wt.to(dev), L.PACK_DGRAD_PS if ps else L.PACK_DGRAD, cpad_out)
     dx, _, _ = ops.conv3x3_raw(cd, gd, wpk_d, cin, mode=L.CONV_DGRAD, out_hw=(h, w), stride=stride, in_pixel_shuffled=ps)
     assert report("x3.conv.dgrad", relerr(_nchw(dx, cd), xr.grad)) < OP_TOL
+    if stride == 2 and cin % 64 == 0:      # conv_s2d3's x3 form with the fused LeakyReLU(0.2) mask (the saved forward input)
+        assert L.lib().fsr_last_kernel().decode() == "conv_s2d3_kernel<x3>"
+        mask = torch.randn(n, cin, h, w)
+        dxm, _, _ = ops.conv3x3_raw(cd, gd, wpk_d, cin, mode=L.CONV_DGRAD, out_hw=(h, w), stride=2, dact_mask=_nhwc(mask, cd, dev), dact_slope=0.2)
+        want = xr.grad * torch.where(mask > 0, torch.ones_like(mask), torch.full_like(mask, 0.2))
+        assert report("x3.conv.dgrad_masked", relerr(_nchw(dxm, cd), want)) < OP_TOL
     dw = ops.conv3x3_wgrad_raw(cd, xd, gd, cout, cin, stride, dy_pixel_shuffled=ps)
     assert report("x3.conv.wgrad", relerr(dw, wr.grad)) < OP_TOL
 
