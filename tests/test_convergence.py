@@ -35,12 +35,13 @@ def test_16bit_training_tracks_fp32_training(pkg):
         pytest.skip("no GPU")
     conv = _tool()
     lines = []
-    results, rows, worst = conv.main(300, modes=("bf16", "f16"), log=lines.append)
+    # x3 (split bf16, three MFMAs per product: the fast mode inside the fp32 tolerance) runs beside the 16-bit modes, same gates
+    results, rows, worst = conv.main(300, modes=("bf16", "f16", "x3"), log=lines.append)
     out = os.path.join(ROOT, "gpurun_out")
     os.makedirs(out, exist_ok=True)
     with open(os.path.join(out, "convergence.txt"), "w") as f:
         f.write("\n".join(lines) + "\n")
-    for r in results["f32"] + results["bf16"] + results["f16"]:
+    for r in results["f32"] + results["bf16"] + results["f16"] + results["x3"]:
         assert r["finite"]
     # the f32 runs themselves learn: pre-training lowers the pixel loss, the discriminator separates real from fake
     pre = results["f32"][0]["curves"]["pretrain_loss"]

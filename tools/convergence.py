@@ -214,5 +214,16 @@ def main(iters=300, modes=("bf16", "f16"), out_json=None, log=print, seeds=(0, 1
 
 
 if __name__ == "__main__":
-    n = int(sys.argv[1]) if len(sys.argv) > 1 else 300
-    main(n, out_json=sys.argv[2] if len(sys.argv) > 2 else None)
+    # python tools/convergence.py [iterations] [out.json] [--seeds N] [--modes bf16,f16,x3]
+    argv = sys.argv[1:]
+    kw = {}
+    if "--seeds" in argv:
+        i = argv.index("--seeds")
+        kw["seeds"] = tuple(range(int(argv[i + 1])))
+        del argv[i:i + 2]
+    if "--modes" in argv:
+        i = argv.index("--modes")
+        kw["modes"] = tuple(m for m in argv[i + 1].split(",") if m)
+        del argv[i:i + 2]
+    n = int(argv[0]) if len(argv) > 0 else 300
+    main(n, out_json=argv[1] if len(argv) > 1 else None, **kw)
