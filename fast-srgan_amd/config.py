@@ -54,8 +54,12 @@ def load_config(path=None, overrides=()):
         for group, vals in loaded.items():
             cfg.setdefault(group, {}).update(vals or {})
     for ov in overrides:
-        if ov.startswith("hydra."):                     # hydra's own keys: enter_run_dir reads them
+        if ov.startswith("hydra."):                     # hydra's own keys: enter_run_dir reads the two it knows
+            if ov.split("=", 1)[0] not in ("hydra.run.dir", "hydra.job.chdir"):
+                raise ValueError("override %r: the only hydra.* keys reproduced here are hydra.run.dir and hydra.job.chdir" % ov)
             continue
+        if ov[:1] in "+~":                              # hydra's append / delete syntax is not a config key
+            raise ValueError("override %r: hydra's +key / ~key syntax is not supported (use a.b=c)" % ov)
         if "=" not in ov:
             raise ValueError("override %r is not of the form a.b=c" % ov)
         key, val = ov.split("=", 1)

@@ -674,15 +674,17 @@ int t3_launch(ConvKArgs& a, int wg_per_cu, hipStream_t stream) {
   const int nblk_n = a.Cout / BN;
   const long long ntiles = (long long)a.tiles_x * a.tiles_y * a.N * nblk_n;
   if (ntiles <= 0 || ntiles > 0x7fffffffLL) return 0;
-  if (a.query) {            // fsr_conv3x3_pack_block: this kernel would run, and it takes the stage-contiguous pack of its block size
-    a.wlin_want = BN;
-    return 1;
-  }
   if (STATS) {   // one partial slot per tile and pixel-row group of waves; the caller's scratch holds stats_P_max of them
     const long long slots = (long long)a.tiles_x * a.tiles_y * (NW / (BN / (NA * 32)));
     if (slots > a.stats_P_max) return 0;
-    a.stats_P = (int)slots;
-    a.stats_tpi = a.stats_per = 0;
+    if (!a.query) {
+      a.stats_P = (int)slots;
+      a.stats_tpi = a.stats_per = 0;
+    }
+  }
+  if (a.query) {            // fsr_conv3x3_pack_block: this kernel would run (every refusal above was passed: the query cannot drift
+    a.wlin_want = BN;       // from the dispatch), and it takes the stage-contiguous pack of its block size
+    return 1;
   }
   a.nblk_n = nblk_n;
   a.t3_ntiles = (int)ntiles;

@@ -79,6 +79,9 @@ int decode_png_chw(const std::vector<unsigned char>& file, std::vector<unsigned 
     pos += 12 + (size_t)len;
   }
   if (!have_ihdr || W <= 0 || H <= 0 || idat.empty()) return -1;
+  // the IHDR dimensions are untrusted: bound them (a data-set image is a few thousand pixels wide) and hold the raster they
+  // claim against what a deflate stream of this size can possibly inflate to (at most ~1032 : 1) BEFORE allocating it
+  if (W > (1 << 16) || H > (1 << 16)) return -2;
   if (interlace != 0) return -4;
   int ch;                                         // samples per pixel in the stream
   if (ctype == 0) ch = 1;
@@ -95,6 +98,7 @@ int decode_png_chw(const std::vector<unsigned char>& file, std::vector<unsigned 
   }
   const size_t rowbytes = ((size_t)W * ch * depth + 7) / 8;
   const size_t bpp = (size_t)(ch * depth + 7) / 8;            // filter distance in bytes (1 for sub-byte palettes)
+  if ((rowbytes + 1) * (size_t)H > (size_t)1040 * idat.size() + 4096) return -2;
   std::vector<unsigned char> raw((rowbytes + 1) * (size_t)H);
   uLongf rawlen = (uLongf)raw.size();
   if (uncompress(raw.data(), &rawlen, idat.data(), (uLong)idat.size()) != Z_OK || rawlen != raw.size()) return -2;
@@ -185,7 +189,12 @@ extern "C" int fsr_png_decode_chw(const char* png_path, unsigned char* out_chw, 
   std::vector<unsigned char> file, chw;
   if (!read_file(png_path, file)) return fsr_fail(-3, "fsr_png_decode_chw: cannot read %s", png_path);
   int H = 0, W = 0;
-  const int rc = decode_png_chw(file, chw, H, W);
+  int rc;
+  try {
+    rc = decode_png_chw(file, chw, H, W);
+  } catch (...) {        // std::bad_alloc / std::length_error of a hostile header must not cross the C ABI
+    rc = -2;
+  }
   if (rc) return fsr_fail(rc, "fsr_png_decode_chw: %s: %s", png_path,
                           rc == -4 ? "interlaced / 16-bit / low-depth grey PNG: not decoded here" : (rc == -1 ? "not a PNG file" : "corrupt PNG stream"));
   *height = H;
@@ -208,9 +217,13 @@ extern "C" int fsr_png_to_npy(const char* const* png_paths, const char* const* n
       const int i = next.fetch_add(1);
       if (i >= count) break;
       int H = 0, W = 0, rc = -3;
-      if (read_file(png_paths[i], file)) {
-        rc = decode_png_chw(file, chw, H, W);
-        if (rc == 0 && !write_npy_u8_chw(npy_paths[i], chw.data(), H, W)) rc = -3;
+      try {
+        if (read_file(png_paths[i], file)) {
+          rc = decode_png_chw(file, chw, H, W);
+          if (rc == 0 && !write_npy_u8_chw(npy_paths[i], chw.data(), H, W)) rc = -3;
+        }
+      } catch (...) {    // an exception escaping a std::thread terminates the process (rank 0 of a training job)
+        rc = -2;
       }
       if (status) status[i] = rc;
       if (rc) failed.fetch_add(1);

@@ -279,7 +279,10 @@ def _const_vec(values, device):
     return t
 
 USE_LIN_PACK = os.environ.get("FSR_PACK_LIN", "1") != "0"   # A/B switch: 0 = every launch reads the standard filter pack
-USE_SIGN_BITS = os.environ.get("FSR_SIGN_BITS", "1") != "0"   # A/B switch: 0 = activation-gradient masks are always the saved tensors
+# A/B switch: 0 = activation-gradient masks are always the saved tensors.  Only conv_s2d3 reads the packed bits, so switching
+# that kernel off (FSR_S2D3=0) switches the bits off with it instead of leaving a mask no kernel takes
+USE_SIGN_BITS = os.environ.get("FSR_SIGN_BITS", "1") != "0" and os.environ.get("FSR_S2D3", "1") != "0"
+_pack_block_memo = {}     # (descriptor fields, optional-tensor mask) -> block size: the dispatch is deterministic per shape
 USE_POOL_ARGMAX = os.environ.get("FSR_POOL_ARGMAX", "1") != "0"   # A/B switch: 0 = the pool backward re-reads its input and output
 USE_C3_KERNELS = True   # tests flip this to compare the first-layer kernels with the padded-tensor path
 
@@ -464,9 +467,17 @@ def conv3x3_raw(cd, x, wpk, cout, *, mode=L.CONV_FWD, out_hw=None, stride=1, bia
     if isinstance(wpk, FilterSpec):     # pack in the layout the kernel this launch dispatches reads
         opt = ((L.OPT_BIAS if bias is not None else 0) | (L.OPT_PRELU if prelu is not None else 0) | (L.OPT_OSCALE if oscale is not None else 0)
                | (L.OPT_MASK if dact_mask is not None else 0) | (L.OPT_PREACT if want_preact else 0) | (L.OPT_STATS if want_stats else 0))
-        blk = L.lib().fsr_conv3x3_pack_block(ctypes.byref(d), opt) if USE_LIN_PACK else 0
-        if blk < 0:
-            L.check(blk, "fsr_conv3x3_pack_block")
+        blk = 0
+        if USE_LIN_PACK:
+            # one ctypes call (a walk of the whole dispatch chain) per SHAPE, not per launch: eager paths (validation,
+            # inference, f32 / x3 without graphs) otherwise pay it for every convolution
+            key = (tuple(getattr(d, f) for f, _ in d._fields_), opt, L.is_emulation(), os.environ.get("FSR_PERSIST_CUS"), os.environ.get("FSR_T3_ROWS"))
+            blk = _pack_block_memo.get(key)
+            if blk is None:
+                blk = L.lib().fsr_conv3x3_pack_block(ctypes.byref(d), opt)
+                if blk < 0:
+                    L.check(blk, "fsr_conv3x3_pack_block")
+                _pack_block_memo[key] = blk
         d.pack_lin = blk
         wpk = packed_filter(cd, wpk.weight, wpk.mode, wpk.k_pad, lin=blk)
     scratch = _workspace(L.lib().fsr_conv3x3_scratch(ctypes.byref(d)), x.device) if want_stats else None

@@ -73,6 +73,9 @@ def main(argv=None, config_dir="configs"):
     if world > 1:
         torch.distributed.barrier()
     if rank != 0:
+        # (a multi-node job need not share a working directory: a rank that does not see rank 0's directory makes its own)
+        if hydra_run_settings(argv)[0]:
+            os.makedirs(os.path.abspath(run_dir[0]), exist_ok=True)
         enter_run_dir(config, argv, run_dir[0], create=False)
     if rank == 0 and not os.path.exists(config.data.numpy_dir):
         write_images_to_numpy_arrays([os.path.join(config.data.image_dir, x) for x in os.listdir(config.data.image_dir)

@@ -175,3 +175,19 @@ def test_native_png_ingest_matches_pil(tmp_path):
     assert L.lib().fsr_png_decode_chw(os.fsencode(str(src / "grey16.png")), None, 0, ctypes.byref(hh), ctypes.byref(ww)) == -4
     assert L.lib().fsr_png_decode_chw(os.fsencode(str(src / "rgb.png")), None, 0, ctypes.byref(hh), ctypes.byref(ww)) == 0 and (hh.value, ww.value) == (h, w)
     assert L.lib().fsr_png_decode_chw(os.fsencode(str(out / "rgb.npy")), None, 0, ctypes.byref(hh), ctypes.byref(ww)) == -1
+    # a hostile header (round-4 advisor): IHDR claims 2^31 - 1 x 2^31 - 1 pixels over a few bytes of IDAT -- status -2, no
+    # allocation of the claimed raster, no exception across the C ABI (the process used to abort in std::length_error)
+    import struct
+    import zlib
+
+    def chunk(kind, data):
+        return struct.pack(">I", len(data)) + kind + data + struct.pack(">I", zlib.crc32(kind + data) & 0xffffffff)
+
+    for dims in ((0x7fffffff, 0x7fffffff), (60000, 60000)):
+        evil = b"\x89PNG\r\n\x1a\n" + chunk(b"IHDR", struct.pack(">IIBBBBB", dims[0], dims[1], 8, 2, 0, 0, 0)) \
+            + chunk(b"IDAT", zlib.compress(b"\0" * 64)) + chunk(b"IEND", b"")
+        (src / "evil.png").write_bytes(evil)
+        assert L.lib().fsr_png_decode_chw(os.fsencode(str(src / "evil.png")), None, 0, ctypes.byref(hh), ctypes.byref(ww)) == -2
+    st = (ctypes.c_int * 1)()
+    pa, na = (ctypes.c_char_p * 1)(os.fsencode(str(src / "evil.png"))), (ctypes.c_char_p * 1)(os.fsencode(str(out / "evil.npy")))
+    assert L.lib().fsr_png_to_npy(pa, na, 1, 2, st) == 1 and st[0] == -2
