@@ -58,7 +58,7 @@ HBM_PEAK_GBS = 8000.0    # same guide: HBM3E ~8 TB/s
 NOMINAL_SCLK_MHZ = 2400.0   # the boost clock MI355X's dense peaks are quoted at
 LDS_FED_CEILING_TFLOPS = {"bf16": 1740.0, "f16": 1740.0}   # measured: profiles/r03_ubench_lds_mfma32.txt (32x32x16, 4+2 reads per 8 MFMAs, 8 waves per CU)
 STEP_GFLOP_PER_IMAGE = 686.71                         # BASELINE.md section 2, as the REFERENCE graph executes it
-TRAFFIC_FILE = os.path.join(ROOT, "profiles", "conv_traffic.json")
+TRAFFIC_FILE = os.path.join(ROOT, "profiles", "conv_traffic.json")            # bf16; the x3 passes: conv_traffic_x3.json
 
 
 def ns(**k):
@@ -296,9 +296,10 @@ def measure_roofline(trainer, ops, lr, hr, dtype, ms_per_step, B):
     # dispatches, and the whole family
     traffic = fam_traffic = None
     traffic_src = "no PMC record for these kernel sources (profiles/conv_traffic.json)"
-    if os.path.exists(TRAFFIC_FILE):
+    traffic_file = TRAFFIC_FILE if args.dtype != "x3" else TRAFFIC_FILE.replace(".json", "_x3.json")
+    if os.path.exists(traffic_file):
         try:
-            t = json.load(open(TRAFFIC_FILE))
+            t = json.load(open(traffic_file))
             if t.get("kernel_sources_sha16") == kernel_sources_hash() and t.get("dtype") == args.dtype and t.get("batch") == B:
                 fam_traffic = t["bytes_per_launch"]
                 # rocprofv3 prints every template argument (conv_tall3's trailing STATS flag: ",false>" / ",true>"), the library's
@@ -306,7 +307,7 @@ def measure_roofline(trainer, ops, lr, hr, dtype, ms_per_step, B):
                 per = {k.replace(",false>", ">").replace(",true>", ",stats>"): v for k, v in t.get("per_kernel", {}).items()}
                 traffic = per.get(dom_name, {}).get("bytes_per_dispatch")
                 traffic_src = ("rocprofv3 --pmc FETCH_SIZE (x2, gfx950 correction) + WRITE_SIZE over one iteration (%s), "
-                               "recorded in profiles/conv_traffic.json for kernel sources %s" % (t.get("files", "?"), t["kernel_sources_sha16"]))
+                               "recorded in profiles/%s for kernel sources %s" % (t.get("files", "?"), os.path.basename(traffic_file), t["kernel_sources_sha16"]))
             else:
                 traffic_src = "profiles/conv_traffic.json was recorded for other kernel sources / another workload: not quoted"
         except (OSError, ValueError, KeyError):

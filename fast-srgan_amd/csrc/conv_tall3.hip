@@ -157,6 +157,10 @@ __global__ __launch_bounds__(NW * 64, 2) void conv_tall3_kernel(const ConvKArgs 
 
   const fsr_lds_addr_t halo_addr = FSR_LDS_ADDR(smem);
   const fsr_lds_addr_t ring_addr = halo_addr + HALO_TOTAL;
+  float pslope = 0.f;
+  if constexpr (X3) {
+    if (a.act == FSR_ACT_PRELU) pslope = a.prelu[0];      // (a scalar load at kernel start: lgkmcnt, not the DMA's vmcnt)
+  }
   const fsr_buf_t in_buf = fsr_make_buf(a.in, (unsigned)((size_t)a.N * a.IH * a.IW * a.Cin * sizeof(T)));
   const fsr_buf_t w_buf = fsr_make_buf(a.wpk, (unsigned)((size_t)9 * a.CoutPad * a.Cin * sizeof(T)));
   const int nchunks = X3 ? 3 * (a.Cin >> 6) : a.Cin >> 5;       // x3: three virtual chunks per (hi, lo) pair of physical ones
@@ -270,9 +274,15 @@ __global__ __launch_bounds__(NW * 64, 2) void conv_tall3_kernel(const ConvKArgs 
   constexpr int BIAS_BYTES = BN * 4;                       // <= 1024: one piece
   const fsr_lds_addr_t bias_addr = ring_addr + NSLOT * SLOT_BYTES;
   const fsr_buf_t bias_buf = fsr_make_buf(a.bias, a.bias ? (unsigned)(a.Cout * 4) : 0u);
+  // x3, PixelShuffle epilogue (a.ps: rows packed [quadrant][channel], the bias in torch order 4 * channel + quadrant): the WHOLE
+  // bias (Cout <= 256 floats: one piece) is fetched and acc_init gathers from it
+  const bool ps_out = X3 && a.ps != 0;
   auto dma_bias = [&](int nbk, unsigned par) {
     if (!(T3_ABL & 2) && wave == 0 && a.bias) {
-      const unsigned vo = lane * 16 < BIAS_BYTES ? (unsigned)(nbk * BIAS_BYTES + lane * 16) : ~0u;
+      unsigned vo = lane * 16 < BIAS_BYTES ? (unsigned)(nbk * BIAS_BYTES + lane * 16) : ~0u;
+      if constexpr (X3) {
+        if (ps_out) vo = lane * 16 < a.Cout * 4 ? (unsigned)(lane * 16) : ~0u;
+      }
       FSR_BLDS16(bias_buf, vo, 0u, bias_addr + (fsr_lds_addr_t)(par * 1024));
     }
   };
@@ -284,7 +294,13 @@ __global__ __launch_bounds__(NW * 64, 2) void conv_tall3_kernel(const ConvKArgs 
       f32x16 b0;
 #pragma unroll
       for (int e = 0; e < 16; ++e) b0[e] = 0.f;
-      if (a.bias) {
+      if (X3 && ps_out && a.bias) {
+        const int row = cur.nb * BN + wco * (NA * 32) + n * 32 + hi * 16;          // 16 rows of one quadrant (Cout / 4 % 16 == 0)
+        const int q = row >> a.t3_ps_shift, cc = row - (q << a.t3_ps_shift);
+        const unsigned bo = (unsigned)(HALO_TOTAL + NSLOT * SLOT_BYTES) + par * 1024 + (unsigned)((4 * cc + q) * 4);
+#pragma unroll
+        for (int e = 0; e < 16; ++e) b0[e] = t3_lds_read<float>(smem, bo + 16 * e);
+      } else if (a.bias) {
         const unsigned bo = (unsigned)(HALO_TOTAL + NSLOT * SLOT_BYTES) + par * 1024 + (unsigned)((wco * (NA * 32) + n * 32 + hi * 16) * 4);
 #pragma unroll
         for (int e4 = 0; e4 < 4; ++e4) {
@@ -498,12 +514,14 @@ __global__ __launch_bounds__(NW * 64, 2) void conv_tall3_kernel(const ConvKArgs 
     };
     const int oimg = cur.img, ogy0 = cur.gy0, ogx0 = cur.gx0, onb = cur.nb;
     const int gx = ogx0 + l15;
+    ST* prep = (ST*)a.preact;
     auto store_tile = [&](auto actc) {
       constexpr int ACT = decltype(actc)::value;
-      const float slope = a.slope;
+      const float slope = ACT == FSR_ACT_PRELU ? pslope : a.slope;
       auto activate = [&](float x) {
         if constexpr (ACT == FSR_ACT_RELU) return fmaxf(x, 0.f);
         else if constexpr (ACT == FSR_ACT_LEAKY) return fmaxf(x, x * slope);
+        else if constexpr (ACT == FSR_ACT_PRELU) return x > 0.f ? x : x * slope;      // any slope (a trained PReLU weight)
         else return x;
       };
       static_for<0, NA>([&](auto nc) {
@@ -530,7 +548,14 @@ __global__ __launch_bounds__(NW * 64, 2) void conv_tall3_kernel(const ConvKArgs 
               store16(outp + off, v);
             }
           } else if (!(T3_ABL & 1) && ok) {
-            const unsigned off = (unsigned)((oimg * a.FOH + gy) * a.FOW + gx) * (unsigned)a.Cout + (unsigned)co;
+            unsigned off = (unsigned)((oimg * a.FOH + gy) * a.FOW + gx) * (unsigned)a.Cout + (unsigned)co;
+            if constexpr (X3) {
+              if (ps_out) {       // depth-to-space store: packed row co = quadrant q, channel cc -> pixel (2 gy + (q >> 1), 2 gx + (q & 1))
+                const int q = co >> a.t3_ps_shift, cc = co - (q << a.t3_ps_shift);
+                off = (unsigned)((oimg * 2 * a.FOH + 2 * gy + (q >> 1)) * (2 * a.FOW) + 2 * gx + (q & 1)) * (unsigned)(a.Cout >> 2) + (unsigned)cc;
+              }
+              if (prep) store16(prep + off, v);      // the pre-activation a PReLU's backward needs (training)
+            }
 
             if (maskp) {   // fused activation backward of the producing layer: dz = dx * act'(y), y = the saved forward input
               // (x3: the hi parts carry the sign; an addend needs both parts)
@@ -629,6 +654,7 @@ __global__ __launch_bounds__(NW * 64, 2) void conv_tall3_kernel(const ConvKArgs 
     }
     if (a.act == FSR_ACT_RELU) store_tile(std::integral_constant<int, FSR_ACT_RELU>{});
     else if (a.act == FSR_ACT_LEAKY) store_tile(std::integral_constant<int, FSR_ACT_LEAKY>{});
+    else if (X3 && a.act == FSR_ACT_PRELU) store_tile(std::integral_constant<int, X3 ? FSR_ACT_PRELU : FSR_ACT_NONE>{});
     else store_tile(std::integral_constant<int, FSR_ACT_NONE>{});
     if (!has_nxt) break;
     // the next tile becomes the current one; its first fragments are already in registers, its pieces in flight
@@ -713,7 +739,18 @@ int fsr_conv_tall3_try(int dtype, ConvKArgs& a, int S, hipStream_t stream) {
   const bool narrow = a.Cout % 128 != 0;
   // (statistics on the 64-channel block: x3 only -- the generator's 64 -> 64 forwards, which the 16-bit modes give to conv64_v2)
   if (narrow && ((a.stats && dtype != FSR_X3) || a.pool2 || S == 2)) return 0;
-  if (a.preact || a.oscale || a.ps || a.out_f32) return 0;
+  if (a.oscale || a.out_f32) return 0;
+  // PixelShuffle epilogue, PReLU and the pre-activation copy (the generator's up-sampling convolutions, model.py:30-40): the x3
+  // form of the 128-channel block only (the 16-bit modes run these layers on conv64_v2)
+  const bool x3up = dtype == FSR_X3 && S == 1 && a.Cout % 128 == 0 && !a.stats && !a.pool2 && !a.dmask;
+  if ((a.preact || a.ps || a.act == FSR_ACT_PRELU) && !x3up) return 0;
+  int ps_out_shift = 0;
+  if (a.ps && a.in_ps) return 0;
+  if (a.ps) {
+    const int cps = a.Cout >> 2;
+    if (a.Cout > 256 || cps % 32 != 0 || (cps & (cps - 1)) != 0) return 0;
+    while ((1 << ps_out_shift) < cps) ++ps_out_shift;
+  }
   // depth-to-space input (the data gradient of a PixelShuffle convolution): x3 only (the 16-bit modes keep their measured
   // dispatch), stride 1, whole power-of-two runs of 32-channel chunks per quadrant
   int ps_shift = 0;
@@ -723,7 +760,7 @@ int fsr_conv_tall3_try(int dtype, ConvKArgs& a, int S, hipStream_t stream) {
     while ((1 << ps_shift) < cpq) ++ps_shift;
   }
   if (a.stats && (a.pool2 || a.dmask)) return 0;   // statistics: forward launches
-  if (a.act != FSR_ACT_NONE && a.act != FSR_ACT_RELU && a.act != FSR_ACT_LEAKY) return 0;
+  if (a.act != FSR_ACT_NONE && a.act != FSR_ACT_RELU && a.act != FSR_ACT_LEAKY && !(a.act == FSR_ACT_PRELU && x3up)) return 0;
   if (a.act == FSR_ACT_LEAKY && !(a.slope >= 0.f && a.slope <= 1.f)) return 0;   // the epilogue's max(v, slope * v) form
   if (a.osy != 1 || a.osx != 1 || a.ooy != 0 || a.oox != 0 || a.org_y != -1 || a.org_x != -1) return 0;
   if (a.pool2 && (a.dmask || (a.GH & 1) || (a.GW & 1) || S == 2)) return 0;
@@ -766,7 +803,7 @@ int fsr_conv_tall3_try(int dtype, ConvKArgs& a, int S, hipStream_t stream) {
   if (S == 2) best_mb = 2;
   ConvKArgs b = a;          // `a` stays untouched unless a launch is taken
   for (int t = 0; t < 9; ++t) b.t3_woff[t] = woff[t];
-  b.t3_ps_shift = ps_shift;
+  b.t3_ps_shift = a.ps ? ps_out_shift : ps_shift;      // (a launch has a depth-to-space INPUT or OUTPUT, never both)
   b.tiles_x = (b.GW + 15) / 16;
   b.tiles_y = (b.GH + 4 * best_mb - 1) / (4 * best_mb);
   int rc = 0;

@@ -229,7 +229,8 @@ def test_x3_train_step_vs_oracle(dev):
             assert (p.cpu() - sd_ref[k]).abs().mean() <= 0.1 * upd + 1e-12, k
 
 
-@pytest.mark.parametrize("case", ["s1_relu_pool", "s1_stats", "s1_narrow_addend", "s1_narrow_stats", "s1_mask", "s2_stats", "s2_bias_leaky_mask", "rows12"])
+@pytest.mark.parametrize("case", ["s1_relu_pool", "s1_stats", "s1_narrow_addend", "s1_narrow_stats", "s1_mask", "s2_stats", "s2_bias_leaky_mask", "rows12",
+                                  "s1_ps_prelu_preact"])
 def test_x3_conv_tall3_forms(dev, cd, case, monkeypatch):
     """conv_tall3.hip in x3 form (three virtual chunks per channel group: (x_hi, w_hi), (x_lo, w_hi), (x_hi, w_lo)) with few
     workgroups, so that every workgroup walks several tiles and the DMA stream runs on across tile and channel-block boundaries:
@@ -271,15 +272,24 @@ def test_x3_conv_tall3_forms(dev, cd, case, monkeypatch):
         mask = torch.randn(n, cout, oh, ow)
         kw = dict(dact_mask=_nhwc(mask, cd, dev), dact_slope=0.0, act=L.ACT_NONE)
         ref = ref * (mask > 0)
+    elif case == "s1_ps_prelu_preact":      # the generator's up-sampling convolution: bias + PixelShuffle(2) + PReLU, pre-activation kept
+        bias = torch.randn(cout) * 0.1
+        slope_t = torch.tensor([-0.3])      # (a trained PReLU weight may have any sign)
+        spec = ops.FilterSpec(wt.to(dev), L.PACK_FWD_PS, cin)
+        kw = dict(bias=bias.to(dev), act=L.ACT_PRELU, prelu=slope_t.to(dev), pixel_shuffle=True, want_preact=True)
+        pre_ref = F.pixel_shuffle(F.conv2d(x, wt, bias, 1, 1), 2)
+        ref = F.prelu(pre_ref, slope_t)
     elif case == "s2_bias_leaky_mask":
         bias = torch.randn(cout) * 0.1
         mask = torch.randn(n, cout, oh, ow)
         kw = dict(bias=bias.to(dev), act=L.ACT_LEAKY, slope=0.2, dact_mask=_nhwc(mask, cd, dev), dact_slope=0.5)
         pre = F.conv2d(x, wt, bias, 2, 1)
         ref = F.leaky_relu(pre * torch.where(mask > 0, torch.ones_like(mask), torch.full_like(mask, 0.5)), 0.2)
-    y, _, stats = ops.conv3x3_raw(cd, xd, spec, cout, stride=stride, **kw)
+    y, pre, stats = ops.conv3x3_raw(cd, xd, spec, cout, stride=stride, **kw)
     name = L.lib().fsr_last_kernel().decode()
     assert name.startswith("conv_tall3_kernel<x3"), name
+    if case == "s1_ps_prelu_preact":
+        assert relerr(_nchw(pre, cd), pre_ref) < OP_TOL
     assert ("s2>" in name) == (stride == 2) and ("stats" in name) == ("want_stats" in kw), name
     assert report("x3.tall3.%s" % case, relerr(_nchw(y, cd), ref)) < OP_TOL
     if stats is not None:

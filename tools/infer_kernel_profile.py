@@ -6,7 +6,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 pkg = importlib.import_module("fast-srgan_amd")
 dev = "cuda:0"
 torch.manual_seed(0)
-G = pkg.Generator(types.SimpleNamespace(n_filters=64, n_layers=8), compute_dtype="bf16").to(dev).eval()
+G = pkg.Generator(types.SimpleNamespace(n_filters=64, n_layers=8), compute_dtype=os.environ.get("INF_DTYPE", "bf16")).to(dev).eval()
 x = torch.rand(32, 3, 180, 320, device=dev) * 2 - 1
 with torch.no_grad():
     for _ in range(2):

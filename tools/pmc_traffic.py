@@ -29,9 +29,22 @@ def norm(name):
     """rocprofv3's demangled kernel name -> the spelling bench.py / fsr_last_kernel use."""
     n = name.replace("void ", "").replace("(anonymous namespace)::", "").split("(")[0]
     n = n.replace("unsigned short", "bf16").replace("_Float16", "f16").replace("float", "f32").replace(" ", "")
-    if n.startswith("conv_tall3_kernel<"):     # its trailing STATS flag and stride: the library's note prints "<...>" / "<...,stats>" / "<...,s2>" / "<...,stats,s2>"
+    if n.startswith("conv_tall3_kernel<"):     # its trailing STATS / stride / x3 flags: the library's note prints "<x3|bf16,...>" / "<...,stats>" / "<...,s2>" / "<...,stats,s2>"
+        if n.endswith(",true>") and n.count(",") >= 9:          # the trailing X3 flag (round 5): ...,STATS,S,X3>
+            n = n[:-len(",true>")].replace("<bf16,", "<x3,", 1) + ">"
+        elif n.endswith(",false>") and n.count(",") >= 9:
+            n = n[:-len(",false>")] + ">"
         n = n.replace(",false,1>", ">").replace(",true,1>", ",stats>").replace(",false,2>", ",s2>").replace(",true,2>", ",stats,s2>")
         n = n.replace(",false>", ">").replace(",true>", ",stats>")
+    if n.startswith("conv_s2d3_kernel<") or n.startswith("conv_igemm_kernel<"):
+        if n.startswith("conv_s2d3_kernel<bf16,true>"):
+            n = "conv_s2d3_kernel<x3>"
+        elif n.startswith("conv_s2d3_kernel<"):
+            n = n.replace(",false>", ">")
+        if n.startswith("conv_igemm_kernel<") and n.endswith(",1>") and n.count(",") == 9:      # trailing X3 = 1
+            n = n[:-len(",1>")].replace("<bf16,", "<x3,", 1) + ">"
+        elif n.startswith("conv_igemm_kernel<") and n.endswith(",0>") and n.count(",") == 9:
+            n = n[:-len(",0>")] + ">"
     return n
 
 
@@ -61,7 +74,7 @@ if len(sys.argv) > 5 and api:
     rec = {"bytes_per_launch": round(byt / api), "bytes_per_iteration": round(byt), "launches_per_step": api, "iterations": iters,
            "fetch_size_kb_per_iteration": round(fetch / iters), "write_size_kb_per_iteration": round(write / iters),
            "formula": "2 x FETCH_SIZE (gfx950 counts 64 B per 128-B request) + WRITE_SIZE, conv forward + data-gradient kernels",
-           "dtype": "bf16", "batch": 32, "kernel_sources_sha16": bench.kernel_sources_hash(),
+           "dtype": os.environ.get("PMC_DTYPE", "bf16"), "batch": 32, "kernel_sources_sha16": bench.kernel_sources_hash(),
            "files": "%s, %s" % (os.path.basename(sys.argv[1]), os.path.basename(sys.argv[2]))}
     fk, wk = per_kernel_kb(sys.argv[1], "FETCH_SIZE"), per_kernel_kb(sys.argv[2], "WRITE_SIZE")
     rec["per_kernel"] = {k: {"dispatches_per_iteration": fk[k][1] / iters,
