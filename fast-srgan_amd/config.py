@@ -2,7 +2,7 @@
 
 hydra / omegaconf are not dependencies; PyYAML reads the same file and the result is an attribute tree with
 the reference's 20 keys (configs/config.yaml:1-25) plus `generator.n_upsample` (default 2),
-`training.compute_dtype` (bf16 | f16 | x3 | f32, default bf16; x3 = split-bf16 operands, the fast mode inside the reference's fp32 tolerance), `training.vgg19_weights` (path of torchvision's vgg19
+`training.compute_dtype` (bf16 | f16 | x3 | f32, default f16 -- the 16-bit mode that tracks fp32 training best, profiles/r05_convergence.txt; x3 = split-bf16 operands, the fast mode inside the reference's fp32 tolerance), `training.vgg19_weights` (path of torchvision's vgg19
 checkpoint), `training.allow_random_vgg` (tests / benchmarks only), `training.hip_graph` (replay the iteration as hipGraphs)
 and the fp16 loss scaler:
 
@@ -28,7 +28,7 @@ DEFAULTS = {
     "discriminator": {"n_filters": 64, "n_layers": 7},
     "training": {"compiled": False, "pretrain_iterations": 100, "iterations": 100, "device": "cuda", "log_iter": 5000,
                  "checkpoint_iter": 5000, "batch_size": 24, "num_workers": 16, "generator_lr": 1e-4,
-                 "discriminator_lr": 1e-4, "compute_dtype": "bf16", "vgg19_weights": "", "allow_random_vgg": False,
+                 "discriminator_lr": 1e-4, "compute_dtype": "f16", "vgg19_weights": "", "allow_random_vgg": False,
                  "hip_graph": True},
 }
 

@@ -23,7 +23,7 @@ parser.add_argument("--batch", default=8, type=int, help="extension: frames per 
 
 
 def load_generator(config, model_path, device="cuda", compute_dtype=None):
-    model = Generator(config.generator, compute_dtype=compute_dtype or getattr(config.training, "compute_dtype", "bf16"))
+    model = Generator(config.generator, compute_dtype=compute_dtype or getattr(config.training, "compute_dtype", "f16"))
     weights = torch.load(model_path, map_location="cpu")
     model.load_state_dict({k.replace("_orig_mod.", ""): v for k, v in weights.items()})
     return model.to(device).eval()

@@ -7,8 +7,8 @@ submodules are kept purely as PARAMETER CONTAINERS (and so that default initiali
 same random numbers in the same order as the reference); their forward methods are never called.
 All math runs through fast-srgan_amd.ops on NHWC activations in the module's compute dtype.
 
-Extra constructor keyword (not in the reference): compute_dtype = "bf16" (default; bf16 MFMA with
-f32 accumulation, f32 parameters/statistics), "f16" (fp16 MFMA), "x3" (split-bf16 operands, three bf16
+Extra constructor keyword (not in the reference): compute_dtype = "f16" (default since round 5; fp16 MFMA with
+f32 accumulation, f32 parameters/statistics), "bf16" (bf16 MFMA), "x3" (split-bf16 operands, three bf16
 MFMAs per product: the fast mode inside the reference's 1e-3 fp32 tolerance) or "f32" (exact-f32 MFMA).
 """
 import os
@@ -19,7 +19,7 @@ import torch
 from . import _lib as L
 from . import ops
 
-_DEFAULT_DTYPE = os.environ.get("FSR_COMPUTE_DTYPE", "bf16")
+_DEFAULT_DTYPE = os.environ.get("FSR_COMPUTE_DTYPE", "f16")
 
 
 class UpSamplingBlock(torch.nn.Module):

@@ -27,7 +27,7 @@ class Compute:
     hi, then 64 bytes of lo; include/fsr_hip.h).  The container is NOT float data: torch arithmetic on it is meaningless, only
     copies (cat along the batch, clone, slicing whole pixels) are legal -- x3_encode / x3_decode convert."""
 
-    def __init__(self, name="bf16"):
+    def __init__(self, name="f16"):
         if name not in _DT:
             raise ValueError("compute dtype must be 'bf16', 'f16', 'x3' or 'f32', got %r" % (name,))
         self.name = name

@@ -53,7 +53,7 @@ class Trainer:
     def __init__(self, config, vgg_weights=None, perceptual_network=None):
         self.config = config
         dev = self.config.training.device
-        cdt = getattr(config.training, "compute_dtype", "bf16")
+        cdt = getattr(config.training, "compute_dtype", "f16")
         self.is_main = D.rank() == 0
         self.writer = _make_writer(osp.join("runs", config.experiment.name)) if self.is_main else _NullWriter()
         self.generator = Generator(config=config.generator, compute_dtype=cdt).to(dev)
