@@ -114,7 +114,10 @@ __global__ __launch_bounds__(256) void conv_c3_fwd_kernel(const C3Args a) {
   }
   // bf16, full 64-channel block: MFMA tile t holds output channels (t>>1)*32 + (row>>2)*8 + (t&1)*4 + (row&3), so that
   // a lane ends up with two runs of 8 consecutive channels of its pixel = two 16-byte stores
-  const bool wide = sizeof(T) == 2 && ntile == 4;
+  // (x3 storage, f32 arithmetic: the same channel deal, so that a lane stores 16 bytes of hi and 16 bytes of lo parts per run
+  // instead of 8 + 8)
+  constexpr bool X3 = std::is_same<ST, x3_t>::value;
+  const bool wide = (sizeof(T) == 2 || X3) && ntile == 4;
   s16x8 wf16[4];
   float wf32[4][8];
 #pragma unroll
@@ -198,6 +201,30 @@ __global__ __launch_bounds__(256) void conv_c3_fwd_kernel(const C3Args a) {
               for (int q = 0; q < 4; ++q) b |= ((int)(pk[q] << 16) > 0 ? 1u << (2 * q) : 0u) | ((int)(pk[q] & 0xffff0000u) > 0 ? 2u << (2 * q) : 0u);
               a.signs[(((size_t)n * a.H + gy) * a.W + gx) * (a.cout >> 3) + nb * 8 + p * 4 + lg] = (unsigned char)b;
             }
+          }
+        }
+        continue;
+      }
+    }
+    if constexpr (X3) {
+      if (wide) {
+        f32x4 acc[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+          for (int j = 0; j < 8; ++j) acc[t] = mfma_f32_16x16x4(wf32[t][j], xv[j], acc[t]);
+        }
+        if (gx < a.W && gy < a.H) {
+          const size_t off = (((size_t)n * a.H + gy) * a.W + gx) * a.cout + nb * 64 + lg * 8;
+#pragma unroll
+          for (int p = 0; p < 2; ++p) {
+            const f32x4 lo = acc[2 * p] + bv[2 * p], hi = acc[2 * p + 1] + bv[2 * p + 1];
+            float v8[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+            if (prep) V16<x3_t, 4>::st((x3_t*)prep + off + p * 32, v8);
+#pragma unroll
+            for (int q = 0; q < 8; ++q) v8[q] = fmaxf(v8[q], 0.f) + slope * fminf(v8[q], 0.f);
+            V16<x3_t, 4>::st((x3_t*)outp + off + p * 32, v8);
           }
         }
         continue;

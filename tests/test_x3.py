@@ -297,3 +297,29 @@ def test_x3_conv_tall3_forms(dev, cd, case, monkeypatch):
         assert relerr(st[..., 0], ref.sum((2, 3))) < 1e-4 and relerr(st[..., 1], (ref * ref).sum((2, 3))) < 1e-4
         _, _, stats2 = ops.conv3x3_raw(cd, xd, spec, cout, stride=stride, **kw)
         assert torch.equal(stats2.cpu(), st)                    # order-fixed partial slots: bit-reproducible
+
+
+@pytest.mark.parametrize("act", ["leaky", "prelu"])
+def test_x3_first_layer_kernels(dev, cd, act):
+    """Conv2d(3 -> 64) straight from the float image (conv_c3.hip) on x3 storage: exact-f32 arithmetic, 16 + 16-byte hi / lo stores
+    of the 64-channel block, the pre-activation copy of a PReLU layer, weight / bias / slope gradients and the image gradient."""
+    torch.manual_seed(4)
+    n, h, w = (2, 37, 45) if dev.type == "cuda" else (1, 9, 20)
+    img = torch.rand(n, 3, h, w) * 2 - 1
+    wt, b, a1 = torch.randn(64, 3, 3, 3) * 0.2, torch.randn(64) * 0.1, torch.tensor([0.25])
+    xd = img.to(dev).requires_grad_(True)
+    p = [leaf(t.to(dev)) for t in (wt, b, a1)]
+    cfg = ops.ConvCfg(cd, act=L.ACT_PRELU, image_in=True) if act == "prelu" else ops.ConvCfg(cd, act=L.ACT_LEAKY, slope=0.2, image_in=True)
+    y, _ = ops.conv3x3(xd, p[0], p[1], p[2] if act == "prelu" else None, cfg)
+    r = torch.randn(n, 64, h, w)
+    y.backward(_nhwc(r, cd, dev))
+    xr = leaf(img)
+    q = [leaf(t) for t in (wt, b, a1)]
+    pre = F.conv2d(xr, q[0], q[1], 1, 1)
+    yr = F.prelu(pre, q[2]) if act == "prelu" else F.leaky_relu(pre, 0.2)
+    yr.backward(r)
+    assert report("x3.c3.%s.y" % act, relerr(_nchw(y.detach(), cd), yr)) < 2e-5      # f32 arithmetic, then the 16-bit pair: 2^-17
+    assert report("x3.c3.%s.dx" % act, relerr(xd.grad, xr.grad)) < OP_TOL
+    assert relerr(p[0].grad, q[0].grad) < OP_TOL and relerr(p[1].grad, q[1].grad) < OP_TOL
+    if act == "prelu":
+        assert relerr(p[2].grad, q[2].grad) < 2e-3

@@ -84,13 +84,13 @@ def main():
             continue
         cin_pad = cd.pad(cin)
         oh, ow = (h - 1) // stride + 1, (w - 1) // stride + 1
-        x = torch.randn(n, h, w, cin_pad, device=dev).to(cd.torch_dtype)
+        x = ops.to_storage(cd, torch.randn(n, h, w, cin_pad, device=dev))
         wt = (torch.randn(cout, cin, 3, 3, device=dev) * 0.05)
         gflop = 2.0 * n * oh * ow * cout * cin * 9 / 1e9
         wpk = ops.packed_filter(cd, wt, L.PACK_FWD_PS if ps else L.PACK_FWD, cin_pad)
         res = []
         cout_pad = cd.pad(cout)
-        dy = torch.randn((n, 2 * oh, 2 * ow, cout // 4) if ps else (n, oh, ow, cout_pad), device=dev).to(cd.torch_dtype)
+        dy = ops.to_storage(cd, torch.randn((n, 2 * oh, 2 * ow, cout // 4) if ps else (n, oh, ow, cout_pad), device=dev))
         if "fwd" in only:
             t = timeit(lambda: ops.conv3x3_raw(cd, x, wpk, cout, stride=stride, pixel_shuffle=ps, out_f32=(cout == 3),
                                                want_stats=(not ps and cout != 3 and "VGG" not in name and "first" not in name)))

@@ -2,7 +2,7 @@
 # Round-5 artefacts for profiles/: rocprofv3 kernel statistics (single stream, eager: exclusive durations) of the timed iteration in
 # the bf16, x3 and exact-f32 modes and of the cfg5 workload (round-4 verdict: the f32_mode / cfg5 rooflines rested on HIP events alone),
 # of generator inference in bf16 and x3, and the PMC traffic passes (FETCH_SIZE / WRITE_SIZE) bound to the kernel sources' hash for
-# the bf16 and the x3 iteration.   usage: bash tools/gpu_r5_artifacts.sh [stats|pmc|inf|all]
+# the bf16 and the x3 iteration.   usage: bash tools/gpu_r5_artifacts.sh [stats|pmc|inf|conv|all]
 set -u
 R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out/r05; mkdir -p $O; export TMPDIR=/tmp
@@ -10,7 +10,7 @@ WHAT=${1:-all}
 COMMON="--steps 5 --warmup 2 --no-cpu-baseline --no-inference --no-graph --no-f32 --no-x3 --no-sustained --no-cfg5"
 cd /tmp
 if [ "$WHAT" = stats ] || [ "$WHAT" = all ]; then
-  for M in bf16 x3 f32; do
+  for M in f16 bf16 x3 f32; do
     FSR_SIDE_STREAM=0 FSR_WGRAD_STREAM=0 timeout 500 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_$M -o bench -- python $R/bench.py --dtype $M $COMMON > $O/rocprof_$M.log 2>&1
     cp $O/prof_$M/bench_kernel_stats.csv $O/bench_kernel_stats_$M.csv; rm -f $O/prof_$M/bench_kernel_trace.csv
   done
@@ -18,7 +18,7 @@ if [ "$WHAT" = stats ] || [ "$WHAT" = all ]; then
   cp $O/prof_cfg5/bench_kernel_stats.csv $O/bench_kernel_stats_cfg5.csv; rm -f $O/prof_cfg5/bench_kernel_trace.csv
 fi
 if [ "$WHAT" = pmc ] || [ "$WHAT" = all ]; then
-  for M in bf16 x3; do
+  for M in f16 x3; do
     for C in FETCH_SIZE WRITE_SIZE; do
       FSR_SIDE_STREAM=0 FSR_WGRAD_STREAM=0 timeout 500 rocprofv3 --kernel-trace --pmc $C --output-format csv -d $O/pmc_${M}_$C -o step -- python $R/bench.py --dtype $M --steps 1 --warmup 1 --no-cpu-baseline --no-inference --no-graph --no-f32 --no-x3 --no-sustained --no-cfg5 > $O/pmc_${M}_$C.log 2>&1
     done
@@ -30,9 +30,15 @@ if [ "$WHAT" = pmc ] || [ "$WHAT" = all ]; then
   done
 fi
 if [ "$WHAT" = inf ] || [ "$WHAT" = all ]; then
-  for M in bf16 x3; do
+  for M in f16 x3; do
     INF_DTYPE=$M timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/inf_$M -o inf -- python $R/tools/infer_kernel_profile.py > $O/inf_$M.log 2>&1
     cp $O/inf_$M/inf_kernel_stats.csv $O/inference_kernel_stats_$M.csv; rm -f $O/inf_$M/inf_kernel_trace.csv
+  done
+fi
+if [ "$WHAT" = conv ] || [ "$WHAT" = all ]; then
+  for M in f16 x3; do
+    echo "== $M, batch 32" >> $O/conv_bench_$M.txt
+    (cd $R && timeout 300 python tools/conv_bench.py --batch 32 --dtype $M 2>&1 | grep -v "amdgpu.ids") >> $O/conv_bench_$M.txt
   done
 fi
 ls $O; tail -3 $O/pmc_traffic_*.txt 2>/dev/null; tail -2 $O/inf_*.log 2>/dev/null
