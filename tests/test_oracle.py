@@ -81,14 +81,15 @@ def test_train_steps_match_reference_trainer():
         out = O.train_step(g, d, v, torch.from_numpy(z[f"lr{it}"]), torch.from_numpy(z[f"hr{it}"]), noise, gs, ds)
         got = np.array([out["loss_real"], out["loss_fake"], out["adv_loss"], out["content_loss"]], dtype=np.float64)
         assert np.allclose(got, z["losses"][it], rtol=2e-5), (it, got, z["losses"][it])
-    # Parameters after two AdamW steps.  Adam normalises every element's update to ~lr whatever the
-    # gradient's size, so elements whose gradient is tiny inherit its (large) relative fp32 noise:
-    # compare in the mean, relative to the mean update the two steps made.
-    for pre, cur in (("g", g), ("d", d)):
+    # Parameters after two AdamW steps: per tensor, the relative L2 error of the UPDATE the two steps made (round-4 verdict: the
+    # former "mean error <= 8 % of the mean update" bounded little).  Adam normalises every element's update to ~lr whatever
+    # the gradient's size, so elements whose gradient is tiny inherit its (large) relative fp32 noise -- which is why this is
+    # per cent, not 1e-5.  Measured: generator tensors 0.1 .. 3.8 %, discriminator tensors 0.00 .. 1.1 %; the bounds are 2x that.
+    for pre, cur, bound in (("g", g, 0.08), ("d", d, 0.025)):
         for k, p in cur.items():
             p0, p2 = torch.from_numpy(z[f"{pre}0.{k}"]), torch.from_numpy(z[f"{pre}2.{k}"])
-            upd = (p2 - p0).abs().mean()
-            assert upd > 0 and (p - p2).abs().mean() <= 0.08 * upd, (pre, k)
+            upd = (p2 - p0).double().norm()
+            assert upd > 0 and (p - p2).double().norm() <= bound * upd, (pre, k, float((p - p2).double().norm() / upd))
 
 
 def test_chunked_train_step_is_the_same_iteration():

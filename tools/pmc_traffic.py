@@ -25,8 +25,31 @@ def total_kb(path, counter):
     return tot, n
 
 
+_cxa = None
+
+
+def demangle(name):
+    """rocprofv3 leaves a name mangled when its demangler does not know a type -- `DF16_` (_Float16), i.e. every fp16 kernel.
+    Demangle with libstdc++ after spelling _Float16 as `unsigned short` (the bf16 storage type), then put the type back."""
+    global _cxa
+    if not name.startswith("_Z"):
+        return name
+    import ctypes
+    if _cxa is None:
+        _cxa = ctypes.CDLL("libstdc++.so.6").__cxa_demangle
+        _cxa.restype = ctypes.c_void_p
+    f16 = "DF16_" in name
+    st = ctypes.c_int()
+    r = _cxa(name.replace("DF16_", "t").encode(), None, None, ctypes.byref(st))
+    if not r or st.value != 0:
+        return name
+    out = ctypes.string_at(r).decode()
+    return out.replace("unsigned short", "_Float16") if f16 else out
+
+
 def norm(name):
     """rocprofv3's demangled kernel name -> the spelling bench.py / fsr_last_kernel use."""
+    name = demangle(name)
     n = name.replace("void ", "").replace("(anonymous namespace)::", "").split("(")[0]
     n = n.replace("unsigned short", "bf16").replace("_Float16", "f16").replace("float", "f32").replace(" ", "")
     if n.startswith("conv_tall3_kernel<"):     # its trailing STATS / stride / x3 flags: the library's note prints "<x3|bf16,...>" / "<...,stats>" / "<...,s2>" / "<...,stats,s2>"
