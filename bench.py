@@ -353,6 +353,7 @@ def main():
     ap.add_argument("--no-inference", action="store_true")
     ap.add_argument("--no-f32", action="store_true", help="skip the exact-f32 (reference precision) leg")
     ap.add_argument("--no-x3", action="store_true", help="skip the x3 (split-bf16, reference tolerance) leg")
+    ap.add_argument("--no-bf16", action="store_true", help="skip the bf16 leg (the headline dtype of rounds 1-4) beside the fp16 default")
     ap.add_argument("--inference-seconds", type=float, default=5.0, help="minimum timed region of every model-only inference leg")
     ap.add_argument("--inference-dtypes", default="f16,bf16,x3,f32", help="compute modes of the inference legs (the first one fills the top-level keys)")
     ap.add_argument("--no-sustained", action="store_true", help="skip the >= 5 s sustained legs that follow a short timed region")
@@ -381,7 +382,7 @@ def main():
     if args.dtype is None:
         args.dtype = wl["dtype"]
     if args.workload != "cfg3":
-        args.no_inference = args.no_f32 = args.no_x3 = args.no_cpu_baseline = args.no_cfg5 = True     # those legs belong to the headline workload
+        args.no_inference = args.no_f32 = args.no_x3 = args.no_bf16 = args.no_cpu_baseline = args.no_cfg5 = True     # those legs belong to the headline workload
     torch.manual_seed(1234)
     trainer = pkg.Trainer(make_config(args.batch, args.dtype, device, wl), perceptual_network=pkg.VGG19(compute_dtype=args.dtype, seed=1234))
     torch.manual_seed(100 + rank)
@@ -503,6 +504,12 @@ def main():
             "[x3] cases, profiles/r05_parity_errors.log); gradients vs float64: G network 1.3x, D network 2.8x the float32 "
             "oracle's own distance (the f32 mode: 1.05x / 1.1x)")
         out["x3_mode"]["roofline"]["peak_note"] = "2500 / 3 TFLOP/s: three bf16 MFMAs per algorithmic multiply-add"
+    if rank == 0 and world == 1 and not args.no_bf16 and args.dtype == "f16" and args.workload == "cfg3":
+        # continuity with rounds 1-4, whose headline was timed in bf16 (the dtype BASELINE configs[1] names): the same kernels as the
+        # fp16 default, 2-4 % faster at a 2-3 % higher shader clock
+        out["bf16_mode"] = precision_leg("bf16", "bf16 (v_mfma_f32_32x32x16_bf16; rounds 1-4 timed `value` in this mode)",
+                                         "no: outside 1e-3 (content loss 1.7e-3, SR max |error| 3.3e-2); held to the operator-level and "
+                                         "convergence gates like fp16")
     if rank == 0 and world == 1 and not args.no_f32 and args.dtype != "f32":
         # the same iteration at the reference's own precision (exact-f32 MFMA), with the SAME --steps / --warmup and its own
         # roofline against the f32 MFMA peak

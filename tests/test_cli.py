@@ -122,7 +122,7 @@ def test_bench_self_spawns_ranks_and_runs_the_rccl_path():
     for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
         env.pop(k, None)
     r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1", "--batch", "2",
-                        "--no-cpu-baseline", "--no-inference", "--no-f32", "--no-x3", "--no-sustained"], env=env, capture_output=True, text=True, timeout=900)
+                        "--no-cpu-baseline", "--no-inference", "--no-f32", "--no-x3", "--no-bf16", "--no-sustained"], env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-1500:]
     line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1]
     d = json.loads(line)

@@ -7,7 +7,7 @@ set -u
 R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out/r05; mkdir -p $O; export TMPDIR=/tmp
 WHAT=${1:-all}
-COMMON="--steps 5 --warmup 2 --no-cpu-baseline --no-inference --no-graph --no-f32 --no-x3 --no-sustained --no-cfg5"
+COMMON="--steps 5 --warmup 2 --no-cpu-baseline --no-inference --no-graph --no-f32 --no-x3 --no-bf16 --no-sustained --no-cfg5"
 cd /tmp
 if [ "$WHAT" = stats ] || [ "$WHAT" = all ]; then
   for M in f16 bf16 x3 f32; do
@@ -20,7 +20,7 @@ fi
 if [ "$WHAT" = pmc ] || [ "$WHAT" = all ]; then
   for M in f16 x3; do
     for C in FETCH_SIZE WRITE_SIZE; do
-      FSR_SIDE_STREAM=0 FSR_WGRAD_STREAM=0 timeout 500 rocprofv3 --kernel-trace --pmc $C --output-format csv -d $O/pmc_${M}_$C -o step -- python $R/bench.py --dtype $M --steps 1 --warmup 1 --no-cpu-baseline --no-inference --no-graph --no-f32 --no-x3 --no-sustained --no-cfg5 > $O/pmc_${M}_$C.log 2>&1
+      FSR_SIDE_STREAM=0 FSR_WGRAD_STREAM=0 timeout 500 rocprofv3 --kernel-trace --pmc $C --output-format csv -d $O/pmc_${M}_$C -o step -- python $R/bench.py --dtype $M --steps 1 --warmup 1 --no-cpu-baseline --no-inference --no-graph --no-f32 --no-x3 --no-bf16 --no-sustained --no-cfg5 > $O/pmc_${M}_$C.log 2>&1
     done
     L=$(grep '^{' $O/pmc_${M}_WRITE_SIZE.log | tail -1 | python -c "import sys,json; print(json.loads(sys.stdin.read())['roofline']['family']['launches_per_step'])")
     OUT=$R/profiles/conv_traffic.json; [ $M = x3 ] && OUT=$R/profiles/conv_traffic_x3.json

@@ -1,7 +1,7 @@
 import json,sys
 d=json.loads([l for l in open(sys.argv[1]) if l.startswith("{")][-1])
-print("bf16", d["value"], d["ms_per_step"], d.get("sustained",{}).get("value"), d["roofline"]["frac"])
-for m in ("x3_mode","f32_mode"):
+print(d["dtype"], d["value"], d["ms_per_step"], d.get("sustained",{}).get("value"), d["roofline"]["frac"])
+for m in ("bf16_mode","x3_mode","f32_mode"):
     if m not in d: continue
     x=d[m]; print(m, x["value"], x["ms_per_step"], x.get("sustained",{}).get("value"), x["roofline"]["kernel"], x["roofline"]["frac"])
     for k in x["roofline"]["kernels"][:10]: print("   ", k["kernel"], k["launches_per_step"], k["ms_per_step"], k["mfma_frac"])
