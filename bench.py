@@ -6,8 +6,9 @@
 
 A "step" is one full GAN training iteration (/root/reference/trainer.py:171-196: D step + G step with the VGG
 perceptual loss and both AdamW updates) over one synthetic batch that is already resident in HBM
-(BASELINE.json configs[2]: 8 residual blocks / 64 filters, batch 32 per GPU, 96x96 -> 384x384, bf16 MFMA with
-f32 accumulation, random-init weights, kaiming-normal VGG19 stand-in).  N > 1 shards by batch (weak scaling):
+(BASELINE.json configs[2]: 8 residual blocks / 64 filters, batch 32 per GPU, 96x96 -> 384x384, the default 16-bit mode --
+fp16 MFMA with f32 accumulation and the dynamic loss scale since round 5 (profiles/r05_convergence.txt; `--dtype bf16` times the
+mode of rounds 1-4) --, random-init weights, kaiming-normal VGG19 stand-in).  N > 1 shards by batch (weak scaling):
 one process per GPU, two RCCL gradient all-reduces per step; `python bench.py --gpus N` without a launcher
 re-executes itself under torch.distributed.run.  Rank 0 prints ONE JSON line.
 
@@ -19,6 +20,10 @@ Extra keys of that line:
                 file does not belong to the kernel sources being run); `lds_fed_mfma_ceiling` = the same rate against what a bare
                 LDS-fed MFMA loop of this wave tile reaches (micro-benchmark); `family` repeats the figures for ALL conv forward +
                 data-gradient launches together; `kernels` lists every kernel configuration against both the MFMA and the HBM roof;
+  x3_mode       the same iteration in the x3 mode (split-bf16 operands: hi = bf16(v), lo = bf16(v - hi), three bf16 MFMAs per product
+                into one f32 accumulator) -- the FAST mode inside north_star's 1e-3 tolerance -- same --steps /
+                --warmup, its own `roofline` against the bf16 MFMA peak over 3;
+  bf16_mode     the same iteration in bf16 (the headline dtype of rounds 1-4), for continuity;
   f32_mode      the same iteration in the exact-f32 MFMA parity mode -- the precision the reference computes in and the mode that
                 meets north_star's 1e-3 tolerance -- timed with the SAME --steps / --warmup, with its own `roofline` against the
                 157.3 TFLOP/s f32 MFMA peak;
@@ -32,8 +37,10 @@ Extra keys of that line:
                 replays, with its own roofline (`python bench.py --workload cfg5` prints the same workload as the main line);
   allreduce     (a process group exists) ms per step the main stream spends in the two RCCL gradient exchanges, from HIP events
                 around each (10 extra steps outside the timed region), per exchange and as the maximum over ranks;
-  inference     generator-only FPS at 90x160 and 180x320 (BASELINE.json configs[1]), batch 1 and batch 32, plus the
-                end-to-end rate of the uint8 frame pipeline (host bytes -> H2D -> G -> uint8 epilogue -> D2H).
+  inference     generator-only FPS at 90x160 and 180x320 (BASELINE.json configs[1]), batch 1 and batch 32, every leg >= 5 s with the
+                shader clock sampled, in the default mode (top level, `dtype`) and under `modes` in bf16, x3 and exact f32, each with the
+                `roofline` of its forward's dominant kernel; plus the end-to-end rate of the uint8 frame pipeline (host bytes -> H2D ->
+                G -> uint8 epilogue -> D2H): median of five warm passes, min / max under `e2e_spread`.
 """
 import argparse
 import hashlib
