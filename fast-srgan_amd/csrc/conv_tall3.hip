@@ -147,7 +147,9 @@ __global__ __launch_bounds__(NW * 64, 2) void conv_tall3_kernel(const ConvKArgs 
   constexpr int HPS = (HPW + SPC - 1) / SPC > 1 ? (HPW + SPC - 1) / SPC : 1;   // halo pieces a wave issues per stage
   static_assert(S == 2 || (HPW + HPS - 1) / HPS + D <= SPC + 1, "halo pieces must land before their chunk starts");
   static_assert(FP >= 1 && FP <= NM && (S == 2 || HPS + 1 <= NM), "one DMA piece per MFMA slot at most");
-  static_assert(S == 1 || (NM - FP >= 2 && HPW == 11 && D == 3), "stride 2: MFMA slots 0 and 1 of a stage's first substep carry its halo pieces (schedule below)");
+  // (the 64-channel block -- x3: the discriminator's 64 -> 64 stride-2 forward -- has two MFMA slots per substep: its filter piece
+  // shares slot 1 with a halo piece; every piece of a stage is still issued in its first substep, which is all the counted waits need)
+  static_assert(S == 1 || (NM - FP >= (NA == 1 ? 1 : 2) && HPW == 11 && D == 3), "stride 2: MFMA slots 0 and 1 of a stage's first substep carry its halo pieces (schedule below)");
 
   HIP_DYNAMIC_SHARED(char, smem)
   const int tid = threadIdx.x, lane = tid & 63;
@@ -738,7 +740,7 @@ int fsr_conv_tall3_try(int dtype, ConvKArgs& a, int S, hipStream_t stream) {
   // fragment, 5 reads per 4 MFMAs)
   const bool narrow = a.Cout % 128 != 0;
   // (statistics on the 64-channel block: x3 only -- the generator's 64 -> 64 forwards, which the 16-bit modes give to conv64_v2)
-  if (narrow && ((a.stats && dtype != FSR_X3) || a.pool2 || S == 2)) return 0;
+  if (narrow && ((a.stats && dtype != FSR_X3) || a.pool2 || (S == 2 && dtype != FSR_X3))) return 0;
   if (a.oscale || a.out_f32) return 0;
   // PixelShuffle epilogue, PReLU and the pre-activation copy (the generator's up-sampling convolutions, model.py:30-40): the x3
   // form of the 128-channel block only (the 16-bit modes run these layers on conv64_v2)
@@ -813,7 +815,9 @@ int fsr_conv_tall3_try(int dtype, ConvKArgs& a, int S, hipStream_t stream) {
     else if (b.stats) rc = t3_launch<TT, 128, 4, 1, 4, MBV, 2, true>(b, 2, stream);               \
     else rc = t3_launch<TT, 128, 4, 1, 4, MBV>(b, 2, stream);                                     \
   } while (0)
-  if (dtype == FSR_X3 && S == 2) {
+  if (dtype == FSR_X3 && S == 2 && narrow) {
+    rc = b.stats ? t3_launch<bf16_t, 64, 4, 1, 4, 2, 1, true, 2, true>(b, 2, stream) : t3_launch<bf16_t, 64, 4, 1, 4, 2, 1, false, 2, true>(b, 2, stream);
+  } else if (dtype == FSR_X3 && S == 2) {
     rc = b.stats ? t3_launch<bf16_t, 128, 4, 1, 4, 2, 2, true, 2, true>(b, 2, stream) : t3_launch<bf16_t, 128, 4, 1, 4, 2, 2, false, 2, true>(b, 2, stream);
   } else if (dtype == FSR_X3) {
 #define T3_GO3(MBV)                                                                                          \

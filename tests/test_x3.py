@@ -230,7 +230,7 @@ def test_x3_train_step_vs_oracle(dev):
 
 
 @pytest.mark.parametrize("case", ["s1_relu_pool", "s1_stats", "s1_narrow_addend", "s1_narrow_stats", "s1_mask", "s2_stats", "s2_bias_leaky_mask", "rows12",
-                                  "s1_ps_prelu_preact"])
+                                  "s1_ps_prelu_preact", "s2_narrow_stats"])
 def test_x3_conv_tall3_forms(dev, cd, case, monkeypatch):
     """conv_tall3.hip in x3 form (three virtual chunks per channel group: (x_hi, w_hi), (x_lo, w_hi), (x_hi, w_lo)) with few
     workgroups, so that every workgroup walks several tiles and the DMA stream runs on across tile and channel-block boundaries:
@@ -241,7 +241,7 @@ def test_x3_conv_tall3_forms(dev, cd, case, monkeypatch):
     torch.manual_seed(12)
     big = dev.type == "cuda"
     stride = 2 if case.startswith("s2") else 1
-    cin, cout = {"s1_narrow_addend": (128, 64), "s1_narrow_stats": (64, 64), "s2_bias_leaky_mask": (128, 256)}.get(case, (128, 128))
+    cin, cout = {"s1_narrow_addend": (128, 64), "s1_narrow_stats": (64, 64), "s2_narrow_stats": (64, 64), "s2_bias_leaky_mask": (128, 256)}.get(case, (128, 128))
     if not big:
         cin = 64 if case != "s1_narrow_addend" else 64      # (emulated lanes are slow: 64 logical = 128 physical channels)
     n = 3 if big else 1
@@ -262,7 +262,7 @@ def test_x3_conv_tall3_forms(dev, cd, case, monkeypatch):
         bias = torch.randn(cout) * 0.1
         kw = dict(bias=bias.to(dev), act=L.ACT_RELU, pool2=True)
         ref = F.max_pool2d(F.relu(F.conv2d(x, wt, bias, 1, 1)), 2)
-    elif case in ("s1_stats", "s1_narrow_stats", "s2_stats", "rows12"):
+    elif case in ("s1_stats", "s1_narrow_stats", "s2_stats", "s2_narrow_stats", "rows12"):
         kw = dict(want_stats=True)
     elif case == "s1_narrow_addend":
         add = torch.randn(n, cout, oh, ow)
