@@ -38,7 +38,8 @@ Extra keys of that line:
   allreduce     (a process group exists) ms per step the main stream spends in the two RCCL gradient exchanges, from HIP events
                 around each (10 extra steps outside the timed region), per exchange and as the maximum over ranks;
   inference     generator-only FPS at 90x160 and 180x320 (BASELINE.json configs[1]), batch 1 and batch 32, every leg >= 5 s with the
-                shader clock sampled, in the default mode (top level, `dtype`) and under `modes` in bf16, x3 and exact f32, each with the
+                shader clock sampled, in the default mode (top level, `dtype`) and under `modes` in x3 and exact f32 (`--inference-dtypes
+                f16,bf16,x3,f32` adds bf16, BASELINE configs[1]'s dtype: within 2 % of fp16, profiles/r05_bench_n1.json.log), each with the
                 `roofline` of its forward's dominant kernel; plus the end-to-end rate of the uint8 frame pipeline (host bytes -> H2D ->
                 G -> uint8 epilogue -> D2H): median of five warm passes, min / max under `e2e_spread`.
 """
@@ -362,7 +363,7 @@ def main():
     ap.add_argument("--no-x3", action="store_true", help="skip the x3 (split-bf16, reference tolerance) leg")
     ap.add_argument("--no-bf16", action="store_true", help="skip the bf16 leg (the headline dtype of rounds 1-4) beside the fp16 default")
     ap.add_argument("--inference-seconds", type=float, default=5.0, help="minimum timed region of every model-only inference leg")
-    ap.add_argument("--inference-dtypes", default="f16,bf16,x3,f32", help="compute modes of the inference legs (the first one fills the top-level keys)")
+    ap.add_argument("--inference-dtypes", default="f16,x3,f32", help="compute modes of the inference legs (the first one fills the top-level keys)")
     ap.add_argument("--no-sustained", action="store_true", help="skip the >= 5 s sustained legs that follow a short timed region")
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of hipGraph replays")
     args = ap.parse_args()
