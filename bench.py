@@ -563,6 +563,8 @@ def main():
         modes = [m for m in args.inference_dtypes.split(",") if m]
         if args.dtype not in modes:
             modes = [args.dtype] + modes
+        if world > 1:       # the other ranks wait at the final barrier meanwhile: the default mode only
+            modes = [args.dtype]
 
         def model_only(dt):
             """Generator-only FPS in compute mode dt: every leg one hipGraph launch per call, >= --inference-seconds timed with the
