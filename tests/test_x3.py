@@ -325,3 +325,42 @@ def test_x3_first_layer_kernels(dev, cd, act):
     assert relerr(p[0].grad, q[0].grad) < OP_TOL and relerr(p[1].grad, q[1].grad) < OP_TOL
     if act == "prelu":
         assert relerr(p[2].grad, q[2].grad) < 2e-3
+
+
+def test_x3_argument_checks(dev, cd):
+    """Refusals of the x3 entry points: nothing is enqueued, fsr_last_error says why -- channel counts that are not whole hi / lo
+    groups of 32, tensors whose base is not 128-byte aligned (the split addressing works on 128-byte blocks), filter packs of the
+    first-layer kernels in the wrong element type are impossible by construction (float image: checked by size)."""
+    import ctypes
+    lib = L.lib()
+    x = ops.to_storage(cd, torch.randn(1, 4, 6, 64)).to(dev)
+    out = ops._empty((1, 4, 6, 64), torch.float32, dev)
+    st = torch.zeros(1, 64, 2, dtype=torch.float32, device=dev)
+    # an unaligned view: 16 channels (64 bytes) into a pixel
+    flat = ops._empty((1 * 4 * 6 * 64 + 64,), torch.float32, dev)
+    mis = flat[16:16 + 4 * 6 * 64].view(1, 4, 6, 64)
+    assert mis.data_ptr() % 128 != 0
+    rc = lib.fsr_instnorm_act_fwd(L.FSR_X3, mis.data_ptr(), st.data_ptr(), None, L.ACT_NONE, 0.0, None, out.data_ptr(), 1, 24, 64, ops._stream())
+    assert rc == -2 and b"128-byte aligned" in lib.fsr_last_error()
+    rc = lib.fsr_add(L.FSR_X3, x.data_ptr(), mis.data_ptr(), out.data_ptr(), x.numel(), ops._stream())
+    assert rc == -2 and b"128-byte aligned" in lib.fsr_last_error()
+    # 48 channels: not whole groups of 32
+    rc = lib.fsr_maxpool2_fwd(L.FSR_X3, x.data_ptr(), out.data_ptr(), None, 1, 4, 6, 48, ops._stream())
+    assert rc == -2 and b"multiple of 32" in lib.fsr_last_error()
+    d = L.ConvDesc(L.FSR_X3, L.CONV_FWD, 1, 4, 6, 48, 4, 6, 64, 1, L.ACT_NONE, 0.0, 0, 0, 0, 0, 0, 0)
+    rc = lib.fsr_conv3x3(ctypes.byref(d), x.data_ptr(), x.data_ptr(), None, None, None, None, 0.0, out.data_ptr(), None, None, None, ops._stream())
+    assert rc == -2 and b"multiple of 32" in lib.fsr_last_error()
+    d = L.ConvDesc(L.FSR_X3, L.CONV_FWD, 1, 4, 6, 64, 4, 6, 64, 1, L.ACT_NONE, 0.0, 0, 0, 0, 0, 0, 0)
+    rc = lib.fsr_conv3x3(ctypes.byref(d), mis.data_ptr(), x.data_ptr(), None, None, None, None, 0.0, out.data_ptr(), None, None, None, ops._stream())
+    assert rc == -2 and b"128-byte aligned" in lib.fsr_last_error()
+    wd = L.WgradDesc(L.FSR_X3, 1, 4, 6, 48, 48, 4, 6, 64, 64, 1, 0)
+    assert lib.fsr_conv3x3_wgrad_workspace(ctypes.byref(wd)) == 0
+    # the grouped weight gradient has no x3 form: refused, the caller launches the layers one by one (ops._wgrad_defer)
+    wd = L.WgradDesc(L.FSR_X3, 1, 4, 6, 64, 64, 4, 6, 64, 64, 1, 0)
+    arr = (ctypes.c_void_p * 1)(x.data_ptr())
+    ws = torch.zeros(1 << 20, dtype=torch.float32, device=dev)
+    rc = lib.fsr_conv3x3_wgrad_grouped(ctypes.byref(wd), 1, arr, arr, arr, ws.data_ptr(), ops._stream())
+    assert rc == -2
+    # smooth L1 on x3 containers needs the caller to say so (a float32 container looks like float data)
+    with pytest.raises(L.FsrError):
+        ops.smooth_l1(x.to(torch.bfloat16), x.to(torch.bfloat16), cd=cd)
