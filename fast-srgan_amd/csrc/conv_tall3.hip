@@ -815,6 +815,8 @@ int fsr_conv_tall3_try(int dtype, ConvKArgs& a, int S, hipStream_t stream) {
     else if (b.stats) rc = t3_launch<TT, 128, 4, 1, 4, MBV, 2, true>(b, 2, stream);               \
     else rc = t3_launch<TT, 128, 4, 1, 4, MBV>(b, 2, stream);                                     \
   } while (0)
+  // x3, 64-channel block: three-tap stages (G = 3, two slots: one barrier per 12 MFMAs and wave instead of per 4) -- A/B switch
+  static const bool g3 = getenv("FSR_T3N_G3") && atoi(getenv("FSR_T3N_G3")) == 1;
   if (dtype == FSR_X3 && S == 2 && narrow) {
     rc = b.stats ? t3_launch<bf16_t, 64, 4, 1, 4, 2, 1, true, 2, true>(b, 2, stream) : t3_launch<bf16_t, 64, 4, 1, 4, 2, 1, false, 2, true>(b, 2, stream);
   } else if (dtype == FSR_X3 && S == 2) {
@@ -822,7 +824,9 @@ int fsr_conv_tall3_try(int dtype, ConvKArgs& a, int S, hipStream_t stream) {
   } else if (dtype == FSR_X3) {
 #define T3_GO3(MBV)                                                                                          \
   do {                                                                                                       \
-    if (narrow && b.stats) rc = t3_launch<bf16_t, 64, 4, 1, 4, MBV, 1, true, 1, true>(b, 2, stream);         \
+    if (narrow && g3 && b.stats) rc = t3_launch<bf16_t, 64, 4, 3, 2, MBV, 1, true, 1, true>(b, 2, stream);   \
+    else if (narrow && g3) rc = t3_launch<bf16_t, 64, 4, 3, 2, MBV, 1, false, 1, true>(b, 2, stream);        \
+    else if (narrow && b.stats) rc = t3_launch<bf16_t, 64, 4, 1, 4, MBV, 1, true, 1, true>(b, 2, stream);    \
     else if (narrow) rc = t3_launch<bf16_t, 64, 4, 1, 4, MBV, 1, false, 1, true>(b, 2, stream);              \
     else if (b.stats) rc = t3_launch<bf16_t, 128, 4, 1, 4, MBV, 2, true, 1, true>(b, 2, stream);             \
     else rc = t3_launch<bf16_t, 128, 4, 1, 4, MBV, 2, false, 1, true>(b, 2, stream);                         \
