@@ -44,16 +44,21 @@ def build_hip(force=False, verbose=True):
     for s in srcs:
         src = os.path.join(CSRC, s)
         obj = os.path.join(OBJ, os.path.splitext(s)[0] + ".o")
-        if force or not os.path.exists(obj) or os.path.getmtime(obj) < max(os.path.getmtime(src), hdr_t):
+        if (force or not os.path.exists(obj) or os.path.getmtime(obj) < max(os.path.getmtime(src), hdr_t)
+                or not os.path.exists(os.path.splitext(obj)[0] + ".res")):
             todo.append((src, obj))
     hipcc = _hipcc()
 
     def cc(job):
         src, obj = job
-        cmd = [hipcc] + (flags if src.endswith(".hip") else ["-x", "hip"] + flags) + ["-c", src, "-o", obj]
+        # -Rpass-analysis=kernel-resource-usage: the registers / scratch / occupancy of every kernel, kept next to the object
+        # (<name>.res) -- tools/kernel_resources.py prints them, tests/test_tools.py asserts the hot kernels spill nothing
+        cmd = [hipcc] + (flags if src.endswith(".hip") else ["-x", "hip"] + flags) + ["-Rpass-analysis=kernel-resource-usage", "-c", src, "-o", obj]
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError("hipcc failed for %s:\n%s" % (src, r.stderr[-8000:]))
+        with open(os.path.splitext(obj)[0] + ".res", "w") as f:
+            f.write(r.stderr)
         return src
 
     if todo:

@@ -56,7 +56,9 @@ def load_config(path=None, overrides=()):
     for ov in overrides:
         if ov.startswith("hydra."):                     # hydra's own keys: enter_run_dir reads the two it knows
             if ov.split("=", 1)[0] not in ("hydra.run.dir", "hydra.job.chdir"):
-                raise ValueError("override %r: the only hydra.* keys reproduced here are hydra.run.dir and hydra.job.chdir" % ov)
+                # (a warning, not an error: a reference command line carrying e.g. hydra.verbose=true must keep working)
+                import warnings
+                warnings.warn("override %r ignored: the only hydra.* keys reproduced here are hydra.run.dir and hydra.job.chdir" % ov)
             continue
         if ov[:1] in "+~":                              # hydra's append / delete syntax is not a config key
             raise ValueError("override %r: hydra's +key / ~key syntax is not supported (use a.b=c)" % ov)

@@ -276,4 +276,7 @@ class VGG19(torch.nn.Module):
         return y
 
     def forward(self, x):
-        return self.features_nhwc(x).permute(0, 3, 1, 2)
+        """(N,3,H,W) in [-1,1] -> (N,512,H/16,W/16) feature VALUES (model.py:20-23).  In the x3 mode the kernels' output is a
+        float32 container of bf16 hi / lo planes: it is decoded here (and the cotangent re-encoded on the way back), so
+        callers of V(x) never see the container; the trainer's loss kernels take features_nhwc() directly."""
+        return ops.values(self.compute, self.features_nhwc(x)).permute(0, 3, 1, 2)

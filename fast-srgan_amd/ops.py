@@ -101,6 +101,27 @@ def from_storage(cd, t):
     return x3_decode(t) if cd.x3 else t.float()
 
 
+class _StorageBoundaryFn(torch.autograd.Function):
+    """Storage tensor of a compute mode -> float32 VALUES, differentiable: the backward re-encodes the cotangent.  The boundary
+    every public forward() crosses before handing a tensor to arbitrary torch code -- an x3 activation is a float32 CONTAINER of
+    interleaved bf16 hi / lo planes, and any torch arithmetic on it (autograd accumulation, .float(), a channel-wise cat)
+    would be silent garbage (round-5 advisor, model.py:279)."""
+
+    @staticmethod
+    def forward(ctx, cd, t):
+        ctx.cd = cd
+        return from_storage(cd, t)
+
+    @staticmethod
+    def backward(ctx, g):
+        return None, to_storage(ctx.cd, g.contiguous())
+
+
+def values(cd, t):
+    """float32 values of a storage tensor, with the cotangent routed back in storage form (module boundaries)."""
+    return _StorageBoundaryFn.apply(cd, t) if cd.x3 else t
+
+
 def add(cd, a, b):
     """a + b of two activation tensors (fsr_add): what autograd's accumulation would do, legal for x3 containers."""
     _check_dev(a, b)
@@ -283,6 +304,8 @@ USE_LIN_PACK = os.environ.get("FSR_PACK_LIN", "1") != "0"   # A/B switch: 0 = ev
 # that kernel off (FSR_S2D3=0) switches the bits off with it instead of leaving a mask no kernel takes
 USE_SIGN_BITS = os.environ.get("FSR_SIGN_BITS", "1") != "0" and os.environ.get("FSR_S2D3", "1") != "0"
 _pack_block_memo = {}     # (descriptor fields, optional-tensor mask) -> block size: the dispatch is deterministic per shape
+_DISPATCH_ENV = ("FSR_PERSIST_CUS", "FSR_T3_ROWS", "FSR_S2D3", "FSR_T3N_G3", "FSR_CONV_STAGE", "FSR_CONV64_S2FWD", "FSR_PACK_LIN",
+                 "FSR_C64T3")   # every switch the conv dispatch reads (csrc: getenv) + the Python-side ones
 USE_POOL_ARGMAX = os.environ.get("FSR_POOL_ARGMAX", "1") != "0"   # A/B switch: 0 = the pool backward re-reads its input and output
 USE_C3_KERNELS = True   # tests flip this to compare the first-layer kernels with the padded-tensor path
 
@@ -471,7 +494,10 @@ def conv3x3_raw(cd, x, wpk, cout, *, mode=L.CONV_FWD, out_hw=None, stride=1, bia
         if USE_LIN_PACK:
             # one ctypes call (a walk of the whole dispatch chain) per SHAPE, not per launch: eager paths (validation,
             # inference, f32 / x3 without graphs) otherwise pay it for every convolution
-            key = (tuple(getattr(d, f) for f, _ in d._fields_), opt, L.is_emulation(), os.environ.get("FSR_PERSIST_CUS"), os.environ.get("FSR_T3_ROWS"))
+            # (the key carries everything the C-side dispatch reads besides the descriptor: the device -- its CU count sizes the
+            # persistent grids --, the library in use and every dispatch switch of the environment; round-5 advisor)
+            key = (tuple(getattr(d, f) for f, _ in d._fields_), opt, L.is_emulation(), str(x.device), L.LIB_PATH,
+                   tuple(os.environ.get(v) for v in _DISPATCH_ENV))
             blk = _pack_block_memo.get(key)
             if blk is None:
                 blk = L.lib().fsr_conv3x3_pack_block(ctypes.byref(d), opt)

@@ -78,13 +78,9 @@ def test_full_width_vgg19_forward_and_input_gradient(pkg, cdn):
     xd = x.to(dev).requires_grad_(True)
     y = V(xd)
     r = torch.randn(2, 512, 4, 6)
-    if cdn == "x3":     # x3 features live in a float32 CONTAINER: seed the backward with the encoded cotangent, decode the features
-        from backend import ops
-        yn = V.features_nhwc(xd)
-        yn.backward(ops.x3_encode(r.permute(0, 2, 3, 1).contiguous()).to(dev))
-        y = ops.x3_decode(yn.detach()).permute(0, 3, 1, 2)
-    else:
-        (y.float() * r.to(dev)).sum().backward()
+    # (x3: the public forward decodes the float32 CONTAINER the kernels write and re-encodes the cotangent on the way back --
+    # ops.values; plain torch arithmetic on V(x) is legal in every mode)
+    (y.float() * r.to(dev)).sum().backward()
 
     def oracle(q):
         xr = x.clone().requires_grad_(True)
@@ -255,22 +251,37 @@ def _adam_state_for_oracle(opt, names):
     return st
 
 
-def test_graph_replayed_bf16_iteration_at_the_benched_batch(pkg):
-    """THE configuration bench.py times (BASELINE configs[2]): batch 32 (the discriminator sees 2B = 64), 96 -> 384, bf16, the
-    iteration replayed as ONE hipGraph with the perceptual branch and the weight gradients on their side streams -- against
-    the oracle with the bf16 storage model (trainer.py:171-196), evaluated in slices of 4 samples (O.train_step(chunk=4), the
-    same iteration: tests/test_oracle.py).  One eager iteration warms the buffers and moves the weights off their
-    initialisation; the replay then runs on a NEW batch, so it demonstrably reads the graph's static inputs."""
+_B32_ORACLE = {}      # the plain fp32 oracle's evaluation of the benched-batch iteration, shared by the x3 and f16 cases (same seed, same start)
+# Gates of the benched-batch replay against the PLAIN fp32 oracle (float32, not float64: a float64 evaluation at batch 32 costs
+# minutes of CPU).  x3: the four losses at north_star's 1e-3; gradients as relative L2 per tensor / cosine per network, ~2x the
+# values measured on the MI355X (profiles/r06_parity_errors.log) -- the float32 oracle itself sits 0.2 % (D) / 9 % (G) from
+# float64 at cfg #1, so these bound kernel bugs (ratios of tens), not the last bit.  f16: the cfg #5 gates.
+B32_X3_LOSS, B32_X3_D_GRAD, B32_X3_G_GRAD, B32_X3_COS_D, B32_X3_COS_G, B32_X3_SLOPE = 1e-3, 0.06, 0.35, 0.998, 0.95, 0.2
+
+
+@pytest.mark.parametrize("cdn", ["x3", "f16", "bf16"])
+def test_graph_replayed_iteration_at_the_benched_batch(pkg, cdn):
+    """THE configuration bench.py times (BASELINE configs[2]): batch 32 (the discriminator sees 2B = 64), 96 -> 384, the
+    iteration replayed as ONE hipGraph with the perceptual branch and the weight gradients on their side streams, in the modes
+    the bench times -- x3 (the headline: `value`), f16 (the default 16-bit mode, device-side dynamic loss scale inside the
+    graph) and bf16 -- against the oracle (trainer.py:171-196) evaluated in slices of 4 samples (O.train_step(chunk=4), the same
+    iteration: tests/test_oracle.py).  One eager iteration warms the buffers; the replay then runs on a NEW batch, so it
+    demonstrably reads the graph's static inputs.
+      bf16: the oracle with the bf16 storage model, from the weights the warm-up iteration left (off their initialisation);
+      x3, f16: the PLAIN fp32 oracle -- one evaluation shared by both: weights and AdamW moments are put back to the
+               initialisation after the capture, so both modes replay the same iteration from the same start."""
     dev = select("hip")
     torch.manual_seed(9)
     B = 32
     cfg = ns(experiment=ns(name="cfg2", seed=1234), generator=ns(n_filters=64, n_layers=8),
              discriminator=ns(n_filters=64, n_layers=7),
              training=ns(compiled=False, device=str(dev), log_iter=1, checkpoint_iter=10 ** 9, generator_lr=1e-4,
-                         discriminator_lr=1e-4, batch_size=B, compute_dtype="bf16"))
-    T = pkg.Trainer(cfg, perceptual_network=pkg.VGG19(compute_dtype="bf16", seed=1234))
+                         discriminator_lr=1e-4, batch_size=B, compute_dtype=cdn))
+    T = pkg.Trainer(cfg, perceptual_network=pkg.VGG19(compute_dtype=cdn, seed=1234))
     assert T.use_side_stream
     v_sd = O.vgg_standin_state_dict(1234, 1)
+    g0 = {k: v.detach().cpu().clone() for k, v in T.generator.state_dict().items()}
+    d0 = {k: v.detach().cpu().clone() for k, v in T.discriminator.state_dict().items()}
 
     def batch():
         return (torch.rand(B, 3, 96, 96) * 2 - 1, torch.rand(B, 3, 384, 384) * 2 - 1, [torch.rand(B, 1, 24, 24) for _ in range(3)])
@@ -279,28 +290,66 @@ def test_graph_replayed_bf16_iteration_at_the_benched_batch(pkg):
     T.capture_train_step(lr0.to(dev), hr0.to(dev), warmup=1, noise=[t.to(dev) for t in n0])
     torch.cuda.synchronize()
     assert len(T._graphs) == 1
-    g1 = {k: v.detach().cpu().clone() for k, v in T.generator.state_dict().items()}
-    d1 = {k: v.detach().cpu().clone() for k, v in T.discriminator.state_dict().items()}
-    g_state = _adam_state_for_oracle(T.optim_generator, [k for k, _ in T.generator.named_parameters()])
-    d_state = _adam_state_for_oracle(T.optim_discriminator, [k for k, _ in T.discriminator.named_parameters()])
-    assert g_state["step"] == 1 and d_state["step"] == 1
+    if cdn == "bf16":
+        g1 = {k: v.detach().cpu().clone() for k, v in T.generator.state_dict().items()}
+        d1 = {k: v.detach().cpu().clone() for k, v in T.discriminator.state_dict().items()}
+        g_state = _adam_state_for_oracle(T.optim_generator, [k for k, _ in T.generator.named_parameters()])
+        d_state = _adam_state_for_oracle(T.optim_discriminator, [k for k, _ in T.discriminator.named_parameters()])
+        assert g_state["step"] == 1 and d_state["step"] == 1
+    else:
+        # back to the initialisation (parameters live in the optimizers' arenas: in-place copies), AdamW moments and step to zero
+        T.generator.load_state_dict(g0)
+        T.discriminator.load_state_dict(d0)
+        for opt in (T.optim_generator, T.optim_discriminator):
+            opt.exp_avg.zero_()
+            opt.exp_avg_sq.zero_()
+            opt.step_dev.zero_()
+            opt.mark_updated()
+        g1, d1, g_state, d_state = g0, d0, {}, {}
     lr, hr, noise = batch()
     got = T.graphed_train_step(lr.to(dev), hr.to(dev), noise=[t.to(dev) for t in noise])
     torch.cuda.synchronize()
     got = {k: float(v) for k, v in got.items()}
-    named_d = [("d." + k, p.grad.detach().cpu().clone()) for k, p in T.discriminator.named_parameters()]
-    named_g = [("g." + k, p.grad.detach().cpu().clone()) for k, p in T.generator.named_parameters()]
-    ref = {}
-    want = O.train_step(g1, d1, v_sd, lr, hr, noise, g_state, d_state, grads_out=ref, q=O.Q_BF16, chunk=4)
-    for k in want:
-        e = report("cfg2_b32_graph.bf16q.%s" % k, abs(got[k] - float(want[k])) / abs(float(want[k])))
-        assert e < STEPQ_LOSS, (k, got[k], float(want[k]))
-    bad = check_grads("cfg2_b32_graph.bf16q.grad", named_d, ref, t_tensor=STEPQ_D_GRAD, t_slope=STEPQ_SLOPE, t_cos=STEPQ_COS_D, t_norm=STEP_NORM)
-    bad += check_grads("cfg2_b32_graph.bf16q.grad", named_g, ref, t_tensor=STEPQ_G_GRAD, t_slope=STEPQ_SLOPE, t_cos=STEPQ_COS_G, t_norm=STEP_NORM)
-    assert not bad, bad
+    inv = 1.0
+    if cdn == "f16":
+        scale, skipped = T.loss_scale_state()
+        assert skipped == 0, (scale, skipped)      # neither the warm-up nor the replay overflowed at the 2^20 start
+        inv = 1.0 / scale                          # the arenas hold S x gradient (AdamW divides on the device)
+    named_d = [("d." + k, p.grad.detach().cpu().clone() * inv) for k, p in T.discriminator.named_parameters()]
+    named_g = [("g." + k, p.grad.detach().cpu().clone() * inv) for k, p in T.generator.named_parameters()]
     for model in (T.generator, T.discriminator):
         for k, p in model.named_parameters():
             assert torch.isfinite(p).all(), k
+    if cdn == "bf16":
+        ref = {}
+        want = O.train_step(g1, d1, v_sd, lr, hr, noise, g_state, d_state, grads_out=ref, q=O.Q_BF16, chunk=4)
+        for k in want:
+            e = report("cfg2_b32_graph.bf16q.%s" % k, abs(got[k] - float(want[k])) / abs(float(want[k])))
+            assert e < STEPQ_LOSS, (k, got[k], float(want[k]))
+        bad = check_grads("cfg2_b32_graph.bf16q.grad", named_d, ref, t_tensor=STEPQ_D_GRAD, t_slope=STEPQ_SLOPE, t_cos=STEPQ_COS_D, t_norm=STEP_NORM)
+        bad += check_grads("cfg2_b32_graph.bf16q.grad", named_g, ref, t_tensor=STEPQ_G_GRAD, t_slope=STEPQ_SLOPE, t_cos=STEPQ_COS_G, t_norm=STEP_NORM)
+        assert not bad, bad
+        return
+    if "want" not in _B32_ORACLE:
+        ref = {}
+        _B32_ORACLE["want"] = O.train_step({k: v.clone() for k, v in g0.items()}, {k: v.clone() for k, v in d0.items()}, v_sd, lr, hr, noise,
+                                           {}, {}, grads_out=ref, chunk=4)
+        _B32_ORACLE["ref"], _B32_ORACLE["inputs"], _B32_ORACLE["g0"] = ref, (lr.clone(), noise[0].clone()), g0
+    want, ref = _B32_ORACLE["want"], _B32_ORACLE["ref"]
+    assert torch.equal(_B32_ORACLE["inputs"][0], lr) and torch.equal(_B32_ORACLE["inputs"][1], noise[0])     # both modes: the same iteration
+    assert all(torch.equal(_B32_ORACLE["g0"][k], g0[k]) for k in g0)
+    tol = B32_X3_LOSS if cdn == "x3" else CFG5_LOSS
+    for k in want:
+        e = report("cfg2_b32_graph.%s.%s" % (cdn, k), abs(got[k] - float(want[k])) / abs(float(want[k])))
+        assert e < tol, (k, got[k], float(want[k]))
+    if cdn == "x3":
+        bad = check_grads("cfg2_b32_graph.x3.grad", named_d, ref, t_tensor=B32_X3_D_GRAD, t_slope=B32_X3_SLOPE, t_cos=B32_X3_COS_D, t_norm=STEP_NORM)
+        bad += check_grads("cfg2_b32_graph.x3.grad", named_g, ref, t_tensor=B32_X3_G_GRAD, t_slope=B32_X3_SLOPE, t_cos=B32_X3_COS_G, t_norm=STEP_NORM)
+    else:
+        bad = check_grads("cfg2_b32_graph.f16.grad", named_d, ref, t_tensor=CFG5_D_GRAD, t_slope=CFG5_SLOPE, t_norm=STEP_NORM)
+        bad += check_grads("cfg2_b32_graph.f16.grad", named_g, ref, t_tensor=CFG5_G_GRAD, t_slope=CFG5_SLOPE, t_norm=STEP_NORM)
+        bad += check_grads("cfg2_b32_graph.f16.grad.all", named_d + named_g, ref, t_tensor=CFG5_G_GRAD, t_slope=CFG5_SLOPE, t_cos=CFG5_COS)
+    assert not bad, bad
 
 
 # cfg #5 (BASELINE configs[4]) train-step gates: fp16 kernels against the PLAIN fp32 oracle, ~1.5x the values measured on the
