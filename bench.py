@@ -212,7 +212,10 @@ def cpu_baseline():
         avail = len(os.sched_getaffinity(0))
     except AttributeError:
         avail = os.cpu_count() or 1
-    cores = max(1, min(avail, 32))   # oneDNN convolutions at this batch stop scaling (and thrash) far below 256 threads
+    # thread count: the fastest of a sweep on the MI355X box's host (profiles/r06_cpu_threads.txt, tools/cpu_threads.py: 16 threads
+    # 0.90 images/s, 32 0.73, 64 0.42, 128 0.16, all 256 0.012 -- oneDNN's convolutions at batch 4 thrash beyond a few dozen threads);
+    # FSR_CPU_THREADS overrides.  `cores` in the line is what was used, `host_cores` what the box has
+    cores = max(1, min(avail, int(os.environ.get("FSR_CPU_THREADS", "16"))))
     torch.set_num_threads(cores)
     with warnings.catch_warnings():
         warnings.simplefilter("ignore")
@@ -395,7 +398,6 @@ def lean_line(full):
     line["data"] = clip(line.get("data", "synthetic"), 120)
     cfg = dict(full.get("config", {}))
     prec = cfg.pop("precision", None)
-    cfg.pop("collectives", None)
     line["config"] = {k: (clip(v, 140) if isinstance(v, str) else v) for k, v in cfg.items()}
     roof = full.get("roofline") or {}
     line["roofline"] = {k: roof[k] for k in _ROOFLINE_KEYS if k in roof}

@@ -867,6 +867,13 @@ int fsr_conv_igemm_dispatch(int dtype, ConvKArgs& a, int S, hipStream_t stream) 
     if (a.query) return 0;            // (the 64-input-channel kernels read the standard pack)
     if (a.wlin) return fsr_fail(-2, "conv3x3: a stage-contiguous filter pack reached a kernel that reads the standard one");
   }
+  // EXPERIMENT switch FSR_C64T3=1 (A/B, tools/conv_bench.py): the 64-input-channel stride-1 layers on the all-DMA kernel where it has an
+  // instantiation (two 32-channel chunks per tile), before the resident-filter kernels
+  if (a.Cin == 64 && S == 1 && fsr_c64t3()) {
+    if (const int rc = fsr_conv_tall3_try(dtype, a, S, stream)) return rc < 0 ? rc : 0;
+  }
+  // 64-input-channel stride-1 layers with enough tiles: resident filter, 32x32x16 MFMA, 16 x 32-pixel tiles (conv64_v3.hip)
+  if (const int rc = fsr_conv64_v3_try(dtype, a, S, stream)) return rc < 0 ? rc : 0;
   // 64 -> 64 channel stride-1 layers: persistent kernel with the whole filter resident in LDS (conv64_persistent.hip)
   if (const int rc = fsr_conv64_persistent_try(dtype, a, S, stream)) return rc < 0 ? rc : 0;
   // 64 -> 64 channel stride-2 forward (Discriminator block 0): persistent streaming kernel (conv64_persistent.hip)

@@ -558,11 +558,14 @@ def test_dgrad_with_fused_activation_mask(dev, cdn, cin, cout, stride):
         assert relerr(_nchw(dx), want) < tol(cdn, 1e-5, 1e-2)
 
 
+@pytest.mark.parametrize("form", ["v2", "v3"])
 @pytest.mark.parametrize("cus", [1, 4, 7, 64])
-def test_persistent_conv_statistics_across_tile_ranges(dev, cus, monkeypatch):
-    """InstanceNorm statistics of the persistent 64-channel kernel when its tile ranges straddle image borders
-    (FSR_PERSIST_CUS sets the number of ranges): every image's partial slots are found and added, whatever the split."""
+def test_persistent_conv_statistics_across_tile_ranges(dev, cus, form, monkeypatch):
+    """InstanceNorm statistics of the persistent 64-channel kernels (conv64_v2: 16 x 16 tiles of 16x16x32 MFMAs; conv64_v3:
+    16 x 32 tiles of 32x32x16) when their tile ranges straddle image borders (FSR_PERSIST_CUS sets the number of ranges): every
+    image's partial slots are found and added, whatever the split."""
     monkeypatch.setenv("FSR_PERSIST_CUS", str(cus))
+    monkeypatch.setenv("FSR_C64V3", "2" if form == "v3" else "0")        # 2: force conv64_v3 whatever the tile count; 0: conv64_v2
     cd = ops.Compute("bf16")
     torch.manual_seed(11)
     n, h, w = (5, 40, 72) if _big(dev) else (3, 20, 36)
@@ -571,6 +574,7 @@ def test_persistent_conv_statistics_across_tile_ranges(dev, cus, monkeypatch):
         wt = _q(torch.randn(cout, 64, 3, 3) * 0.1, cd)
         wpk = ops.packed_filter(cd, wt.to(dev), L.PACK_FWD, 64)
         y, _, stats = ops.conv3x3_raw(cd, _nhwc(x, cd, dev), wpk, cout, want_stats=True)
+        assert ops._last_kernel().startswith("conv64_%s_kernel" % form), ops._last_kernel()
         ref = F.conv2d(x, wt, None, 1, 1)
         assert relerr(_nchw(y), ref) < 1e-2
         s = stats.cpu()
@@ -578,15 +582,19 @@ def test_persistent_conv_statistics_across_tile_ranges(dev, cus, monkeypatch):
         assert relerr(s[..., 1], (ref * ref).sum((2, 3))) < 1e-3
 
 
+@pytest.mark.parametrize("form,cdn", [("v2", "bf16"), ("v3", "bf16"), ("v3", "f16")])
 @pytest.mark.parametrize("cus", [1, 3, 256])
-@pytest.mark.parametrize("shape", [(1, 5, 7), (3, 16, 16), (2, 17, 33), (4, 8, 40)])
-def test_persistent_conv_variants_on_ragged_shapes(dev, cus, shape, monkeypatch):
-    """Every epilogue of the 64-input-channel persistent kernel (plain + bias + activation, pre-activation copy, fused
-    PixelShuffle, fused max-pool, InstanceNorm statistics, fused activation-gradient mask) on images smaller than / not a
-    multiple of the 16x16 tile, with one, a few and more tile ranges than tiles (deferred epilogue of the last tile, statistics
-    flushes in consecutive tiles, empty workgroups)."""
+@pytest.mark.parametrize("shape", [(1, 5, 7), (3, 16, 16), (2, 17, 33), (4, 8, 40), (2, 36, 70)])
+def test_persistent_conv_variants_on_ragged_shapes(dev, cus, shape, form, cdn, monkeypatch):
+    """Every epilogue of the 64-input-channel persistent kernels (plain + bias + activation, pre-activation copy, fused
+    PixelShuffle, fused max-pool, InstanceNorm statistics, fused activation-gradient mask and skip addend) on images smaller than /
+    not a multiple of the tile (conv64_v2: 16 x 16, conv64_v3: 16 x 32), with one, a few and more tile ranges than tiles (deferred
+    epilogue of the last tile, tiles of several images in one range, empty workgroups)."""
     monkeypatch.setenv("FSR_PERSIST_CUS", str(cus))
-    cd = ops.Compute("bf16")
+    monkeypatch.setenv("FSR_C64V3", "2" if form == "v3" else "0")
+    if shape == (2, 36, 70) and not _big(dev) and (form == "v2" or cus != 3):
+        pytest.skip("the multi-tile shape: one emulator case")
+    cd = ops.Compute(cdn)
     torch.manual_seed(21)
     n, h, w = shape
     x = _q(torch.randn(n, 64, h, w), cd)
@@ -598,7 +606,7 @@ def test_persistent_conv_variants_on_ragged_shapes(dev, cus, shape, monkeypatch)
         ref = F.conv2d(x, wt, bias, 1, 1)
         # plain + LeakyReLU + pre-activation copy
         y, pre, _ = ops.conv3x3_raw(cd, xd, wpk, cout, bias=bias.to(dev), act=L.ACT_LEAKY, slope=0.2, want_preact=True)
-        assert ops._last_kernel().startswith("conv64")
+        assert ops._last_kernel().startswith("conv64_%s_kernel" % form), ops._last_kernel()
         assert relerr(_nchw(pre), ref) < 1e-2 and relerr(_nchw(y), F.leaky_relu(ref, 0.2)) < 1e-2
         # statistics
         y, _, stats = ops.conv3x3_raw(cd, xd, wpk, cout, bias=bias.to(dev), want_stats=True)
@@ -609,6 +617,10 @@ def test_persistent_conv_variants_on_ragged_shapes(dev, cus, shape, monkeypatch)
         y, _, _ = ops.conv3x3_raw(cd, xd, wpk, cout, dact_mask=_nhwc(mask, cd, dev), dact_slope=0.2)
         want = F.conv2d(x, wt, None, 1, 1) * torch.where(mask > 0, torch.ones(()), torch.tensor(0.2))
         assert relerr(_nchw(y), want) < 1e-2
+        # ... and the same tensor as an ADDEND (the gradient arriving over a skip connection)
+        y, _, _ = ops.conv3x3_raw(cd, xd, wpk, cout, dact_mask=_nhwc(mask, cd, dev), dact_add=True)
+        assert ops._last_kernel().startswith("conv64_%s_kernel" % form), ops._last_kernel()
+        assert relerr(_nchw(y), F.conv2d(x, wt, None, 1, 1) + mask) < 1e-2
         # fused max-pool (even sizes only)
         if h % 2 == 0 and w % 2 == 0:
             y, _, _ = ops.conv3x3_raw(cd, xd, wpk, cout, bias=bias.to(dev), act=L.ACT_RELU, pool2=True)
@@ -617,9 +629,11 @@ def test_persistent_conv_variants_on_ragged_shapes(dev, cus, shape, monkeypatch)
     wt = _q(torch.randn(256, 64, 3, 3) * 0.1, cd)
     bias = torch.randn(256) * 0.1
     wpk = ops.packed_filter(cd, wt.to(dev), L.PACK_FWD_PS, 64)
-    y, _, _ = ops.conv3x3_raw(cd, xd, wpk, 256, bias=bias.to(dev), pixel_shuffle=True, act=L.ACT_PRELU, prelu=torch.tensor([0.25]).to(dev))
-    want = F.prelu(F.pixel_shuffle(F.conv2d(x, wt, bias, 1, 1), 2), torch.tensor([0.25]))
-    assert relerr(_nchw(y), want) < 1e-2
+    y, pre, _ = ops.conv3x3_raw(cd, xd, wpk, 256, bias=bias.to(dev), pixel_shuffle=True, act=L.ACT_PRELU, prelu=torch.tensor([-0.25]).to(dev),
+                                want_preact=True)
+    assert ops._last_kernel().startswith("conv64_%s_kernel" % form), ops._last_kernel()
+    shuffled = F.pixel_shuffle(F.conv2d(x, wt, bias, 1, 1), 2)
+    assert relerr(_nchw(y), F.prelu(shuffled, torch.tensor([-0.25]))) < 1e-2 and relerr(_nchw(pre), shuffled) < 1e-2
 
 
 @pytest.mark.parametrize("cus", [1, 5, 256])
