@@ -110,19 +110,23 @@ __device__ __forceinline__ V t3_lds_read(const char* smem, unsigned off) {
 
 // X3 (FSR_X3, T = bf16_t): the input is an x3 tensor seen as a bf16 tensor of a.Cin = 2 x logical channels whose
 // 32-channel chunks alternate hi / lo, the filter pack alternates w_hi / w_lo chunks the same way.  The kernel then walks
-// THREE virtual chunks per logical 32-channel group -- (x_hi, w_hi), (x_lo, w_hi), (x_hi, w_lo) -- through the unchanged
-// pipeline: only the source offsets of the DMA pieces are mapped (t3_hmap / t3_fmap), so the x_hi halo chunk is fetched
-// twice (from L2), and the epilogue stores / reads x3 elements (hi and lo 64 bytes apart, fsr_common.h).
+// THREE virtual chunks per logical 32-channel group through the unchanged pipeline: only the source offsets of the DMA pieces
+// are mapped (t3_hmap / t3_fmap), and the epilogue stores / reads x3 elements (hi and lo 64 bytes apart, fsr_common.h).
+// Order: stride 2 -- (x_hi, w_hi), (x_lo, w_hi), (x_hi, w_lo), every chunk fetching its halo; stride 1 (REUSE below) --
+// (x_hi, w_hi), (x_hi, w_lo), (x_lo, w_hi), the x_hi halo fetched ONCE.
 __device__ __forceinline__ int t3_div3(int j) { return (int)(((unsigned)j * 0xAAABu) >> 17); }     // j < 2^15
-template <bool X3> __device__ __forceinline__ int t3_hmap(int j) {      // physical input chunk of virtual chunk j
+// REUSE (x3, stride 1; round 6): the virtual chunks of a group are walked (x_hi, w_hi), (x_hi, w_lo), (x_lo, w_hi), and the second one
+// reads the x_hi halo the first one brought in -- no second DMA of it.  Halo chunks then no longer alternate buffers by chunk
+// parity: chunks 0 and 1 of a group live in buffer 0, chunk 2 in buffer 1 (every tile has a multiple of three chunks).
+template <bool X3, bool REUSE = false> __device__ __forceinline__ int t3_hmap(int j) {      // physical input chunk of virtual chunk j
   if constexpr (!X3) return j;
   const int g = t3_div3(j), r = j - 3 * g;
-  return __builtin_amdgcn_readfirstlane(2 * g + (r == 1 ? 1 : 0));      // (wave-uniform: the DMA's scalar offset operand)
+  return __builtin_amdgcn_readfirstlane(2 * g + (r == (REUSE ? 2 : 1) ? 1 : 0));      // (wave-uniform: the DMA's scalar offset operand)
 }
-template <bool X3> __device__ __forceinline__ int t3_fmap(int j) {      // physical filter chunk of virtual chunk j
+template <bool X3, bool REUSE = false> __device__ __forceinline__ int t3_fmap(int j) {      // physical filter chunk of virtual chunk j
   if constexpr (!X3) return j;
   const int g = t3_div3(j), r = j - 3 * g;
-  return __builtin_amdgcn_readfirstlane(2 * g + (r == 2 ? 1 : 0));
+  return __builtin_amdgcn_readfirstlane(2 * g + (r == (REUSE ? 1 : 2) ? 1 : 0));
 }
 
 // PSM (x3 only; round 6: a TEMPLATE parameter -- as run-time flags of the shared body these paths cost every plain instantiation
@@ -134,6 +138,7 @@ __global__ __launch_bounds__(NW * 64, 2) void conv_tall3_kernel(const ConvKArgs 
   static_assert(!X3 || std::is_same<T, bf16_t>::value, "x3: bf16 planes");
   static_assert(PSM == 0 || (X3 && S == 1 && !STATS && (NA == 2 || PSM == 1)), "depth-to-space forms: x3, stride 1, no statistics; the store form on the 128-channel block");
   constexpr bool IN_PS = PSM == 1, UP = PSM == 2;
+  constexpr bool REUSE = X3 && S == 1;      // the x_hi halo of a group is fetched once (t3_hmap)
   typedef typename std::conditional<X3, x3_t, T>::type ST;    // storage type of the output-side tensors
   // a wave owns 32 * MB pixels x 32 * NA channels; two waves per SIMD (256 registers each), from two workgroups.  (The
   // 128 x 128 wave tile with 256 accumulators in AGPRs and ONE 512-register wave per SIMD was built and measured in round 3 --
@@ -263,7 +268,7 @@ __global__ __launch_bounds__(NW * 64, 2) void conv_tall3_kernel(const ConvKArgs 
   // byte offset (wave-uniform) of virtual chunk c inside a pixel's channels; depth-to-space input: the chunk lies in quadrant
   // q = chunk >> t3_ps_shift of the 2 x 2 block: + (q >> 1) rows and (q & 1) columns of Cin / 4 channels
   auto hsoff = [&](int c) -> unsigned {
-    const int p = t3_hmap<X3>(c);
+    const int p = t3_hmap<X3, REUSE>(c);
     if constexpr (!IN_PS) return (unsigned)(p * 64);
     else {
       const int q = p >> a.t3_ps_shift, cq = p - (q << a.t3_ps_shift);
@@ -284,7 +289,7 @@ __global__ __launch_bounds__(NW * 64, 2) void conv_tall3_kernel(const ConvKArgs 
   // filter pieces of the tap at position `pos` of chunk c's stages (stride 1: the tap itself; stride 2: T3_S2_TAP[pos])
   auto dma_filter = [&](unsigned ws, int c, unsigned woff_tap, int k, unsigned slot_tap_off) {
     if constexpr (!(T3_ABL & 2))
-      FSR_BLDS16(w_buf, wvoff[k], woff_tap + ws + (unsigned)t3_fmap<X3>(c) * wcs, ring_addr + (fsr_lds_addr_t)(slot_tap_off + (wave + k * NW) * 1024));
+      FSR_BLDS16(w_buf, wvoff[k], woff_tap + ws + (unsigned)(t3_fmap<X3, REUSE>(c)) * wcs, ring_addr + (fsr_lds_addr_t)(slot_tap_off + (wave + k * NW) * 1024));
   };
   // The bias of a tile's channel block comes by DMA as well (one piece of BN floats, wave 0, double buffered by tile parity):
   // an ordinary global load next to the epilogue's stores would make hipcc drain vmcnt -- the whole DMA pipeline -- per tile.
@@ -363,6 +368,12 @@ __global__ __launch_bounds__(NW * 64, 2) void conv_tall3_kernel(const ConvKArgs 
   // ---- prologue of the workgroup's first tile: bias, halo chunk 0, the first D stages ------------------------------------
   setup(logical(tile), cur, hv_cur, ws_cur);
   int gc = 0;                      // global chunk counter of this workgroup (halo buffer = gc & 1, ring slot = (gc + si) % NSLOT)
+  int r3 = 0;                      // REUSE: position of the chunk in its group of three (halo buffer = r3 == 2)
+  // halo buffer of the chunk `d` (0 or 1) chunks after the current one
+  auto hbuf = [&](int d) -> unsigned {
+    if constexpr (REUSE) return (unsigned)((r3 + d == 2 || r3 + d == 5) ? 1 : 0);
+    else return (unsigned)((gc + d) & 1);
+  };
   unsigned tpar = 0;               // tile parity (bias buffer)
   dma_bias(cur.nb, tpar);
   if constexpr (S == 2) {
@@ -395,7 +406,7 @@ __global__ __launch_bounds__(NW * 64, 2) void conv_tall3_kernel(const ConvKArgs 
   bool full_prev = true;           // stride 2: did the preceding stage issue its complete static set of pieces
 
   for (;;) {
-    for (int c = 0; c < ((T3_ABL & 4) ? 0 : nchunks); ++c, ++gc) {
+    for (int c = 0; c < ((T3_ABL & 4) ? 0 : nchunks); ++c, ++gc, r3 = (r3 == 2 ? 0 : r3 + 1)) {
       const bool last = c + 1 == nchunks;
       if (last && has_nxt) {         // from here on the DMA feeds the next tile
         setup(logical(next), nxt, hv_nxt, ws_nxt);
@@ -404,7 +415,7 @@ __global__ __launch_bounds__(NW * 64, 2) void conv_tall3_kernel(const ConvKArgs 
       static_for<0, SPC>([&](auto sic) {
         constexpr int si = decltype(sic)::value;
         const unsigned sl = slot_of(gc, si);
-        const unsigned hb = S == 2 ? 0u : (unsigned)((gc & 1) * T3_HALO_BYTES);
+        const unsigned hb = S == 2 ? 0u : hbuf(0) * (unsigned)T3_HALO_BYTES;
         // the stage whose pieces this stage issues: D stages ahead, possibly in the next tile
         constexpr int siD = (si + D) % SPC, dcD = (si + D) / SPC;
         const bool crossD = c + dcD >= nchunks;
@@ -416,7 +427,7 @@ __global__ __launch_bounds__(NW * 64, 2) void conv_tall3_kernel(const ConvKArgs 
         constexpr int siN = (si + 1) % SPC, dcN = (si + 1) / SPC;
         const bool has_next_stage = (c + dcN < nchunks) || has_nxt;
         const unsigned slN = slot_of(gc + dcN, siN);
-        const unsigned hbN = S == 2 ? 0u : (unsigned)(((gc + dcN) & 1) * T3_HALO_BYTES);
+        const unsigned hbN = S == 2 ? 0u : hbuf(dcN) * (unsigned)T3_HALO_BYTES;
         // stride 2: this stage's pieces are its FP filter pieces + one halo piece (+ a second one in stages 4, 5), all issued
         // in its first substep; the set is complete when the filter stage ahead exists and (stages 4..8) a next chunk does
         const bool full_this = S == 2 ? (issue && (si < 4 || !last || has_nxt)) : true;
@@ -482,8 +493,10 @@ __global__ __launch_bounds__(NW * 64, 2) void conv_tall3_kernel(const ConvKArgs 
               }
             } else if constexpr (q == 0 && i >= 1 && i <= HPS && si * HPS + (i - 1) < HPW) {
               constexpr int hk = si * HPS + (i - 1);
-              if (!last) dma_halo(hv_cur, c + 1, hk, (unsigned)((gc + 1) & 1));
-              else if (has_nxt) dma_halo(hv_nxt, 0, hk, (unsigned)((gc + 1) & 1));
+              // (REUSE: the chunk after position 0 reads the halo already there)
+              if (!last) {
+                if (!REUSE || r3 != 0) dma_halo(hv_cur, c + 1, hk, hbuf(1));
+              } else if (has_nxt) dma_halo(hv_nxt, 0, hk, hbuf(1));
             }
             if constexpr (q < G && i >= NM - FP) {
               if (issue) dma_filter(wsD, cD, a.t3_woff[t3_tap_at<S>(siD * G + q)], i - (NM - FP), slD + q * BN * 64);
