@@ -41,7 +41,15 @@
 
 #include <stdlib.h>
 
+// Ablation builds (-DFSR_ABLV3=<mask>; results WRONG on purpose, the product library is built with 0):
+//   1 no output stores   2 no halo DMA after the prologue   4 no MFMAs   8 no epilogue at all   16 no vmcnt wait before the barriers
+#ifndef FSR_ABLV3
+#define FSR_ABLV3 0
+#endif
+
 namespace {
+
+constexpr int V3_ABL = FSR_ABLV3;
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
@@ -276,8 +284,13 @@ __global__ __launch_bounds__(512) void conv64_v3_kernel(const ConvKArgs a) {
             p0[e] = pack2<T>(v[2 * e], v[2 * e + 1]);
             p1[e] = pack2<T>(v[8 + 2 * e], v[8 + 2 * e + 1]);
           }
-          fsr_st<2>((u32x4*)p, (u32x4)(p0));
-          fsr_st<2>((u32x4*)(p + 8), (u32x4)(p1));
+          if constexpr (!(V3_ABL & 1)) {
+            fsr_st<2>((u32x4*)p, (u32x4)(p0));
+            fsr_st<2>((u32x4*)(p + 8), (u32x4)(p1));
+          } else if (a.GW < 0) {          // (never true: keeps the values alive)
+            fsr_st<2>((u32x4*)p, (u32x4)(p0));
+            fsr_st<2>((u32x4*)(p + 8), (u32x4)(p1));
+          }
         };
         if (pool2) {
           // MaxPool2d(2,2) fused: rows (gy, gy ^ 1) sit in lanes (l, l ^ 16), columns in (l, l ^ 1); the activation is monotonic
@@ -358,13 +371,14 @@ __global__ __launch_bounds__(512) void conv64_v3_kernel(const ConvKArgs a) {
         if constexpr (s == 17) {
           // publish the next chunk's halo: this wave's pieces have landed, then everybody's; the barrier also retires the reads of
           // this chunk's buffer (the last substep's fragments are in registers), which the DMA of the next chunk overwrites
-          FSR_WAIT_VM(0);
+          if constexpr (!(V3_ABL & 16)) FSR_WAIT_VM(0);
           FSR_BARRIER();
         }
         static_for<0, 4>([&](auto ic) {
           constexpr int i = decltype(ic)::value;
           constexpr int n = i >> 1, m = i & 1;
-          acc[n][m] = Mfma32v<T>::run(fa[buf][n], fb[buf][m], acc[n][m]);
+          if constexpr (!(V3_ABL & 4)) acc[n][m] = Mfma32v<T>::run(fa[buf][n], fb[buf][m], acc[n][m]);
+          else if (a.GW < 0) acc[n][m] = Mfma32v<T>::run(fa[buf][n], fb[buf][m], acc[n][m]);
           // fragment i of the NEXT substep, into the other register set
           if constexpr (s + 1 < 18) {
             read_frag(ic, std::integral_constant<int, buf ^ 1>{}, cc, std::integral_constant<int, s + 1>{});
@@ -374,7 +388,7 @@ __global__ __launch_bounds__(512) void conv64_v3_kernel(const ConvKArgs a) {
             if (has_nxt) read_frag(ic, std::integral_constant<int, buf ^ 1>{}, std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{});
           }
           // the halo pieces of the next chunk, one per substep (substeps 1 .. 5), after the substep's second MFMA
-          if constexpr (i == 1 && s >= 1 && s <= V3_HPW) {
+          if constexpr (i == 1 && s >= 1 && s <= V3_HPW && !(V3_ABL & 2)) {
             if constexpr (c == 0) dma_halo(hv_cur, 1, s - 1);
             else {
               if (has_nxt) dma_halo(hv_nxt, 0, s - 1);
@@ -384,7 +398,7 @@ __global__ __launch_bounds__(512) void conv64_v3_kernel(const ConvKArgs a) {
         });
         // the previous tile's epilogue, inside this tile's first chunk: waves 0-3 early, their SIMD partners (waves 4-7) later
         if constexpr (c == 0 && (s == 3 || s == 11)) {
-          if (have_prev && ch == (s == 3 ? 0 : 1)) ep_finish();
+          if (have_prev && ch == (s == 3 ? 0 : 1) && (!(V3_ABL & 8) || a.GW < 0)) ep_finish();
         }
       });
     });

@@ -21,8 +21,9 @@ BF16Q_OUT, BF16Q_LOGITS, BF16Q_GRAD, BF16Q_SLOPE, BF16Q_COS = 1e-2, 6e-2, 0.6, 0
 BF16_OUT, BF16_GRAD, BF16_SCALAR, BF16_COS = 3e-2, 1.0, 1.0, 0.9
 # fp16 (the default 16-bit mode) against the plain fp32 oracle / the f32 mode; set ~2x the values measured on the MI355X
 # (profiles/r06_parity_errors.log)
-F16_OUT, F16_GRAD, F16_SCALAR, F16_COS = 4e-3, 0.6, 0.6, 0.95
-F16_KAT_MEAN, F16_KAT_MAX = 1e-3, 1.2e-2
+# measured: SR 1.3e-3, logits 4.3e-3, tensors <= 0.20, slopes <= 0.28, cosine 0.9932; shipped weights: mean |error| 3.6e-4, max 5.3e-3
+F16_OUT, F16_GRAD, F16_SCALAR, F16_COS = 4e-3, 0.4, 0.5, 0.985
+F16_KAT_MEAN, F16_KAT_MAX = 8e-4, 1.1e-2
 
 
 @pytest.fixture(params=BACKENDS)

@@ -256,7 +256,9 @@ _B32_ORACLE = {}      # the plain fp32 oracle's evaluation of the benched-batch 
 # minutes of CPU).  x3: the four losses at north_star's 1e-3; gradients as relative L2 per tensor / cosine per network, ~2x the
 # values measured on the MI355X (profiles/r06_parity_errors.log) -- the float32 oracle itself sits 0.2 % (D) / 9 % (G) from
 # float64 at cfg #1, so these bound kernel bugs (ratios of tens), not the last bit.  f16: the cfg #5 gates.
-B32_X3_LOSS, B32_X3_D_GRAD, B32_X3_G_GRAD, B32_X3_COS_D, B32_X3_COS_G, B32_X3_SLOPE = 1e-3, 0.06, 0.35, 0.998, 0.95, 0.2
+# Measured (profiles/r06_parity_errors.log): x3 losses 9e-8 .. 3.3e-6; D tensors 0.7-1.9 %, cosine 0.999994; G tensors <= 12.5 %, cosine
+# 0.9963 (the float32 oracle itself sits 9 % from float64 on G); PReLU slopes <= 0.45 % of the largest slope gradient.
+B32_X3_LOSS, B32_X3_D_GRAD, B32_X3_G_GRAD, B32_X3_COS_D, B32_X3_COS_G, B32_X3_SLOPE = 1e-3, 0.04, 0.25, 0.9999, 0.99, 0.02
 
 
 @pytest.mark.parametrize("cdn", ["x3", "f16", "bf16"])
@@ -267,9 +269,11 @@ def test_graph_replayed_iteration_at_the_benched_batch(pkg, cdn):
     graph) and bf16 -- against the oracle (trainer.py:171-196) evaluated in slices of 4 samples (O.train_step(chunk=4), the same
     iteration: tests/test_oracle.py).  One eager iteration warms the buffers; the replay then runs on a NEW batch, so it
     demonstrably reads the graph's static inputs.
-      bf16: the oracle with the bf16 storage model, from the weights the warm-up iteration left (off their initialisation);
-      x3, f16: the PLAIN fp32 oracle -- one evaluation shared by both: weights and AdamW moments are put back to the
-               initialisation after the capture, so both modes replay the same iteration from the same start."""
+    All three are held to the PLAIN fp32 oracle -- ONE evaluation (a minute and a half of CPU) shared by the three cases: weights
+    and AdamW moments are put back to the initialisation after the capture, so every mode replays the same iteration from the
+    same start.  x3: north_star's 1e-3 on the losses; f16: the cfg #5 gates; bf16: its plain-fp32 gates of the cfg #1 test.
+    (Rounds 4-5 held bf16 to the bf16-STORAGE oracle here, a second 130 s evaluation; that comparison stays at cfg #1 size,
+    test_train_step_at_baseline_cfg1_size[bf16].)"""
     dev = select("hip")
     torch.manual_seed(9)
     B = 32
@@ -290,22 +294,16 @@ def test_graph_replayed_iteration_at_the_benched_batch(pkg, cdn):
     T.capture_train_step(lr0.to(dev), hr0.to(dev), warmup=1, noise=[t.to(dev) for t in n0])
     torch.cuda.synchronize()
     assert len(T._graphs) == 1
-    if cdn == "bf16":
-        g1 = {k: v.detach().cpu().clone() for k, v in T.generator.state_dict().items()}
-        d1 = {k: v.detach().cpu().clone() for k, v in T.discriminator.state_dict().items()}
-        g_state = _adam_state_for_oracle(T.optim_generator, [k for k, _ in T.generator.named_parameters()])
-        d_state = _adam_state_for_oracle(T.optim_discriminator, [k for k, _ in T.discriminator.named_parameters()])
-        assert g_state["step"] == 1 and d_state["step"] == 1
-    else:
-        # back to the initialisation (parameters live in the optimizers' arenas: in-place copies), AdamW moments and step to zero
-        T.generator.load_state_dict(g0)
-        T.discriminator.load_state_dict(d0)
-        for opt in (T.optim_generator, T.optim_discriminator):
-            opt.exp_avg.zero_()
-            opt.exp_avg_sq.zero_()
-            opt.step_dev.zero_()
-            opt.mark_updated()
-        g1, d1, g_state, d_state = g0, d0, {}, {}
+    g_state = _adam_state_for_oracle(T.optim_generator, [k for k, _ in T.generator.named_parameters()])
+    assert g_state["step"] == 1 and float(g_state[("v", "neck.0.weight")].abs().sum()) > 0      # the warm-up iteration did update
+    # back to the initialisation (parameters live in the optimizers' arenas: in-place copies), AdamW moments and step to zero
+    T.generator.load_state_dict(g0)
+    T.discriminator.load_state_dict(d0)
+    for opt in (T.optim_generator, T.optim_discriminator):
+        opt.exp_avg.zero_()
+        opt.exp_avg_sq.zero_()
+        opt.step_dev.zero_()
+        opt.mark_updated()
     lr, hr, noise = batch()
     got = T.graphed_train_step(lr.to(dev), hr.to(dev), noise=[t.to(dev) for t in noise])
     torch.cuda.synchronize()
@@ -320,16 +318,6 @@ def test_graph_replayed_iteration_at_the_benched_batch(pkg, cdn):
     for model in (T.generator, T.discriminator):
         for k, p in model.named_parameters():
             assert torch.isfinite(p).all(), k
-    if cdn == "bf16":
-        ref = {}
-        want = O.train_step(g1, d1, v_sd, lr, hr, noise, g_state, d_state, grads_out=ref, q=O.Q_BF16, chunk=4)
-        for k in want:
-            e = report("cfg2_b32_graph.bf16q.%s" % k, abs(got[k] - float(want[k])) / abs(float(want[k])))
-            assert e < STEPQ_LOSS, (k, got[k], float(want[k]))
-        bad = check_grads("cfg2_b32_graph.bf16q.grad", named_d, ref, t_tensor=STEPQ_D_GRAD, t_slope=STEPQ_SLOPE, t_cos=STEPQ_COS_D, t_norm=STEP_NORM)
-        bad += check_grads("cfg2_b32_graph.bf16q.grad", named_g, ref, t_tensor=STEPQ_G_GRAD, t_slope=STEPQ_SLOPE, t_cos=STEPQ_COS_G, t_norm=STEP_NORM)
-        assert not bad, bad
-        return
     if "want" not in _B32_ORACLE:
         ref = {}
         _B32_ORACLE["want"] = O.train_step({k: v.clone() for k, v in g0.items()}, {k: v.clone() for k, v in d0.items()}, v_sd, lr, hr, noise,
@@ -338,13 +326,17 @@ def test_graph_replayed_iteration_at_the_benched_batch(pkg, cdn):
     want, ref = _B32_ORACLE["want"], _B32_ORACLE["ref"]
     assert torch.equal(_B32_ORACLE["inputs"][0], lr) and torch.equal(_B32_ORACLE["inputs"][1], noise[0])     # both modes: the same iteration
     assert all(torch.equal(_B32_ORACLE["g0"][k], g0[k]) for k in g0)
-    tol = B32_X3_LOSS if cdn == "x3" else CFG5_LOSS
+    tol = {"x3": B32_X3_LOSS, "f16": CFG5_LOSS, "bf16": STEP_BF16_LOSS}[cdn]
     for k in want:
         e = report("cfg2_b32_graph.%s.%s" % (cdn, k), abs(got[k] - float(want[k])) / abs(float(want[k])))
         assert e < tol, (k, got[k], float(want[k]))
     if cdn == "x3":
         bad = check_grads("cfg2_b32_graph.x3.grad", named_d, ref, t_tensor=B32_X3_D_GRAD, t_slope=B32_X3_SLOPE, t_cos=B32_X3_COS_D, t_norm=STEP_NORM)
         bad += check_grads("cfg2_b32_graph.x3.grad", named_g, ref, t_tensor=B32_X3_G_GRAD, t_slope=B32_X3_SLOPE, t_cos=B32_X3_COS_G, t_norm=STEP_NORM)
+    elif cdn == "bf16":
+        bad = check_grads("cfg2_b32_graph.bf16.grad", named_d, ref, t_tensor=STEP_BF16_D_GRAD, t_slope=STEP_BF16_SLOPE, t_norm=STEP_NORM)
+        bad += check_grads("cfg2_b32_graph.bf16.grad", named_g, ref, t_tensor=STEP_BF16_G_GRAD, t_slope=STEP_BF16_SLOPE, t_norm=STEP_NORM)
+        bad += check_grads("cfg2_b32_graph.bf16.grad.all", named_d + named_g, ref, t_tensor=STEP_BF16_G_GRAD, t_slope=STEP_BF16_SLOPE_ALL, t_cos=STEP_BF16_COS)
     else:
         bad = check_grads("cfg2_b32_graph.f16.grad", named_d, ref, t_tensor=CFG5_D_GRAD, t_slope=CFG5_SLOPE, t_norm=STEP_NORM)
         bad += check_grads("cfg2_b32_graph.f16.grad", named_g, ref, t_tensor=CFG5_G_GRAD, t_slope=CFG5_SLOPE, t_norm=STEP_NORM)
