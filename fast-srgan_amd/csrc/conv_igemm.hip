@@ -855,6 +855,10 @@ int fsr_conv_igemm_dispatch_classes(int dtype, ConvKArgs* cls, int n, hipStream_
   return fsr_fail(-2, "conv3x3: unknown dtype %d", dtype);
 }
 
+#ifdef FSR_EXPERIMENT_C64V3
+int fsr_conv64_v3_try(int dtype, ConvKArgs& a, int S, hipStream_t stream);      // tools/experiments/conv64_v3.hip
+#endif
+
 int fsr_conv_igemm_dispatch(int dtype, ConvKArgs& a, int S, hipStream_t stream) {
   if (dtype == FSR_X3) {
     // 64 and more logical input channels, stride 1: the all-DMA 32x32x16 kernel on three virtual chunks per channel group (conv_tall3.hip)
@@ -867,13 +871,13 @@ int fsr_conv_igemm_dispatch(int dtype, ConvKArgs& a, int S, hipStream_t stream) 
     if (a.query) return 0;            // (the 64-input-channel kernels read the standard pack)
     if (a.wlin) return fsr_fail(-2, "conv3x3: a stage-contiguous filter pack reached a kernel that reads the standard one");
   }
-  // EXPERIMENT switch FSR_C64T3=1 (A/B, tools/conv_bench.py): the 64-input-channel stride-1 layers on the all-DMA kernel where it has an
-  // instantiation (two 32-channel chunks per tile), before the resident-filter kernels
-  if (a.Cin == 64 && S == 1 && fsr_c64t3()) {
-    if (const int rc = fsr_conv_tall3_try(dtype, a, S, stream)) return rc < 0 ? rc : 0;
-  }
-  // 64-input-channel stride-1 layers with enough tiles: resident filter, 32x32x16 MFMA, 16 x 32-pixel tiles (conv64_v3.hip)
+  // (Round 6 measured two alternatives for the 64-input-channel stride-1 layers and kept conv64_v2: the all-DMA kernel on two
+  // 32-channel chunks per tile -- VGG 64->64 457 us against 412 -- and a resident-filter kernel on 32x32x16 MFMAs with 16 x 32-pixel
+  // tiles, tools/experiments/conv64_v3.hip -- 406 against 412, 64->128 236 against 214; profiles/r06_conv64_v2_v3_t3.txt,
+  // profiles/r06_conv64_v3_ablation.txt.)
+#ifdef FSR_EXPERIMENT_C64V3   // tools/experiments/build_v3_variants.sh only: never defined for the product library
   if (const int rc = fsr_conv64_v3_try(dtype, a, S, stream)) return rc < 0 ? rc : 0;
+#endif
   // 64 -> 64 channel stride-1 layers: persistent kernel with the whole filter resident in LDS (conv64_persistent.hip)
   if (const int rc = fsr_conv64_persistent_try(dtype, a, S, stream)) return rc < 0 ? rc : 0;
   // 64 -> 64 channel stride-2 forward (Discriminator block 0): persistent streaming kernel (conv64_persistent.hip)

@@ -14,11 +14,6 @@ int fsr_t3_run_f16(ConvKArgs& b, bool narrow, int mb, int S, hipStream_t stream)
 int fsr_t3_run_x3_narrow(ConvKArgs& b, int mb, int S, bool g3, hipStream_t stream);
 int fsr_t3_run_x3_wide(ConvKArgs& b, int mb, int S, bool up_form, hipStream_t stream);
 
-bool fsr_c64t3() {      // FSR_C64T3=1: 16-bit 64-input-channel layers may take this kernel (experiment; read per call)
-  const char* e = getenv("FSR_C64T3");
-  return e && atoi(e) != 0;
-}
-
 int fsr_t3_cus() {
   // FSR_PERSIST_CUS=<n> (tests): number of CUs the persistent walk is sized for -- few, so that every workgroup walks several
   // tiles and the DMA stream runs on across tile boundaries.  Read per launch (the tests change it between launches).
@@ -44,7 +39,7 @@ int fsr_conv_tall3_try(int dtype, ConvKArgs& a, int S, hipStream_t stream) {
 #ifdef FSR_NO_T3S2     // A/B builds (tools/build_variant.sh): stride-2 forwards stay on conv_igemm.hip
   if (S == 2) return 0;
 #endif
-  if (a.Cin < (fsr_c64t3() ? 64 : 128) || a.Cin % 32 != 0 || a.Cout % 64 != 0 || a.CoutPad != a.Cout) return 0;
+  if (a.Cin < 128 || a.Cin % 32 != 0 || a.Cout % 64 != 0 || a.CoutPad != a.Cout) return 0;
   // Cout = 64 (the data gradient of a 64 -> 128 layer): 64-channel blocks, a wave = 32 MB pixels x 32 channels (one filter
   // fragment, 5 reads per 4 MFMAs)
   const bool narrow = a.Cout % 128 != 0;

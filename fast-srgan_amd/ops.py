@@ -304,8 +304,8 @@ USE_LIN_PACK = os.environ.get("FSR_PACK_LIN", "1") != "0"   # A/B switch: 0 = ev
 # that kernel off (FSR_S2D3=0) switches the bits off with it instead of leaving a mask no kernel takes
 USE_SIGN_BITS = os.environ.get("FSR_SIGN_BITS", "1") != "0" and os.environ.get("FSR_S2D3", "1") != "0"
 _pack_block_memo = {}     # (descriptor fields, optional-tensor mask) -> block size: the dispatch is deterministic per shape
-_DISPATCH_ENV = ("FSR_PERSIST_CUS", "FSR_T3_ROWS", "FSR_S2D3", "FSR_T3N_G3", "FSR_CONV_STAGE", "FSR_CONV64_S2FWD", "FSR_PACK_LIN",
-                 "FSR_C64T3", "FSR_C64V3")   # every switch the conv dispatch reads (csrc: getenv) + the Python-side ones
+_DISPATCH_ENV = ("FSR_PERSIST_CUS", "FSR_T3_ROWS", "FSR_S2D3", "FSR_T3N_G3", "FSR_CONV_STAGE", "FSR_CONV64_S2FWD",
+                 "FSR_PACK_LIN")   # every switch the conv dispatch reads (csrc: getenv) + the Python-side ones
 USE_POOL_ARGMAX = os.environ.get("FSR_POOL_ARGMAX", "1") != "0"   # A/B switch: 0 = the pool backward re-reads its input and output
 USE_C3_KERNELS = True   # tests flip this to compare the first-layer kernels with the padded-tensor path
 

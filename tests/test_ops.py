@@ -558,14 +558,12 @@ def test_dgrad_with_fused_activation_mask(dev, cdn, cin, cout, stride):
         assert relerr(_nchw(dx), want) < tol(cdn, 1e-5, 1e-2)
 
 
-@pytest.mark.parametrize("form", ["v2", "v3"])
 @pytest.mark.parametrize("cus", [1, 4, 7, 64])
-def test_persistent_conv_statistics_across_tile_ranges(dev, cus, form, monkeypatch):
-    """InstanceNorm statistics of the persistent 64-channel kernels (conv64_v2: 16 x 16 tiles of 16x16x32 MFMAs; conv64_v3:
-    16 x 32 tiles of 32x32x16) when their tile ranges straddle image borders (FSR_PERSIST_CUS sets the number of ranges): every
-    image's partial slots are found and added, whatever the split."""
+def test_persistent_conv_statistics_across_tile_ranges(dev, cus, monkeypatch):
+    """InstanceNorm statistics of the persistent 64-channel kernel when its tile ranges straddle image borders
+    (FSR_PERSIST_CUS sets the number of ranges): every image's partial slots are found and added, whatever the split."""
     monkeypatch.setenv("FSR_PERSIST_CUS", str(cus))
-    monkeypatch.setenv("FSR_C64V3", "2" if form == "v3" else "0")        # 2: force conv64_v3 whatever the tile count; 0: conv64_v2
+    form = "v2"
     cd = ops.Compute("bf16")
     torch.manual_seed(11)
     n, h, w = (5, 40, 72) if _big(dev) else (3, 20, 36)
@@ -582,18 +580,18 @@ def test_persistent_conv_statistics_across_tile_ranges(dev, cus, form, monkeypat
         assert relerr(s[..., 1], (ref * ref).sum((2, 3))) < 1e-3
 
 
-@pytest.mark.parametrize("form,cdn", [("v2", "bf16"), ("v3", "bf16"), ("v3", "f16")])
+@pytest.mark.parametrize("cdn", ["bf16", "f16"])
 @pytest.mark.parametrize("cus", [1, 3, 256])
-@pytest.mark.parametrize("shape", [(1, 5, 7), (3, 16, 16), (2, 17, 33), (4, 8, 40), (2, 36, 70)])
-def test_persistent_conv_variants_on_ragged_shapes(dev, cus, shape, form, cdn, monkeypatch):
-    """Every epilogue of the 64-input-channel persistent kernels (plain + bias + activation, pre-activation copy, fused
-    PixelShuffle, fused max-pool, InstanceNorm statistics, fused activation-gradient mask and skip addend) on images smaller than /
-    not a multiple of the tile (conv64_v2: 16 x 16, conv64_v3: 16 x 32), with one, a few and more tile ranges than tiles (deferred
-    epilogue of the last tile, tiles of several images in one range, empty workgroups)."""
+@pytest.mark.parametrize("shape", [(1, 5, 7), (3, 16, 16), (2, 17, 33), (4, 8, 40)])
+def test_persistent_conv_variants_on_ragged_shapes(dev, cus, shape, cdn, monkeypatch):
+    """Every epilogue of the 64-input-channel persistent kernel (plain + bias + activation, pre-activation copy, fused
+    PixelShuffle (+ its pre-activation copy), fused max-pool, InstanceNorm statistics, fused activation-gradient mask and skip
+    addend) on images smaller than / not a multiple of the 16x16 tile, with one, a few and more tile ranges than tiles (deferred
+    epilogue of the last tile, statistics flushes in consecutive tiles, empty workgroups)."""
     monkeypatch.setenv("FSR_PERSIST_CUS", str(cus))
-    monkeypatch.setenv("FSR_C64V3", "2" if form == "v3" else "0")
-    if shape == (2, 36, 70) and not _big(dev) and (form == "v2" or cus != 3):
-        pytest.skip("the multi-tile shape: one emulator case")
+    if cdn == "f16" and not _big(dev) and cus != 3:
+        pytest.skip("fp16: one emulator case per shape")
+    form = "v2"
     cd = ops.Compute(cdn)
     torch.manual_seed(21)
     n, h, w = shape

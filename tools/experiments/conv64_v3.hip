@@ -217,9 +217,12 @@ __global__ __launch_bounds__(512) void conv64_v3_kernel(const ConvKArgs a) {
   T* outp = (T*)a.out;
   T* prep = (T*)a.preact;
   const T* maskp = MASK ? (const T*)a.dmask : nullptr;
-  auto ep_finish = [&]() __attribute__((always_inline)) {
+  // partc: -1 = the whole epilogue; 0 .. 3 = the statistics (part 0 only) and fragment (n, m) = (part >> 1, part & 1) alone
+  // (-DFSR_V3_SPREAD: the four fragments are stored two substeps apart instead of in one burst)
+  auto ep_part = [&](auto partc) __attribute__((always_inline)) {
+    constexpr int PART = decltype(partc)::value;
     const int gx = e_tc.gx0 + ch * 16 + l15;
-    if constexpr (STATS) {
+    if constexpr (STATS && PART <= 0) {
       // sums and sums of squares of the pre-activation over the wave's 4 x 16 patch, eight channels at a time (conv_tall3's
       // butterfly: the register set halves at the first three steps), one partial slot per patch
       auto butterfly = [&](float (&x)[8]) {
@@ -272,6 +275,7 @@ __global__ __launch_bounds__(512) void conv64_v3_kernel(const ConvKArgs a) {
       const int cb = n * 32 + hi * 16;                      // channel inside the 64-channel block
       static_for<0, 2>([&](auto mc) {
         constexpr int m = decltype(mc)::value;
+        if constexpr (PART >= 0 && PART != 2 * n + m) return;
         const int gy = e_tc.gy0 + rg * 4 + 2 * m + lrow;
         const bool ok = gy < a.GH && gx < a.GW;
         float v[16];
@@ -340,6 +344,8 @@ __global__ __launch_bounds__(512) void conv64_v3_kernel(const ConvKArgs a) {
     });
   };
 
+  auto ep_finish = [&]() __attribute__((always_inline)) { ep_part(std::integral_constant<int, -1>{}); };
+
   // ---- prologue: chunk 0 of the first tile, the filter, the bias
   TileC cur = coords(tile_begin), nxt = cur;
   unsigned hv_cur[V3_HPW], hv_nxt[V3_HPW];
@@ -397,9 +403,16 @@ __global__ __launch_bounds__(512) void conv64_v3_kernel(const ConvKArgs a) {
           __builtin_amdgcn_sched_barrier(0);
         });
         // the previous tile's epilogue, inside this tile's first chunk: waves 0-3 early, their SIMD partners (waves 4-7) later
+#ifdef FSR_V3_SPREAD
+        if constexpr (c == 0 && s >= 2 && s <= 16 && (s & 1) == 0) {
+          constexpr int part = ((s - 2) >> 1) & 3;
+          if (have_prev && ch == (s <= 8 ? 0 : 1)) ep_part(std::integral_constant<int, part>{});
+        }
+#else
         if constexpr (c == 0 && (s == 3 || s == 11)) {
           if (have_prev && ch == (s == 3 ? 0 : 1) && (!(V3_ABL & 8) || a.GW < 0)) ep_finish();
         }
+#endif
       });
     });
     // the tile is complete: hand the accumulators to the deferred epilogue
