@@ -12,6 +12,11 @@ GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run by the driver with -m gpu)")
+    # The CPU oracle (torch fp32 convolutions at batch 4) is the long pole of the parity tests, and torch's default of one thread
+    # per core is the wrong setting on the MI355X box's 256-thread host: profiles/r06_cpu_threads.txt -- 16 threads 4.4 s per
+    # iteration, 128 threads 25.8 s, 256 threads 330 s.
+    import torch
+    torch.set_num_threads(max(1, min(16, os.cpu_count() or 1)))
 
 
 @pytest.fixture(scope="session")

@@ -73,11 +73,20 @@ def run(pkg, mode, iters, noise_seed, hr_all, lr_all, hr_eval, lr_eval, batch=4,
         idx = torch.randint(0, n_img, (batch,), generator=order)
         pre.append(T.pretrain_step(lr_all[idx].to(device), hr_all[idx].to(device)).detach().float().reshape(()))
     hist = []
+    # the first GAN iteration runs eagerly (it creates every lazily allocated buffer), the rest replay ONE captured hipGraph with
+    # new batch / label-noise contents: bit-identical to eager steps (tests/test_trainer.py::test_graphed_replays_equal_eager_steps)
+    # at a fraction of the host time -- an eager batch-4 iteration is ~600 launches, 60 ms of host work.  CONV_EAGER=1: all eager.
+    use_graph = os.environ.get("CONV_EAGER") != "1"
     for it in range(iters):
         idx = torch.randint(0, n_img, (batch,), generator=order)
         lr, hr = lr_all[idx].to(device), hr_all[idx].to(device)
         noise = [torch.rand(batch, 1, hr.shape[2] // 16, hr.shape[3] // 16, generator=ng).to(device) for _ in range(3)]
-        out = T.train_step(lr, hr, noise)
+        if it == 0 or not use_graph:
+            out = T.train_step(lr, hr, noise)
+        else:
+            if it == 1:
+                T.capture_train_step(lr, hr, warmup=0, noise=noise)
+            out = T.graphed_train_step(lr, hr, noise)
         hist.append(torch.stack([out[k].detach().float().reshape(()) for k in LOSSES]))
         if log and (it + 1) % 100 == 0:
             log("  %s seed %d: iteration %d" % (mode, noise_seed, it + 1))
