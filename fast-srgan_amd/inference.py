@@ -18,7 +18,7 @@ from .model import Generator
 parser = ArgumentParser("Real Time Image Super Resolution")
 parser.add_argument("--image_dir", default=None, required=True, type=str)
 parser.add_argument("--output_dir", default=None, required=True, type=str)
-parser.add_argument("--compute_dtype", default=None, choices=["bf16", "f16", "x3", "f32"], help="extension: kernel precision")
+parser.add_argument("--compute_dtype", default=None, choices=["bf16", "f16", "x3", "x3v", "f32"], help="extension: kernel precision")
 parser.add_argument("--batch", default=8, type=int, help="extension: frames per device batch (same-shape frames are batched)")
 
 

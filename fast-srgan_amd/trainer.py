@@ -88,10 +88,13 @@ class Trainer:
         # The initial 2^20 is measured (tools/f16_scale_probe.py, profiles/r03_f16_loss_scale.txt): at 2^14 nothing overflows
         # but part of the perceptual gradient underflows and 300 iterations end with a content loss 5-10x the fp32 runs';
         # 2^20 .. 2^22 track fp32; 2^26 overflows, is halved four times in the first iterations and then tracks fp32 too.
-        self.loss_scale = float(getattr(config.training, "loss_scale", 1048576.0 if cdt == "f16" else 1.0))
+        # (x3v: the perceptual network alone runs in fp16 -- its backward needs the scale all the same; the x3 networks share
+        # float32's exponent range and are indifferent to it)
+        scaled = "f16" in (self.generator.compute.name, self.perceptual_network.compute.name)
+        self.loss_scale = float(getattr(config.training, "loss_scale", 1048576.0 if scaled else 1.0))
         if not (self.loss_scale > 0.0 and self.loss_scale == self.loss_scale and self.loss_scale != float("inf")):
             raise ValueError("training.loss_scale must be a positive finite number, got %r" % (self.loss_scale,))
-        self.dynamic_loss_scale = bool(getattr(config.training, "dynamic_loss_scale", cdt == "f16"))
+        self.dynamic_loss_scale = bool(getattr(config.training, "dynamic_loss_scale", scaled))
         self.loss_scale_growth_interval = float(getattr(config.training, "loss_scale_growth_interval", 1000))
         if not self.loss_scale_growth_interval >= 1.0:
             raise ValueError("training.loss_scale_growth_interval must be >= 1, got %r" % (self.loss_scale_growth_interval,))

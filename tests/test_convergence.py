@@ -38,12 +38,12 @@ def test_16bit_training_tracks_fp32_training(pkg):
     # x3 (split bf16, three MFMAs per product: the fast mode inside the fp32 tolerance) runs beside the 16-bit modes, same gates
     # (bf16, the 16-bit mode of rounds 1-4, ran here too until round 6: 56 s of a suite with a time limit; its 8-seed table is
     # profiles/r05_convergence.txt, `python tools/convergence.py 300 out.json --modes bf16,f16,x3` reproduces it)
-    results, rows, worst = conv.main(300, modes=("f16", "x3"), log=lines.append)
+    results, rows, worst = conv.main(300, modes=("f16", "x3", "x3v"), log=lines.append)
     out = os.path.join(ROOT, "gpurun_out")
     os.makedirs(out, exist_ok=True)
     with open(os.path.join(out, "convergence.txt"), "w") as f:
         f.write("\n".join(lines) + "\n")
-    for r in results["f32"] + results["f16"] + results["x3"]:
+    for r in results["f32"] + results["f16"] + results["x3"] + results["x3v"]:
         assert r["finite"]
     # the f32 runs themselves learn: pre-training lowers the pixel loss, the discriminator separates real from fake
     pre = results["f32"][0]["curves"]["pretrain_loss"]

@@ -62,11 +62,18 @@ def test_bench_lean_line_is_short_and_parses():
 
 
 def test_bench_headline_is_the_mode_inside_the_tolerance():
-    """The top-level `value` of the headline workload is timed in x3 (round-5 verdict item 1b); cfg5 in the fp16 BASELINE
-    configs[4] names."""
+    """The top-level `value` of the headline workload is timed in the fastest mode whose outputs and losses meet north_star's
+    1e-3 (round-5 verdict item 1b): x3v = x3 Generator / Discriminator + fp16 perceptual network; cfg5 in the fp16 BASELINE
+    configs[4] names.  A launch is priced against the MFMA peak of ITS arithmetic (x3v mixes x3 and fp16 launches)."""
     b = _load_bench()
-    assert b.WORKLOADS["cfg3"]["dtype"] == "x3" and b.WORKLOADS["cfg5"]["dtype"] == "f16"
+    assert b.WORKLOADS["cfg3"]["dtype"] == "x3v" and b.WORKLOADS["cfg5"]["dtype"] == "f16"
     assert abs(b.MFMA_PEAK_TFLOPS["x3"] - 2500.0 / 3) < 1e-9
+    assert b.kernel_peak("conv_tall3_kernel<x3,128,4,1,4,4,2>", "x3v") == b.MFMA_PEAK_TFLOPS["x3"]
+    assert b.kernel_peak("conv_tall3_kernel<f16,128,4,1,4,4,2,stats>", "x3v") == 2500.0
+    assert b.kernel_peak("conv64_v2_kernel<f16,false,false>", "x3v") == 2500.0 and b.kernel_peak("conv_s2d3_kernel<x3>", "x3v") == b.MFMA_PEAK_TFLOPS["x3"]
+    import importlib
+    m = importlib.import_module("fast-srgan_amd.model")
+    assert m.split_compute_dtype("x3v") == ("x3", "f16") and m.split_compute_dtype("x3") == ("x3", "x3") and m.split_compute_dtype("f16") == ("f16", "f16")
 
 
 # The instantiations that carry the GAN iteration (profiles/r05_bench_kernel_stats_{f16,x3}.csv: every convolution kernel above 1.5 %

@@ -350,7 +350,7 @@ def test_graph_replay_of_iteration_and_inference(pkg):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("cdt", ["f32", "x3", "f16", "bf16"])
+@pytest.mark.parametrize("cdt", ["f32", "x3", "x3v", "f16", "bf16"])
 def test_graphed_replays_equal_eager_steps(pkg, cdt):
     """N replays of the captured iteration == N eager train_steps, bit for bit (injected label noise, new batch every
     step), in every mode the bench times.  A replay that read filters packed at capture time, or statistics summed in another
@@ -384,7 +384,7 @@ def test_graphed_replays_equal_eager_steps(pkg, cdt):
     for oe, og in ((Te.optim_generator, Tg.optim_generator), (Te.optim_discriminator, Tg.optim_discriminator)):
         assert torch.equal(oe.flat_param, og.flat_param) and torch.equal(oe.exp_avg_sq, og.exp_avg_sq)
         assert float(oe.step_dev) == float(og.step_dev) == 7.0
-    if cdt == "f16":
+    if cdt in ("f16", "x3v"):
         assert Te.loss_scale_state() == Tg.loss_scale_state() and Tg.loss_scale_state()[1] == 0
 
 

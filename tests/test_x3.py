@@ -197,20 +197,24 @@ def test_x3_generator_discriminator_vs_oracle(dev):
     assert not bad, bad
 
 
-def test_x3_train_step_vs_oracle(dev):
+@pytest.mark.parametrize("mode", ["x3", "x3v"])
+def test_x3_train_step_vs_oracle(dev, mode):
     """One whole iteration (trainer.py:171-196) in x3 mode against the fp32 oracle: four losses to 1e-3 (measured ~1e-5),
-    one AdamW update of both networks in the mean."""
+    one AdamW update of both networks in the mean.  mode x3v: the same with the frozen perceptual network in fp16 (x3 Generator /
+    Discriminator, the dynamic loss scale of the fp16 mode) -- same gates; the content loss is the one quantity fp16 touches."""
     pkg = importlib.import_module("fast-srgan_amd")
     torch.manual_seed(9)
     big = dev.type == "cuda"
     nf, wd, nl = (64, 2, 2) if big else (32, 2, 1)
     cfg = ns(experiment=ns(name="t", seed=1234), generator=ns(n_filters=nf, n_layers=nl), discriminator=ns(n_filters=nf, n_layers=7),
              training=ns(compiled=False, device=str(dev), log_iter=1, checkpoint_iter=10 ** 9, generator_lr=1e-4, discriminator_lr=1e-4,
-                         batch_size=2, compute_dtype="x3"))
+                         batch_size=2, compute_dtype=mode))
     with warnings.catch_warnings():
         warnings.simplefilter("ignore")
-        V = pkg.VGG19(compute_dtype="x3", width_div=wd, seed=1234)
+        V = pkg.VGG19(compute_dtype=mode, width_div=wd, seed=1234)
         T = pkg.Trainer(cfg, perceptual_network=V)
+    assert T.generator.compute.name == "x3" and T.discriminator.compute.name == "x3"
+    assert V.compute.name == ("f16" if mode == "x3v" else "x3") and (T.loss_scale_state() is not None) == (mode == "x3v")
     g_sd = {k: v.detach().cpu().clone() for k, v in T.generator.state_dict().items()}
     d_sd = {k: v.detach().cpu().clone() for k, v in T.discriminator.state_dict().items()}
     g0, d0 = {k: v.clone() for k, v in g_sd.items()}, {k: v.clone() for k, v in d_sd.items()}
@@ -221,7 +225,7 @@ def test_x3_train_step_vs_oracle(dev):
     got = T.train_step(lr.to(dev), hr.to(dev), [t.to(dev) for t in noise])
     want = O.train_step(g_sd, d_sd, v_sd, lr, hr, noise, {}, {})
     for k in want:
-        e = report("step.x3.%s.%s" % (dev.type, k), abs(float(got[k]) - float(want[k])) / abs(float(want[k])))
+        e = report("step.%s.%s.%s" % (mode, dev.type, k), abs(float(got[k]) - float(want[k])) / abs(float(want[k])))
         assert e <= 1e-3, (k, float(got[k]), float(want[k]))
     for sd_ref, sd0, mod in ((g_sd, g0, T.generator), (d_sd, d0, T.discriminator)):
         for k, p in mod.state_dict().items():
@@ -229,6 +233,8 @@ def test_x3_train_step_vs_oracle(dev):
             # (Adam normalises every element's update to ~lr: an element whose tiny gradient changes sign under 2^-17 products moves
             # by 2 lr -- measured up to 0.10 of the mean update on a bias vector; the f32 mode's bound is 0.1)
             assert (p.cpu() - sd_ref[k]).abs().mean() <= 0.2 * upd + 1e-12, k
+    if mode == "x3v":
+        assert T.loss_scale_state()[1] == 0          # nothing overflowed: no skipped update
 
 
 @pytest.mark.parametrize("case", ["s1_relu_pool", "s1_stats", "s1_narrow_addend", "s1_narrow_stats", "s1_mask", "s2_stats", "s2_bias_leaky_mask", "rows12",

@@ -3,16 +3,18 @@
 # (single stream, eager: exclusive durations) of the timed iteration in the x3, f16, bf16 and exact-f32 modes and of the cfg5 workload,
 # of generator inference in f16 and x3, the PMC traffic passes (FETCH_SIZE / WRITE_SIZE, separate passes, kernel-trace only) bound
 # to the kernel sources' hash for the x3 and the f16 iteration, and the per-layer convolution timings.
-#   usage: bash tools/gpu_artifacts.sh [stats|pmc|inf|conv|all] [tag, default r06]
+#   usage: bash tools/gpu_artifacts.sh [stats|pmc|inf|conv|all] [tag, default r06] ["modes of the stats / pmc passes", default all]
 set -u
 R=$GRAFT_REPO_ROOT
 WHAT=${1:-all}
 TAG=${2:-r06}
+SMODES=${3:-"x3v x3 f16 bf16 f32"}
+PMODES=${3:-"x3v x3 f16"}
 O=$R/gpurun_out/$TAG; mkdir -p $O; export TMPDIR=/tmp
 COMMON="--steps 5 --warmup 2 --no-cpu-baseline --no-inference --no-graph --no-f32 --no-x3 --no-f16 --no-bf16 --no-sustained --no-cfg5"
 cd /tmp
 if [ "$WHAT" = stats ] || [ "$WHAT" = all ]; then
-  for M in x3 f16 bf16 f32; do
+  for M in $SMODES; do
     FSR_SIDE_STREAM=0 FSR_WGRAD_STREAM=0 timeout 500 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_$M -o bench -- python $R/bench.py --dtype $M $COMMON --detail $O/bench_detail_$M.json > $O/rocprof_$M.log 2>&1
     cp $O/prof_$M/bench_kernel_stats.csv $O/bench_kernel_stats_$M.csv; rm -f $O/prof_$M/bench_kernel_trace.csv
   done
@@ -20,12 +22,12 @@ if [ "$WHAT" = stats ] || [ "$WHAT" = all ]; then
   cp $O/prof_cfg5/bench_kernel_stats.csv $O/bench_kernel_stats_cfg5.csv; rm -f $O/prof_cfg5/bench_kernel_trace.csv
 fi
 if [ "$WHAT" = pmc ] || [ "$WHAT" = all ]; then
-  for M in x3 f16; do
+  for M in $PMODES; do
     for C in FETCH_SIZE WRITE_SIZE; do
       FSR_SIDE_STREAM=0 FSR_WGRAD_STREAM=0 timeout 500 rocprofv3 --kernel-trace --pmc $C --output-format csv -d $O/pmc_${M}_$C -o step -- python $R/bench.py --dtype $M --steps 1 --warmup 1 --no-cpu-baseline --no-inference --no-graph --no-f32 --no-x3 --no-f16 --no-bf16 --no-sustained --no-cfg5 --detail $O/pmc_detail_${M}.json > $O/pmc_${M}_$C.log 2>&1
     done
     L=$(python -c "import sys,json; print(json.load(open('$O/pmc_detail_${M}.json'))['roofline']['family']['launches_per_step'])")
-    OUT=$R/profiles/conv_traffic.json; [ $M = x3 ] && OUT=$R/profiles/conv_traffic_x3.json
+    OUT=$R/profiles/conv_traffic.json; [ $M != f16 ] && OUT=$R/profiles/conv_traffic_$M.json
     (cd $R && PMC_DTYPE=$M python tools/pmc_traffic.py $O/pmc_${M}_FETCH_SIZE/step_counter_collection.csv $O/pmc_${M}_WRITE_SIZE/step_counter_collection.csv 4 $L $OUT) > $O/pmc_traffic_$M.txt 2>&1
     cp $OUT $O/
     rm -f $O/pmc_${M}_*/step_kernel_trace.csv
