@@ -85,7 +85,7 @@ class Trainer:
         # discriminator overflow also skips the generator update of that iteration (its gradients went through the same
         # too-large scale).  The flag is cleared at the START of every iteration as well as by the scale update, so an
         # exception between a flagged step and the update cannot leave it up for the next iteration.
-        # The initial 2^20 is measured (tools/f16_scale_probe.py, profiles/r03_f16_loss_scale.txt): at 2^14 nothing overflows
+        # The initial 2^20 is measured (profiles/r03_f16_loss_scale.txt): at 2^14 nothing overflows
         # but part of the perceptual gradient underflows and 300 iterations end with a content loss 5-10x the fp32 runs';
         # 2^20 .. 2^22 track fp32; 2^26 overflows, is halved four times in the first iterations and then tracks fp32 too.
         # (x3v: the perceptual network alone runs in fp16 -- its backward needs the scale all the same; the x3 networks share
