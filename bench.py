@@ -93,8 +93,8 @@ MODE_DESCRIBED = {
     "f32": "f32 (v_mfma_f32_16x16x4_f32, exact fmaf chains)"}
 MODE_MEETS = {
     "x3v": "all four losses within 1e-3 relative fp32 (content loss, the one quantity the fp16 network produces: 1.9e-4; the others as "
-           "x3) and every generator output as x3 (the generator IS x3); parameter gradients at pure x3's distance from float64 "
-           "(tests/test_parity_bench.py [x3v] cases, DESIGN.md 2c)",
+           "x3) and every generator output as x3 (the generator IS x3); parameter gradients at pure x3's distance from float64; the perceptual "
+           "gradient itself is fp16-quality (11.8 % rel-L2 from fp32's, x3: 0.45 %) (tests/test_parity_bench.py [x3v] / [f16] cases, DESIGN.md 2c)",
     "x3": "forward outputs and all four losses within 1e-3 relative fp32 (measured 0 .. 7e-5: tests/test_x3.py, tests/test_parity_bench.py "
           "[x3] cases); parameter gradients are NOT at the f32 mode's gates: vs float64 the G network sits at 1.3x, the D network at "
           "2.8x the float32 oracle's own distance (DESIGN.md 2b)",
