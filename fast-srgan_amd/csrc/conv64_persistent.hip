@@ -41,15 +41,26 @@ __device__ __forceinline__ unsigned tap64(const ConvKArgs& a, int t) {
 // 64-channel input at memory speed instead of living one tile per workgroup.  (This register-staged, two-barriers-per-tile
 // structure was also the FIRST form of the 64-channel-block kernel; conv64_v2_kernel below replaced it in round 2 and the
 // block instantiation was deleted in round 4.)
-template <typename T>
+// X3 (round 6; T = bf16_t): the input is an x3 tensor -- per pixel and 32-channel group 64 bytes of hi, then 64 bytes of lo, i.e. 128
+// bf16 elements per pixel of which group g owns [64 g, 64 g + 64) -- and the filter the x3 pack ([w_hi | w_lo] per 32 input channels).
+// A tile is then two passes of this same kernel body, one per channel group: the group's 128 bytes per pixel ARE a 64-channel 16-bit
+// pixel whose first half is x_hi and whose second half is x_lo, and the three products x_hi w_hi + x_lo w_hi + x_hi w_lo are three MFMAs
+// on the four fragments the 16-bit form reads for its two.  Only eight filter rows are kept in LDS per (group, tap) (Cout <= 8: the
+// lanes of rows 8 .. 15 read rows 0 .. 7 again and their accumulator rows are never stored), so the filter block is the 16-bit form's
+// size and two workgroups still share a CU.  (Until round 6 these launches ran on conv_igemm<x3,8,16,...> at 2.3 TB/s.)
+template <typename T, bool X3 = false>
 __global__ __launch_bounds__(NTHR64, 2) void conv64_thin_kernel(const ConvKArgs a) {
+  static_assert(!X3 || std::is_same<T, bf16_t>::value, "x3: bf16 planes");
   constexpr int NT = 1;
-  constexpr int ROWS = NT * 16;
-  constexpr int HUNITS = HT * HT * 8;                   // 16-byte units of one halo
+  constexpr int NG = X3 ? 2 : 1;                        // channel-group passes per tile
+  constexpr int ROWS = X3 ? 8 : NT * 16;                // filter rows kept per (group, tap)
+  constexpr int PIX = X3 ? 128 : 64;                    // T elements per input pixel
+  constexpr int HUNITS = HT * HT * 8;                   // 16-byte units of one halo (one group: 128 bytes per pixel)
   constexpr int HPT = (HUNITS + NTHR64 - 1) / NTHR64;   // 6
   HIP_DYNAMIC_SHARED(char, smem)
   T* wl = (T*)smem;
-  constexpr int WB = 9 * NT * 16 * P64 * 2;            // bytes of the resident filter block
+  constexpr int WB = 9 * NT * 16 * P64 * 2;            // bytes of the resident filter block (x3: 2 groups x 9 taps x 8 rows)
+  static_assert(NG * 9 * ROWS * P64 * 2 == WB, "the filter block of every form is 9 x 16 rows of the 160-byte pitch");
   T* halo = (T*)(smem + WB);
 
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -58,23 +69,26 @@ __global__ __launch_bounds__(NTHR64, 2) void conv64_thin_kernel(const ConvKArgs 
   const int tiles_per_img = a.tiles_x * a.tiles_y;
   const int ntiles = tiles_per_img * a.N;
 
-  // ---- the 16 filter rows, all nine taps: [9][16][64] -> LDS, once
+  // ---- the filter rows, all nine taps (x3: of both channel groups): [g][9][ROWS][64] -> LDS, once
   {
     const T* wpk = (const T*)a.wpk;
-    constexpr int WU = 9 * ROWS * 8;                    // 16-byte units of the resident filter block
+    constexpr int WU = NG * 9 * ROWS * 8;               // 16-byte units of the resident filter block
 #pragma unroll
     for (int i = 0; i < (WU + NTHR64 - 1) / NTHR64; ++i) {
-      const int u = tid + i * NTHR64;                   // (slice*ROWS + row)*8 + unit
+      const int u = tid + i * NTHR64;                   // ((g*9 + slice)*ROWS + row)*8 + unit
       if (WU % NTHR64 == 0 || u < WU) {
-        const int slice = u / (ROWS * 8), ru = u % (ROWS * 8);
-        const u32x4 v = *(const u32x4*)(wpk + ((size_t)slice * a.CoutPad * 64 + (size_t)ru * 8));
+        const int gs = u / (ROWS * 8), ru = u % (ROWS * 8);
+        const int g = gs / 9, slice = gs - 9 * g, row = ru >> 3, unit = ru & 7;
+        const u32x4 v = *(const u32x4*)(wpk + ((size_t)(slice * a.CoutPad + row) * PIX + (size_t)(g * 64 + unit * 8)));
         *(u32x4*)(wl + (u >> 3) * P64 + (u & 7) * 8) = v;
       }
     }
   }
 
   u32x4 hreg[HPT];
-  auto halo_issue = [&](int tile) {
+  // halo of step s = (tile s / NG, channel group s % NG)
+  auto halo_issue = [&](int step) {
+    const int tile = step / NG, g = step - tile * NG;
     const int img = tile / tiles_per_img;
     const int rem = tile - img * tiles_per_img;
     const int ty = rem / a.tiles_x, tx = rem - ty * a.tiles_x;
@@ -88,7 +102,7 @@ __global__ __launch_bounds__(NTHR64, 2) void conv64_thin_kernel(const ConvKArgs 
         const int hy = p / HT, hx = p - hy * HT;
         const int iy = iy0 + hy, ix = ix0 + hx;
         if (iy >= 0 && iy < a.IH && ix >= 0 && ix < a.IW)
-          v = *(const u32x4*)(in + ((unsigned)((img * a.IH + iy) * a.IW + ix) * 64u + (unsigned)(unit * 8)));
+          v = *(const u32x4*)(in + ((unsigned)((img * a.IH + iy) * a.IW + ix) * (unsigned)PIX + (unsigned)(g * 64 + unit * 8)));
       }
       hreg[i] = v;
     }
@@ -109,7 +123,7 @@ __global__ __launch_bounds__(NTHR64, 2) void conv64_thin_kernel(const ConvKArgs 
 #pragma unroll
   for (int m = 0; m < 2; ++m) pixbase[m] = ((wave * 2 + m) * HT + l15) * P64 + lg * 8;
 #pragma unroll
-  for (int n = 0; n < NT; ++n) wbase[n] = (n * 16 + l15) * P64 + lg * 8;
+  for (int n = 0; n < NT; ++n) wbase[n] = (n * 16 + (X3 ? (l15 & 7) : l15)) * P64 + lg * 8;
   f32x4 bias[NT];
 #pragma unroll
   for (int n = 0; n < NT; ++n) {
@@ -128,64 +142,87 @@ __global__ __launch_bounds__(NTHR64, 2) void conv64_thin_kernel(const ConvKArgs 
 #pragma unroll
     for (int r = 0; r < 4; ++r) oscale[r] = a.oscale[lg * 4 + r < a.Cout ? lg * 4 + r : 0];
   }
-  int tile = tile_begin;
-  if (tile < tile_end) halo_issue(tile);
+  const int step_begin = tile_begin * NG, step_end = tile_end * NG;
+  int step = step_begin;
+  if (step < step_end) halo_issue(step);
   __syncthreads();                 // filter visible
-  if (tile < tile_end) halo_commit();
+  if (step < step_end) halo_commit();
   __syncthreads();
 
-  for (; tile < tile_end; ++tile) {
-    const int next = tile + 1;
-    if (next < tile_end) halo_issue(next);
+  f32x4 acc[2][NT];
+  for (; step < step_end; ++step) {
+    const int next = step + 1;
+    const int tile = step / NG, g = step - tile * NG;
+    if (next < step_end) halo_issue(next);
 
-    f32x4 acc[2][NT];
+    if (g == 0) {
 #pragma unroll
-    for (int m = 0; m < 2; ++m)
+      for (int m = 0; m < 2; ++m)
 #pragma unroll
-      for (int n = 0; n < NT; ++n) acc[m][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int n = 0; n < NT; ++n) acc[m][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
 #pragma unroll
     for (int t = 0; t < 9; ++t) {
       const unsigned tc = tap64(a, t);
       const int toff = ((int)(tc & 3u) * HT + (int)((tc >> 2) & 3u)) * P64;
-      const T* wsl = wl + (int)(tc >> 4) * ROWS * P64;
+      const T* wsl = wl + ((g * 9 + (int)(tc >> 4)) * ROWS) * P64;
+      if constexpr (X3) {
+        // the group's pixel = [x_hi 32 | x_lo 32], its filter row = [w_hi 32 | w_lo 32]: hi hi + lo hi + hi lo
+        s16x8 wf[2], xf[2][2];
 #pragma unroll
-      for (int ks = 0; ks < 2; ++ks) {
-        s16x8 wf[NT], xf[2];
+        for (int ks = 0; ks < 2; ++ks) {
+          wf[ks] = *(const s16x8*)(wsl + wbase[0] + ks * 32);
 #pragma unroll
-        for (int n = 0; n < NT; ++n) wf[n] = *(const s16x8*)(wsl + wbase[n] + ks * 32);
+          for (int m = 0; m < 2; ++m) xf[m][ks] = *(const s16x8*)(halo + pixbase[m] + toff + ks * 32);
+        }
 #pragma unroll
-        for (int m = 0; m < 2; ++m) xf[m] = *(const s16x8*)(halo + pixbase[m] + toff + ks * 32);
+        for (int m = 0; m < 2; ++m) {
+          acc[m][0] = mfma16<T>(wf[0], xf[m][0], acc[m][0]);
+          acc[m][0] = mfma16<T>(wf[0], xf[m][1], acc[m][0]);
+          acc[m][0] = mfma16<T>(wf[1], xf[m][0], acc[m][0]);
+        }
+      } else {
 #pragma unroll
-        for (int m = 0; m < 2; ++m)
+        for (int ks = 0; ks < 2; ++ks) {
+          s16x8 wf[NT], xf[2];
 #pragma unroll
-          for (int n = 0; n < NT; ++n) acc[m][n] = mfma16<T>(wf[n], xf[m], acc[m][n]);
+          for (int n = 0; n < NT; ++n) wf[n] = *(const s16x8*)(wsl + wbase[n] + ks * 32);
+#pragma unroll
+          for (int m = 0; m < 2; ++m) xf[m] = *(const s16x8*)(halo + pixbase[m] + toff + ks * 32);
+#pragma unroll
+          for (int m = 0; m < 2; ++m)
+#pragma unroll
+            for (int n = 0; n < NT; ++n) acc[m][n] = mfma16<T>(wf[n], xf[m], acc[m][n]);
+        }
       }
     }
 
-    // ---- epilogue of this tile
+    // ---- epilogue of this tile (after its last channel group)
     FSR_WAIT_LOADS();   // the prefetched halo has landed; the stores below then drain under the next tile
-    const int img = tile / tiles_per_img;
-    const int rem = tile - img * tiles_per_img;
-    const int ty = rem / a.tiles_x, tx = rem - ty * a.tiles_x;
-    const int gx = tx * 16 + l15, gyb = ty * 16 + wave * 2;
-    const bool col_ok = gx < a.GW;
-    // float output, Cout <= 16 valid channels (lane group lg holds channels 4 lg .. 4 lg + 3): scale, bias, tanh / slope
+    if (g == NG - 1) {
+      const int img = tile / tiles_per_img;
+      const int rem = tile - img * tiles_per_img;
+      const int ty = rem / a.tiles_x, tx = rem - ty * a.tiles_x;
+      const int gx = tx * 16 + l15, gyb = ty * 16 + wave * 2;
+      const bool col_ok = gx < a.GW;
+      // float output, Cout <= 16 valid channels (lane group lg holds channels 4 lg .. 4 lg + 3): scale, bias, tanh / slope
 #pragma unroll
-    for (int m = 0; m < 2; ++m) {
-      if (col_ok && gyb + m < a.GH) {
-        const size_t off = (((size_t)img * a.FOH + gyb + m) * a.FOW + gx) * a.Cout + lg * 4;
+      for (int m = 0; m < 2; ++m) {
+        if (col_ok && gyb + m < a.GH) {
+          const size_t off = (((size_t)img * a.FOH + gyb + m) * a.FOW + gx) * a.Cout + lg * 4;
 #pragma unroll
-        for (int r = 0; r < 4; ++r)
-          if (lg * 4 + r < a.Cout) {
-            float v = acc[m][0][r] * oscale[r] + bias[0][r];
-            v = (a.act == FSR_ACT_TANH) ? tanhf(v) : (v > 0.f ? v : v * slope);
-            if (a.out_f32 == FSR_OUT_U8) ((unsigned char*)a.out)[off + r] = image_u8(v);   // HWC uint8 image (inference)
-            else ((float*)a.out)[off + r] = v;
-          }
+          for (int r = 0; r < 4; ++r)
+            if (lg * 4 + r < a.Cout) {
+              float v = acc[m][0][r] * oscale[r] + bias[0][r];
+              v = (a.act == FSR_ACT_TANH) ? tanhf(v) : (v > 0.f ? v : v * slope);
+              if (a.out_f32 == FSR_OUT_U8) ((unsigned char*)a.out)[off + r] = image_u8(v);   // HWC uint8 image (inference)
+              else ((float*)a.out)[off + r] = v;
+            }
+        }
       }
     }
     __syncthreads();   // every wave is done with the halo
-    if (next < tile_end) halo_commit();
+    if (next < step_end) halo_commit();
     __syncthreads();
   }
 }
@@ -781,9 +818,12 @@ int fsr_conv64_s2fwd_try(int dtype, ConvKArgs& a, int S, hipStream_t stream) {
 
 // Returns 1 if the launch was taken, 0 if the shape is not this kernel's, < 0 on error.
 int fsr_conv64_persistent_try(int dtype, ConvKArgs& a, int S, hipStream_t stream) {
-  if ((dtype != FSR_BF16 && dtype != FSR_F16) || S != 1 || a.Cin != 64 || a.ntaps != 9) return 0;
+  // x3 (a.Cin = 128 physical bf16 channels): the thin kernel only (the head and the image gradients; round 6)
+  const bool x3 = dtype == FSR_X3;
+  if ((dtype != FSR_BF16 && dtype != FSR_F16 && !x3) || S != 1 || a.Cin != (x3 ? 128 : 64) || a.ntaps != 9) return 0;
   // thin: float output of at most 16 channels (head conv, image gradients); otherwise 64-channel blocks
   const bool thin = a.CoutPad == 16 && a.out_f32 && !a.ps && !a.in_ps && !a.stats && !a.preact && !a.dmask && !a.pool2;
+  if (x3 && (!thin || a.Cout > 8 || a.wlin)) return 0;      // (eight filter rows per tap in LDS: conv64_thin_kernel<bf16_t, true>)
   if (!thin) {
     if (a.Cout % 64 != 0 || a.CoutPad != a.Cout || a.Cout > 256) return 0;
     if (a.in_ps || a.out_f32 || a.oscale) return 0;
@@ -793,7 +833,8 @@ int fsr_conv64_persistent_try(int dtype, ConvKArgs& a, int S, hipStream_t stream
     if (a.stats && a.dmask) return 0;   // InstanceNorm backward sums: generic kernel
   }
   if (a.osy != 1 || a.osx != 1 || a.ooy != 0 || a.oox != 0) return 0;
-  if ((long long)a.N * a.IH * a.IW * 64 >= (1LL << 31) || (long long)a.N * a.FOH * a.FOW * a.Cout >= (1LL << 31)) return 0;
+  // (the thin kernel indexes its input with unsigned 32-bit element offsets; x3: 128 elements per pixel -- 720p x 32 frames is 3.8e9)
+  if ((long long)a.N * a.IH * a.IW * (x3 ? 128 : 64) >= (x3 ? (1LL << 32) : (1LL << 31)) || (long long)a.N * a.FOH * a.FOW * a.Cout >= (1LL << 31)) return 0;
   a.tiles_x = (a.GW + 15) / 16;
   a.tiles_y = (a.GH + 15) / 16;
   a.taps_lo = 0;
@@ -810,6 +851,7 @@ int fsr_conv64_persistent_try(int dtype, ConvKArgs& a, int S, hipStream_t stream
   if (!attr_set) {
     (void)hipFuncSetAttribute((const void*)conv64_thin_kernel<bf16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_THIN);
     (void)hipFuncSetAttribute((const void*)conv64_thin_kernel<f16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_THIN);
+    (void)hipFuncSetAttribute((const void*)conv64_thin_kernel<bf16_t, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_THIN);
     (void)hipFuncSetAttribute((const void*)conv64_v2_kernel<bf16_t, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS64V2);
     (void)hipFuncSetAttribute((const void*)conv64_v2_kernel<bf16_t, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS64V2);
     (void)hipFuncSetAttribute((const void*)conv64_v2_kernel<bf16_t, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS64V2);
@@ -830,7 +872,9 @@ int fsr_conv64_persistent_try(int dtype, ConvKArgs& a, int S, hipStream_t stream
   a.stats_P = (a.stats_tpi + per - 1) / per + 1;
   if (a.stats && a.stats_P > a.stats_P_max) return fsr_fail(-3, "conv64: %d partial slots per image exceed the scratch buffer's %d", a.stats_P, a.stats_P_max);
   const int grid = (int)((ntiles + per - 1) / per) * nblk;
-  if (dtype == FSR_F16) {
+  if (x3) {
+    hipLaunchKernelGGL((conv64_thin_kernel<bf16_t, true>), dim3(grid), dim3(NTHR64), LDS_THIN, stream, a);
+  } else if (dtype == FSR_F16) {
     if (thin) hipLaunchKernelGGL((conv64_thin_kernel<f16_t>), dim3(grid), dim3(NTHR64), LDS_THIN, stream, a);
     else if (a.stats) hipLaunchKernelGGL((conv64_v2_kernel<f16_t, true, false>), dim3(grid), dim3(NTHR64), LDS64V2, stream, a);
     else if (a.dmask) hipLaunchKernelGGL((conv64_v2_kernel<f16_t, false, true>), dim3(grid), dim3(NTHR64), LDS64V2, stream, a);
@@ -841,7 +885,7 @@ int fsr_conv64_persistent_try(int dtype, ConvKArgs& a, int S, hipStream_t stream
     else if (a.dmask) hipLaunchKernelGGL((conv64_v2_kernel<bf16_t, false, true>), dim3(grid), dim3(NTHR64), LDS64V2, stream, a);
     else hipLaunchKernelGGL((conv64_v2_kernel<bf16_t, false, false>), dim3(grid), dim3(NTHR64), LDS64V2, stream, a);
   }
-  fsr_note_kernel(thin ? "conv64_thin_kernel" : "conv64_v2_kernel");
+  fsr_note_kernel(x3 ? "conv64_thin_kernel<x3>" : (thin ? "conv64_thin_kernel" : "conv64_v2_kernel"));
   int rc = fsr_check_launch(thin ? "conv64_thin_kernel" : "conv64_v2_kernel");
   return rc ? rc : 1;
 }

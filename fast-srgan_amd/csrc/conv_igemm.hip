@@ -865,6 +865,8 @@ int fsr_conv_igemm_dispatch(int dtype, ConvKArgs& a, int S, hipStream_t stream) 
     if (const int rc = fsr_conv_tall3_try(dtype, a, S, stream)) return rc < 0 ? rc : 0;
     if (a.query) return 0;            // (the standard x3 pack)
     if (a.wlin) return fsr_fail(-2, "conv3x3: a stage-contiguous filter pack reached a kernel that reads the standard one");
+    // the 64 -> 3 ends (head, image gradients): the streaming thin kernel's x3 form (conv64_persistent.hip)
+    if (const int rc = fsr_conv64_persistent_try(dtype, a, S, stream)) return rc < 0 ? rc : 0;
     return dispatch_X3(a, S, stream);
   }
   if (a.Cin == 64) {

@@ -101,6 +101,42 @@ def test_x3_conv_fwd_dgrad_wgrad(dev, cd, stride, cin, cout, ps):
     assert report("x3.conv.wgrad", relerr(dw, wr.grad)) < OP_TOL
 
 
+@pytest.mark.parametrize("cus", [1, 3])
+def test_x3_thin_kernel_head_and_image_gradient(dev, cd, cus, monkeypatch):
+    """conv64_thin_kernel<x3> (round 6): the 64 -> 3 ends of the networks on x3 storage -- the generator's head with its tanh
+    (model.py:102-110; float and uint8 output) and a 64 -> 3 data gradient with the per-channel scale of the VGG normalisation --
+    streamed as two channel-group passes per tile (hi hi + lo hi + hi lo on the 16-bit kernel's four fragment reads), on maps
+    that are not multiples of the 16 x 16 tile, one and several tile ranges per workgroup."""
+    monkeypatch.setenv("FSR_PERSIST_CUS", str(cus))
+    torch.manual_seed(4)
+    big = dev.type == "cuda"
+    n, h, w = (3, 37, 45) if big else (2, 17, 19)
+    x = torch.randn(n, 64, h, w)
+    wt = torch.randn(3, 64, 3, 3) * 0.1
+    bias = torch.randn(3) * 0.1
+    xd = _nhwc(x, cd, dev)
+    wpk = ops.packed_filter(cd, wt.to(dev), L.PACK_FWD, 64)
+    y, _, _ = ops.conv3x3_raw(cd, xd, wpk, 3, bias=bias.to(dev), act=L.ACT_TANH, out_f32=True)
+    assert L.lib().fsr_last_kernel().decode() == "conv64_thin_kernel<x3>", L.lib().fsr_last_kernel()
+    ref = torch.tanh(F.conv2d(x, wt, bias, 1, 1))
+    assert y.dtype == torch.float32 and y.shape == (n, h, w, 3)
+    assert report("x3.thin.head", relerr(y.cpu().permute(0, 3, 1, 2), ref)) < OP_TOL
+    yu, _, _ = ops.conv3x3_raw(cd, xd, wpk, 3, bias=bias.to(dev), act=L.ACT_TANH, out_u8=True)
+    assert L.lib().fsr_last_kernel().decode() == "conv64_thin_kernel<x3>"
+    want_u8 = (((y.cpu() + 1.0) / 2.0) * 255.0).to(torch.uint8)          # inference.py:53-56 on the float output of the same kernel
+    assert yu.dtype == torch.uint8 and torch.equal(yu.cpu(), want_u8)
+    # the data gradient of a 3 -> 64 first layer: 64 gradient channels in, 3 float channels out, scaled per channel
+    w1 = torch.randn(64, 3, 3, 3) * 0.1
+    g = torch.randn(n, 64, h, w)
+    xr = leaf(torch.randn(n, 3, h, w))
+    F.conv2d(xr, w1, None, 1, 1).backward(g)
+    scale = torch.tensor([2.0, 0.5, 1.5])
+    wpk_d = ops.packed_filter(cd, w1.to(dev), L.PACK_DGRAD, 64)
+    dx, _, _ = ops.conv3x3_raw(cd, _nhwc(g, cd, dev), wpk_d, 3, mode=L.CONV_DGRAD, out_hw=(h, w), out_f32=True, oscale=scale.to(dev))
+    assert L.lib().fsr_last_kernel().decode() == "conv64_thin_kernel<x3>", L.lib().fsr_last_kernel()
+    assert report("x3.thin.image_gradient", relerr(dx.cpu().permute(0, 3, 1, 2), xr.grad * scale.view(1, 3, 1, 1))) < OP_TOL
+
+
 def test_x3_conv_epilogues_autograd(dev, cd):
     """Conv3x3Fn with the fused epilogues in x3 storage: bias + PReLU + PixelShuffle (pre-activation copy, act_bwd with its
     bias / slope reductions), LeakyReLU applied by the consumer's data-gradient mask, the residual skip added in the
