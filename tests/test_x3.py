@@ -239,6 +239,8 @@ def test_x3_train_step_vs_oracle(dev, mode):
     one AdamW update of both networks in the mean.  mode x3v: the same with the frozen perceptual network in fp16 (x3 Generator /
     Discriminator, the dynamic loss scale of the fp16 mode) -- same gates; the content loss is the one quantity fp16 touches."""
     pkg = importlib.import_module("fast-srgan_amd")
+    if mode == "x3" and dev.type != "cuda":
+        pytest.skip("emulator: the x3v case runs the same x3 Generator / Discriminator kernels (35 s saved); x3 VGG kernels: the operator tests")
     torch.manual_seed(9)
     big = dev.type == "cuda"
     nf, wd, nl = (64, 2, 2) if big else (32, 2, 1)
