@@ -3,6 +3,7 @@ import os
 import socket
 import sys
 
+import pytest
 import torch
 import torch.multiprocessing as mp
 
@@ -69,17 +70,20 @@ def test_two_rank_gradient_average_equals_single_process(tmp_path):
 
 
 # ------------------------------------------------------------------ the whole iteration, batch-sharded over 2 ranks
-def _tiny_trainer(pkg, dev):
+def _tiny_trainer(pkg, dev, mode="f32"):
+    """mode "x3v" (the bench headline): x3 Generator / Discriminator, fp16 perceptual network, the device-side dynamic loss scale --
+    16-bit and x3 tensors carry multiples of 32 channels."""
     import types
     import warnings
     ns = types.SimpleNamespace
-    cfg = ns(experiment=ns(name="ddp", seed=1234), generator=ns(n_filters=16, n_layers=1),
-             discriminator=ns(n_filters=16, n_layers=7),
+    nf, wd = (16, 4) if mode == "f32" else (32, 2)
+    cfg = ns(experiment=ns(name="ddp", seed=1234), generator=ns(n_filters=nf, n_layers=1),
+             discriminator=ns(n_filters=nf, n_layers=7),
              training=ns(compiled=False, device=str(dev), log_iter=1, checkpoint_iter=10 ** 9, generator_lr=1e-4,
-                         discriminator_lr=1e-4, batch_size=1, compute_dtype="f32"))
+                         discriminator_lr=1e-4, batch_size=1, compute_dtype=mode))
     with warnings.catch_warnings():
         warnings.simplefilter("ignore")
-        return pkg.Trainer(cfg, perceptual_network=pkg.VGG19(compute_dtype="f32", width_div=4, seed=1234))
+        return pkg.Trainer(cfg, perceptual_network=pkg.VGG19(compute_dtype=mode, width_div=wd, seed=1234))
 
 
 def _ddp_data():
@@ -90,7 +94,7 @@ def _ddp_data():
     return lr, hr, noise
 
 
-def _step_worker(rank, world, port, out_dir):
+def _step_worker(rank, world, port, out_dir, mode="f32"):
     os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1",
                       MASTER_PORT=str(port))
     sys.path.insert(0, ROOT)
@@ -102,22 +106,26 @@ def _step_worker(rank, world, port, out_dir):
     D = importlib.import_module("fast-srgan_amd.distributed")
     D.init_from_env(backend="gloo")
     torch.manual_seed(7 + rank)                       # different initialisation per rank; Trainer broadcasts rank 0's
-    T = _tiny_trainer(pkg, dev)
+    T = _tiny_trainer(pkg, dev, mode)
     init = {"g": T.optim_generator.flat_param.clone(), "d": T.optim_discriminator.flat_param.clone()}
     lr, hr, noise = _ddp_data()
     T.train_step(lr[rank:rank + 1], hr[rank:rank + 1], [n[rank:rank + 1] for n in noise])
     torch.save({"init": init, "g_grad": T.optim_generator.flat_grad / world, "d_grad": T.optim_discriminator.flat_grad / world,
-                "g": T.optim_generator.flat_param.clone(), "d": T.optim_discriminator.flat_param.clone()},
+                "g": T.optim_generator.flat_param.clone(), "d": T.optim_discriminator.flat_param.clone(),
+                "scale": T.loss_scale_state()},
                os.path.join(out_dir, f"step_rank{rank}.pt"))
     torch.distributed.barrier()
     torch.distributed.destroy_process_group()
 
 
-def test_two_rank_iteration_equals_single_process_at_global_batch(tmp_path):
+@pytest.mark.parametrize("mode", ["f32", "x3v"])
+def test_two_rank_iteration_equals_single_process_at_global_batch(tmp_path, mode):
     """trainer.py:171-196 sharded by batch over 2 ranks (gloo, kernels on the host emulator) vs ONE process at the
-    global batch: per-sample InstanceNorm + mean-reduced losses make the averaged gradients identical."""
+    global batch: per-sample InstanceNorm + mean-reduced losses make the averaged gradients identical.
+    x3v -- the mode bench.py's `value` is timed in --: the gradient arenas carry the loss scale S through the exchange (AdamW
+    divides by it on the device, after the non-finite check every rank takes on the SUMMED arena: the ranks skip alike)."""
     world, port = 2, _free_port()
-    mp.spawn(_step_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    mp.spawn(_step_worker, args=(world, port, str(tmp_path), mode), nprocs=world, join=True)
     res = [torch.load(os.path.join(str(tmp_path), f"step_rank{r}.pt")) for r in range(world)]
     for k in ("g", "d"):
         assert torch.equal(res[0]["init"][k], res[1]["init"][k])
@@ -127,7 +135,9 @@ def test_two_rank_iteration_equals_single_process_at_global_batch(tmp_path):
     from backend import relerr2, select
     dev = select("emu")
     pkg = importlib.import_module("fast-srgan_amd")
-    T = _tiny_trainer(pkg, dev)
+    T = _tiny_trainer(pkg, dev, mode)
+    if mode == "x3v":      # both ranks kept the initial scale and skipped nothing; so does the single process
+        assert res[0]["scale"] == res[1]["scale"] == T.loss_scale_state() and res[0]["scale"][1] == 0
     with torch.no_grad():
         T.optim_generator.flat_param.copy_(res[0]["init"]["g"])
         T.optim_discriminator.flat_param.copy_(res[0]["init"]["d"])
