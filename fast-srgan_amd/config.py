@@ -2,7 +2,7 @@
 
 hydra / omegaconf are not dependencies; PyYAML reads the same file and the result is an attribute tree with
 the reference's 20 keys (configs/config.yaml:1-25) plus `generator.n_upsample` (default 2),
-`training.compute_dtype` (bf16 | f16 | x3 | x3v | f32; x3v = x3 Generator / Discriminator + fp16 frozen perceptual network: every loss and output still within 1e-3 of fp32, 31 % faster than x3; default f16 -- the 16-bit mode that tracks fp32 training best, profiles/r05_convergence.txt; x3 = split-bf16 operands, the fast mode whose forward outputs and losses sit inside the reference's 1e-3 fp32 tolerance -- its parameter gradients are 1.3x (G) / 2.8x (D) as far from float64 as the float32 reference's own), `training.vgg19_weights` (path of torchvision's vgg19
+`training.loss_scale` / `dynamic_loss_scale` / `loss_scale_growth_interval` / `loss_scale_growth` (fp16 and x3v: DESIGN 2c, 5), `training.compute_dtype` (bf16 | f16 | x3 | x3v | f32; x3v = x3 Generator / Discriminator + fp16 frozen perceptual network: every loss and output still within 1e-3 of fp32, 31 % faster than x3; default f16 -- the 16-bit mode that tracks fp32 training best, profiles/r05_convergence.txt; x3 = split-bf16 operands, the fast mode whose forward outputs and losses sit inside the reference's 1e-3 fp32 tolerance -- its parameter gradients are 1.3x (G) / 2.8x (D) as far from float64 as the float32 reference's own), `training.vgg19_weights` (path of torchvision's vgg19
 checkpoint), `training.allow_random_vgg` (tests / benchmarks only), `training.hip_graph` (replay the iteration as hipGraphs)
 and the fp16 loss scaler:
 

@@ -465,7 +465,7 @@ __global__ __launch_bounds__(NTHR64) void conv64_v2_kernel(const ConvKArgs a) {
             pp[n >> 1][(n & 1) * 2 + 1] = pack2<T>(v[2], v[3]);
           }
 #pragma unroll
-          for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f) + slope * fminf(v[r], 0.f);
+          for (int r = 0; r < 4; ++r) v[r] = act_slope(v[r], slope);       // (NaN-propagating: fsr_common.h)
           pk[n >> 1][(n & 1) * 2] = pack2<T>(v[0], v[1]);
           pk[n >> 1][(n & 1) * 2 + 1] = pack2<T>(v[2], v[3]);
         });

@@ -636,7 +636,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv_igemm_kernel(const ConvK
         }
         if (prep) store_vec4<ST>(prep + (base + m * rstride), v);
 #pragma unroll
-        for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f) + slope * fminf(v[r], 0.f);
+        for (int r = 0; r < 4; ++r) v[r] = act_slope(v[r], slope);       // (NaN-propagating: fsr_common.h)
         store_vec4<ST>(outp + (base + m * rstride), v);
       }
     });

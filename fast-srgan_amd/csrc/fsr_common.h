@@ -274,6 +274,12 @@ __device__ __forceinline__ f32x4 mfma_f32_16x16x4(float a, float b, f32x4 c) {
   return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
 }
 
+// v > 0 ? v : v * slope (ReLU: slope 0, identity: slope 1).  NOT max(v, 0) + slope * min(v, 0): v_max_f32 / v_min_f32 return the
+// non-NaN operand, so that form turns a NaN into 0 -- in a DATA-GRADIENT epilogue that silently zeroed the NaNs of an overflowed fp16
+// backward on their way to the optimizer's non-finite check (round 6: the x3v mode's fp16 perceptual branch; found by
+// tests/test_x3.py::test_x3v_overflow_in_the_fp16_perceptual_branch_skips_the_iteration).  Same result on every finite input.
+__device__ __forceinline__ float act_slope(float v, float slope) { return v > 0.f ? v : v * slope; }
+
 __device__ __forceinline__ float act_apply(float v, int act, float slope) {
   switch (act) {
     case FSR_ACT_RELU: return v > 0.f ? v : 0.f;

@@ -96,6 +96,14 @@ class Trainer:
             raise ValueError("training.loss_scale must be a positive finite number, got %r" % (self.loss_scale,))
         self.dynamic_loss_scale = bool(getattr(config.training, "dynamic_loss_scale", scaled))
         self.loss_scale_growth_interval = float(getattr(config.training, "loss_scale_growth_interval", 1000))
+        # Growth factor after `growth_interval` clean iterations: 2 when the TRAINED networks are fp16 (their own gradient arenas
+        # overflow first and bring the scale back down), 1 -- no growth -- in x3v, where only the frozen perceptual network is
+        # fp16: the x3 arenas share float32's range and would never report that the scale has outgrown fp16, so a growing scale
+        # would end in a perceptual backward that overflows every iteration (found in round 6).  An overflow that does reach an
+        # arena still skips the iteration and halves the scale.
+        self.loss_scale_growth = float(getattr(config.training, "loss_scale_growth", 2.0 if self.generator.compute.name == "f16" else 1.0))
+        if not self.loss_scale_growth >= 1.0:
+            raise ValueError("training.loss_scale_growth must be >= 1, got %r" % (self.loss_scale_growth,))
         if not self.loss_scale_growth_interval >= 1.0:
             raise ValueError("training.loss_scale_growth_interval must be >= 1, got %r" % (self.loss_scale_growth_interval,))
         self._scale_state = None
@@ -242,7 +250,7 @@ class Trainer:
     def _update_loss_scale(self):
         if self._scale_state is not None:
             from . import _lib as L
-            L.check(L.lib().fsr_loss_scale_update(ops._p(self._scale_state), self.loss_scale_growth_interval, 2.0, 0.5, ops._stream()),
+            L.check(L.lib().fsr_loss_scale_update(ops._p(self._scale_state), self.loss_scale_growth_interval, self.loss_scale_growth, 0.5, ops._stream()),
                     "fsr_loss_scale_update")
 
     def loss_scale_state(self):

@@ -275,6 +275,39 @@ def test_x3_train_step_vs_oracle(dev, mode):
         assert T.loss_scale_state()[1] == 0          # nothing overflowed: no skipped update
 
 
+def test_x3v_overflow_in_the_fp16_perceptual_branch_skips_the_iteration(dev):
+    """x3v under a loss scale that fp16 cannot carry (2^100: the content-loss seed alone overflows): the perceptual network's backward
+    produces inf / NaN, they reach the x3 generator's gradient arena, and the device-side check skips the generator's update of the
+    iteration, leaves its parameters, moments and step counter untouched and halves the scale -- the next iterations do the same
+    until the scale fits.  Nothing is poisoned for good.  (Until round 6 the NaNs never arrived: a data-gradient epilogue spelled
+    its activation max(v, 0) + slope * min(v, 0), which maps NaN to 0 -- fsr_common.h: act_slope.)"""
+    pkg = importlib.import_module("fast-srgan_amd")
+    torch.manual_seed(12)
+    cfg = ns(experiment=ns(name="t", seed=1234), generator=ns(n_filters=32, n_layers=1), discriminator=ns(n_filters=32, n_layers=7),
+             training=ns(compiled=False, device=str(dev), log_iter=1, checkpoint_iter=10 ** 9, generator_lr=1e-4, discriminator_lr=1e-4,
+                         batch_size=1, compute_dtype="x3v", loss_scale=2.0 ** 100))
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        T = pkg.Trainer(cfg, perceptual_network=pkg.VGG19(compute_dtype="x3v", width_div=2, seed=1234))
+    assert T.dynamic_loss_scale and T.loss_scale_state() == (2.0 ** 100, 0)
+    g0, d0 = T.optim_generator.flat_param.clone(), T.optim_discriminator.flat_param.clone()
+    lr, hr = torch.rand(1, 3, 8, 8) * 2 - 1, torch.rand(1, 3, 32, 32) * 2 - 1
+    noise = [torch.rand(1, 1, 2, 2) for _ in range(3)]
+    out = T.train_step(lr.to(dev), hr.to(dev), [t.to(dev) for t in noise])
+    assert all(torch.isfinite(v).all() for v in out.values())          # the LOSSES are forward quantities: finite
+    scale, skipped = T.loss_scale_state()
+    assert skipped == 1 and scale == 2.0 ** 99
+    # the generator -- the network the perceptual gradient flows into -- did not move: parameters, moments, step counter
+    assert torch.equal(T.optim_generator.flat_param, g0)
+    assert float(T.optim_generator.step_dev) == 0.0 and float(T.optim_generator.exp_avg.abs().sum()) == 0.0
+    # (the discriminator stepped earlier in the iteration, trainer.py:180, on its own finite x3 gradients -- correctly: the scale is
+    # divided out on the device; the shared flag only couples the other way, a D overflow also skipping G)
+    assert float(T.optim_discriminator.step_dev) == 1.0 and torch.isfinite(T.optim_discriminator.flat_param).all()
+    assert not torch.equal(T.optim_discriminator.flat_param, d0)
+    # x3v does not grow the scale (only an overflow moves it): 2^99 stays after clean iterations would have been counted
+    assert T.loss_scale_growth == 1.0
+
+
 @pytest.mark.parametrize("case", ["s1_relu_pool", "s1_stats", "s1_narrow_addend", "s1_narrow_stats", "s1_mask", "s2_stats", "s2_bias_leaky_mask", "rows12",
                                   "s1_ps_prelu_preact", "s2_narrow_stats"])
 def test_x3_conv_tall3_forms(dev, cd, case, monkeypatch):
