@@ -92,7 +92,7 @@ HOT_KERNELS = [k % dt for k in HOT_KERNELS for dt in ("bf16", "f16", "x3")] + [
     "conv_wgrad_kernel<bf16,128,64,1,8,true>", "conv_wgrad_kernel<bf16,128,64,2,4,true>",
 ]
 # kernels known to spill (cold: a generic x3 fallback configuration; the x3 up-sampling epilogue, 6 launches per iteration)
-SCRATCH_ALLOWED = {"conv_igemm_kernel<x3,8,128,2,2,64,2,1,0>": 96, "conv_tall3_kernel<x3,128,4,1,4,4,2,up>": 32}
+SCRATCH_ALLOWED = {"conv_igemm_kernel<x3,8,128,2,2,64,2,1,0>": 128, "conv_tall3_kernel<x3,128,4,1,4,4,2,up>": 32}
 
 
 def test_hot_kernels_do_not_spill():
