@@ -7,47 +7,37 @@
 A "step" is one full GAN training iteration (/root/reference/trainer.py:171-196: D step + G step with the VGG
 perceptual loss and both AdamW updates) over one synthetic batch that is already resident in HBM
 (BASELINE.json configs[2]: 8 residual blocks / 64 filters, batch 32 per GPU, 96x96 -> 384x384, random-init weights,
-kaiming-normal VGG19 stand-in).  `value` is timed in the x3 mode -- split-bf16 operands, three bf16 MFMAs per product, f32
-accumulation: the FASTEST mode whose outputs and losses sit inside north_star's 1e-3 relative fp32 tolerance (round-5 verdict,
-item 1b); the 16-bit modes (`--dtype f16` / `bf16`) and exact f32 are labelled legs.  N > 1 shards by batch (weak scaling):
-one process per GPU, two RCCL gradient all-reduces per step; `python bench.py --gpus N` without a launcher
-re-executes itself under torch.distributed.run.
+kaiming-normal VGG19 stand-in).  `value` is timed in the x3v mode -- Generator and Discriminator in x3 (split-bf16 operands, three
+bf16 MFMAs per product, f32 accumulation), the FROZEN perceptual network in fp16: the FASTEST mode whose outputs and four losses sit
+inside north_star's 1e-3 relative fp32 tolerance (round-5 verdict, item 1b) --; pure x3, the 16-bit modes
+(`--dtype f16` / `bf16`) and exact f32 are labelled legs.  N > 1 shards by batch (weak scaling): one process per GPU, two RCCL
+gradient all-reduces per step; `python bench.py --gpus N` without a launcher re-executes itself under torch.distributed.run.
 
-Rank 0 prints ONE LEAN JSON line on stdout (lean_line(): < 6 KB -- the driver keeps the last 8 KB of stdout, and round 5's
-25 KB line did not parse there) and writes the FULL object to bench_detail.json (gpurun_out/ when that directory exists,
-else next to this file).  The lean line carries the contract keys, the dominant kernel's `roofline` (with `traffic`),
-`cpu_baseline`, and one scalar per leg under `legs`.
+Rank 0 prints ONE LEAN JSON line on stdout (lean_line(): 3 KB, hard limit 6 KB -- the driver keeps the last 8 KB of stdout, and
+round 5's 25 KB line did not parse there) and writes the FULL object to bench_detail.json (gpurun_out/ when that directory exists,
+else next to this file; --detail PATH).  The lean line carries the contract keys, the dominant kernel's `roofline` (with `traffic`),
+`cpu_baseline`, and one scalar per leg.
 
-Keys of the full object (bench_detail.json):
-  roofline      the DOMINANT kernel of the iteration (the kernel symbol with the largest share of its time: the tall implicit-GEMM
-                3x3 convolution configuration): algorithmic FLOPs per launch / its average launch duration, measured with HIP events
-                on the launch stream during an instrumented single-stream step, against the dense MFMA peak; `traffic` = HBM bytes
-                per launch of that kernel from the rocprofv3 PMC passes recorded in profiles/conv_traffic.json (null when that
-                file does not belong to the kernel sources being run); `lds_fed_mfma_ceiling` = the same rate against what a bare
-                LDS-fed MFMA loop of this wave tile reaches (micro-benchmark); `family` repeats the figures for ALL conv forward +
-                data-gradient launches together; `kernels` lists every kernel configuration against both the MFMA and the HBM roof;
-  x3_mode       the same iteration in the x3 mode (split-bf16 operands: hi = bf16(v), lo = bf16(v - hi), three bf16 MFMAs per product
-                into one f32 accumulator) -- the FAST mode inside north_star's 1e-3 tolerance -- same --steps /
-                --warmup, its own `roofline` against the bf16 MFMA peak over 3;
-  bf16_mode     the same iteration in bf16 (the headline dtype of rounds 1-4), for continuity;
-  f32_mode      the same iteration in the exact-f32 MFMA parity mode -- the precision the reference computes in and the mode that
-                meets north_star's 1e-3 tolerance -- timed with the SAME --steps / --warmup, with its own `roofline` against the
-                157.3 TFLOP/s f32 MFMA peak;
-  sustained     (default run only) >= 5 s of back-to-back steps in each mode with the shader clock sampled from sysfs
-                (pp_dpm_sclk of this GPU) during the timed region: the steady-state rate a 20-step burst may flatter;
+Keys of the full object (bench_detail.json; DESIGN.md section 4 describes each):
+  roofline      the DOMINANT kernel of the iteration (the kernel symbol with the largest share of its time): algorithmic FLOPs per
+                launch / its average launch duration from HIP events on the launch stream of an instrumented single-stream step,
+                against the dense MFMA peak of ITS arithmetic (kernel_peak: x3 launches 2500 / 3, fp16 / bf16 2500, f32 157.3 TFLOP/s);
+                `traffic` = HBM bytes per launch of that kernel from the rocprofv3 PMC passes recorded in
+                profiles/conv_traffic[_x3|_x3v].json (null when that file does not belong to the kernel sources being run);
+                `family` = ALL conv forward + data-gradient launches together; `kernels` = every configuration against both roofs;
+  x3_mode, f16_mode, bf16_mode, f32_mode
+                the same iteration in the other compute modes, each with the SAME --steps / --warmup and its own `roofline`;
+  sustained     >= --sustained-seconds of back-to-back steps of the headline mode with the shader clock sampled from sysfs;
   cpu_baseline  the oracle's CPU restatement of the same iteration AND of generator inference at 90x160 / 180x320 (BASELINE.md
-                section 3: "inference + one G/D step"), timed on the host cores (N=1, rank 0); `cores` = threads used,
-                `host_cores` = what the box has;
-  cfg5          (default N = 1 run) BASELINE configs[4] as a measured configuration: 12 residual blocks, three pixel-shuffle stages,
-                128x128 -> 1024x1024, fp16 MFMA with the dynamic loss scale, batch 4 on this GPU, >= 100 steps and >= 5 s of hipGraph
-                replays, with its own roofline (`python bench.py --workload cfg5` prints the same workload as the main line);
-  allreduce     (a process group exists) ms per step the main stream spends in the two RCCL gradient exchanges, from HIP events
-                around each (10 extra steps outside the timed region), per exchange and as the maximum over ranks;
-  inference     generator-only FPS at 90x160 and 180x320 (BASELINE.json configs[1]), batch 1 and batch 32, every leg >= 5 s with the
-                shader clock sampled, in the default mode (top level, `dtype`) and under `modes` in x3 and exact f32 (`--inference-dtypes
-                f16,bf16,x3,f32` adds bf16, BASELINE configs[1]'s dtype: within 2 % of fp16, profiles/r05_bench_n1.json.log), each with the
-                `roofline` of its forward's dominant kernel; plus the end-to-end rate of the uint8 frame pipeline (host bytes -> H2D ->
-                G -> uint8 epilogue -> D2H): median of five warm passes, min / max under `e2e_spread`.
+                section 3), on FSR_CPU_THREADS (default 16: the fastest of profiles/r06_cpu_threads.txt) host threads (N=1, rank 0);
+  cfg5          (default N = 1 run) BASELINE configs[4]: 12 residual blocks, three pixel-shuffle stages, 128x128 -> 1024x1024, fp16
+                MFMA with the dynamic loss scale, batch 4 on this GPU, >= 100 steps and >= 3 s of hipGraph replays, its own roofline;
+  allreduce     (a process group exists) ms per step the main stream spends in the two RCCL gradient exchanges, per exchange and
+                as the maximum over ranks;
+  inference     generator-only FPS at 90x160 and 180x320 (BASELINE.json configs[1]), batch 1 and batch 32, every leg >=
+                --inference-seconds with the clock sampled, in the headline's generator mode (x3) and under `modes` in fp16, bf16 and
+                exact f32, each with the `roofline` of its forward's dominant kernel; plus the end-to-end rate of the uint8 frame
+                pipeline in fp16 (host bytes -> H2D -> G -> uint8 epilogue -> D2H): median of three warm passes.
 """
 import argparse
 import hashlib
